@@ -1,0 +1,202 @@
+/*
+ * panoptic_hip.h -- C-ABI of libpanoptic_hip.so, the MI355X (gfx950) implementation of the
+ * panoptic hot path of prs-eth/PanopticSegForLargeScalePointCloud.
+ *
+ * The reference has no FFI of its own: its hot path calls third-party native libraries through
+ * Python.  Each entry point below replaces one of those call sites; the
+ * "replaces:" line names the reference file:line (relative to the reference tree) whose native call
+ * it stands in for.  All pointers are raw DEVICE pointers unless marked "host"; sizes are element
+ * counts; every function enqueues on `stream` (a hipStream_t passed as void*) and returns a status
+ * code.  No ownership is transferred, nothing is allocated behind the caller's back: functions
+ * that need scratch take a workspace whose size the matching *_workspace() call reports.
+ *
+ * Conventions
+ *   coords      int32 [n,4] rows (batch, x, y, z)  -- the layout BaseMinkowski._set_input builds
+ *               (torch_points3d/applications/minkowski.py:121).
+ *   hash table  open addressing, `cap` = pp_hash_capacity(n) slots: keys uint64[cap], vals int32[cap].
+ *   kernel map  int32 nbr[K][n_out]  (offset-major; -1 = no neighbour); K = 27 for 3x3x3, offset index
+ *               k = (dx+1) + 3(dy+1) + 9(dz+1).
+ *   features    float32 row-major [n, C].
+ *   weights     "ME layout" float32 [K, Cin, Cout] (MinkowskiConvolution.kernel), packed once per
+ *               weight update into MFMA fragment order by pp_pack_weight.
+ */
+#ifndef PANOPTIC_HIP_H
+#define PANOPTIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pp_stream_t; /* hipStream_t */
+
+enum {
+  PP_OK = 0,
+  PP_ERR_INVALID = 1,  /* bad argument (null pointer, unsupported size) */
+  PP_ERR_RANGE = 2,    /* coordinate/batch index not representable in the 64-bit key */
+  PP_ERR_HIP = 3,      /* a HIP runtime call failed; see pp_last_error() */
+  PP_ERR_WORKSPACE = 4 /* workspace too small */
+};
+
+/* Library identity / diagnostics.  pp_version: "panoptic_hip <n> gfx950". */
+const char* pp_version(void);
+const char* pp_last_error(void);
+/* Device-side triad (a[i] = b[i] + s*c[i]) used by bench.py to confirm the HBM roofline denominator. */
+int pp_triad(float* a, const float* b, const float* c, float s, int64_t n, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  coordinate hash            replaces: ME.SparseTensor(features, coordinates) coordinate-map insert,
+ *                                torch_points3d/applications/minkowski.py:121-122
+ * info[0] = rows whose coordinate already existed (duplicates), info[1] = rows outside key range.
+ * vals[slot] = smallest row index holding that coordinate.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t pp_hash_capacity(int64_t n);
+int pp_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
+                  int32_t* info /*int32[2]*/, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  strided output coordinates  replaces: MinkowskiConvolution(stride=2) output-map generation,
+ *                                 torch_points3d/modules/MinkowskiEngine/api_modules.py:256-271
+ * out_coords = unique(floor(c / ts_out) * ts_out) per batch, ordered by first appearance in `coords`.
+ * On return (keys, vals) hash the OUTPUT coordinates (vals = output row), n_out[0] = #output rows,
+ * fine_to_coarse[i] = output row of input row i (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_stride_coords_workspace(int64_t n);
+int pp_stride_coords(const int32_t* coords, int64_t n, int32_t ts_out, uint64_t* keys, int32_t* vals,
+                     int64_t cap, int32_t* out_coords /*[n,4] capacity*/, int32_t* n_out /*int32[1]*/,
+                     int32_t* fine_to_coarse, void* workspace, size_t workspace_bytes,
+                     int32_t* info /*int32[2]*/, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  kernel map (rulebook)       replaces: ME kernel-map build inside every MinkowskiConvolution /
+ *                                 MinkowskiConvolutionTranspose, api_modules.py:30-51,259-267
+ * nbr[k][o] = row (in the map hashed by keys/vals) of  out_coords[o] + sign * offset_k * step,  or -1.
+ * sign=+1: convolution (stride 1: step = tensor stride; stride 2: step = input tensor stride).
+ * sign=-1: transposed convolution (mirrored offsets; with a coarse input map this is ME's swapped map).
+ * ksize in {1,3}; ksize==1 ignores step/sign (pure coordinate lookup).
+ * ---------------------------------------------------------------------------------------------- */
+int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys, const int32_t* vals,
+                  int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr,
+                  pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  sparse convolution forward  replaces: ME ConvolutionForward (gather-GEMM-scatter per offset),
+ *                                 api_modules.py:30-51 ; K6 folded BN + ReLU epilogue api_modules.py:40-41 ;
+ *                                 K7 ME.cat fused as a second source, api_modules.py:308
+ * out[o] = epilogue( sum_k  [in0 | in1][nbr[k][o]] . W_k )
+ * epilogue(v) = relu?( v * scale + shift ) + residual      (scale/shift/residual may be NULL)
+ * nbr == NULL with K == 1: identity map (1x1 convolution, n_out rows in == rows out).
+ * transpose_w: 0 -> packed[k] = W_k (Cin x Cout);  1 -> packed[k] = W_k^T (used for input gradients).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout);
+int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin, int32_t cout,
+                   int32_t transpose_w, float* packed, pp_stream_t stream);
+int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
+                  const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
+                  const float* shift, int32_t relu, const float* residual, float* out,
+                  pp_stream_t stream);
+
+/* K5  weight gradient             replaces: ME ConvolutionBackward (dW part), reached from
+ *                                 loss.backward(), torch_points3d/models/panoptic/PointGroup3heads.py:636-639
+ * dw[k] (+)= sum_o in[nbr[k][o]]^T . dout[o]          dw is float32 [K,cin,cout], zeroed by the callee. */
+int pp_spconv_bwd_weight(const float* in, int32_t cin, const float* dout, int32_t cout,
+                         const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  batch-norm pieces on [n,C]  replaces: ME.MinkowskiBatchNorm (= BatchNorm1d on F), api_modules.py:40,53,269
+ * pp_channel_stats: sum[c], sumsq[c] in float64 (training-mode statistics; two-pass inside).
+ * pp_affine_act   : y = act(x*scale + shift) + residual; act: 0 none, 1 relu, 2 leaky(slope).
+ * pp_bn_bwd_reduce: per-channel sum(dy), sum(dy * x) (float64) for the BN backward.
+ * ---------------------------------------------------------------------------------------------- */
+int pp_channel_stats(const float* x, int64_t n, int32_t c, double* sum, double* sumsq, pp_stream_t stream);
+int pp_affine_act(const float* x, int64_t n, int32_t c, const float* scale, const float* shift,
+                  int32_t act, float slope, const float* residual, float* y, pp_stream_t stream);
+int pp_bn_bwd_reduce(const float* x, const float* dy, int64_t n, int32_t c, double* sum_dy,
+                     double* sum_dy_x, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heads                           replaces: Semantic/Offset/Embed MLP heads in eval mode,
+ *                                 PointGroup3heads.py:69-81,106-108 ; core/common_modules/base_modules.py:35-45
+ * y = W2 . leaky_relu_0.2( (W1 . x) * scale + shift ) + b2 ; optional log-softmax; optional argmax out.
+ * x [n,cin], W1 [chid,cin] (torch Linear layout), W2 [cout,chid]; cin,chid <= 32, cout <= 32.
+ * ---------------------------------------------------------------------------------------------- */
+int pp_head_mlp(const float* x, int64_t n, int32_t cin, const float* w1, int32_t chid, const float* scale,
+                const float* shift, const float* w2, const float* b2, int32_t cout, int32_t log_softmax,
+                float* y, int64_t* argmax /*may be NULL*/, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8+K9 region growing            replaces: torch_points_kernels.region_grow (ball_query PARTIAL_DENSE +
+ *                                 sequential DFS), call sites PointGroup3heads.py:166-174,185-205,296-304,340-357
+ * Exact semantics of SURVEY.md App. C incl. neighbour-list truncation at nsample (lowest indices first):
+ * a point's cluster = the smallest-index point that reaches it through directed neighbour-list edges.
+ * Clusters ordered by (class ascending, seed index ascending); points ascending inside a cluster.
+ * counts[0] = #clusters, counts[1] = #points in clusters.  num_classes > max(labels).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_region_grow_workspace(int64_t n, int32_t nsample);
+int pp_region_grow(const float* pos /*[n,3]*/, const int64_t* labels, const int64_t* batch, int64_t n,
+                   const int64_t* ignore_labels, int32_t n_ignore, int32_t num_classes, int32_t nsample,
+                   float radius, int32_t min_cluster_size, int32_t* point_cluster /*[n]*/,
+                   int32_t* cluster_offsets /*[n+1] capacity*/, int64_t* cluster_points /*[n] capacity*/,
+                   int32_t* counts /*int32[2]*/, void* workspace, size_t workspace_bytes,
+                   pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K12 flat-kernel mean shift      replaces: sklearn MeanShift(bandwidth, bin_seeding=True).fit(X).labels_
+ *                                 via torch_points3d/utils/meanshift_cluster.py:9-18,72-123
+ * Points of sample s are rows sample_offsets[s]..sample_offsets[s+1]-1 (host array).  Samples with
+ * <= min_points_exclusive (reference: 3) points get label -1 and 0 clusters.
+ * labels[i] = cluster id inside its sample (rank in sklearn's (count, centre) descending order).
+ * centers: float32 [m, dim] capacity, rows packed per sample at the sample's point offset (optional).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_meanshift_workspace(int64_t m, int32_t dim, int32_t n_samples);
+int pp_meanshift(const float* x /*[m,dim]*/, int64_t m, int32_t dim, const int64_t* sample_offsets /*host*/,
+                 int32_t n_samples, float bandwidth, int32_t min_points_exclusive, int32_t max_iter,
+                 int32_t* labels /*[m]*/, int32_t* n_clusters /*[n_samples]*/, float* centers,
+                 void* workspace, size_t workspace_bytes, pp_stream_t stream);
+
+/* Group points by a small integer key into CSR form (stable: ascending point order inside a group).
+ * key[i] in [0,n_groups) or -1 (dropped).  ids[i] (int64) is what gets written (NULL -> i).
+ * offsets [n_groups+1], out [n] capacity, total[0] = #kept.  Used to turn labels into the
+ * List[LongTensor] the reference APIs return (meanshift_cluster.py:102-111). */
+size_t pp_group_by_key_workspace(int64_t n);
+int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n, int32_t n_groups, int32_t* offsets,
+                    int64_t* out, int32_t* total, void* workspace, size_t workspace_bytes,
+                    pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K11 segment reductions          replaces: torch_scatter.scatter(src, index, dim=0, reduce=...),
+ *                                 PointGroup3heads.py:419-452 ; core/losses/panoptic_losses.py:260,276
+ * reduce: 0 sum, 1 mean, 2 max.  index int64 [n] in [0,n_seg).  out [n_seg,c]; empty segments -> 0.
+ * arg (int64 [n_seg,c], may be NULL) receives the arg-max row for reduce=2 (needed by its backward).
+ * ---------------------------------------------------------------------------------------------- */
+int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
+                      int32_t reduce, float* out, int64_t* arg, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K10 instance IoU                replaces: torch_points_kernels.instance_iou,
+ *                                 core/losses/panoptic_losses.py:37 ; metrics/panoptic_tracker_pointgroup_npm3d.py:681
+ * Proposals in CSR (offsets int32 [n_prop+1], points int64).  gt_instances int64 [n] (0 = none, ids 1..k
+ * per batch element), gt_offsets int32 [n_batch+1] = cumsum of per-sample GT counts (device),
+ * gt_sizes int32 [total_gt] (device).  iou float32 [n_prop, total_gt] (zeroed by the callee).
+ * ---------------------------------------------------------------------------------------------- */
+int pp_instance_iou(const int32_t* prop_offsets, const int64_t* prop_points, int32_t n_prop,
+                    const int64_t* gt_instances, const int64_t* batch, const int32_t* gt_offsets,
+                    const int32_t* gt_sizes, int32_t total_gt, float* iou, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K14 proposal x proposal intersections   replaces: dense torch.mm(mask, mask^T) in
+ *                                 PanopticResults.get_instances, models/panoptic/structure_3heads.py:40-60
+ * inter int32 [n_prop, n_prop] (zeroed by the callee) from the point->proposal incidence;
+ * n_points = size of the point index space.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_proposal_intersections_workspace(int64_t total_points, int64_t n_points);
+int pp_proposal_intersections(const int32_t* prop_offsets, const int64_t* prop_points, int32_t n_prop,
+                              int64_t n_points, int32_t* inter, void* workspace, size_t workspace_bytes,
+                              pp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANOPTIC_HIP_H */

@@ -1,0 +1,254 @@
+"""NumPy front-end of the CPU oracle (oracle/panoptic_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package never imports this module.  See the header of panoptic_oracle.c for what is pinned
+against the reference and what is not ("parity unpinned" for the MinkowskiEngine / torch-points-kernels
+pieces: the reference ships no vectors and those libraries are absent).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpanoptic_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "panoptic_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpanoptic_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed with status %d" % (name, rc))
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+
+
+# ------------------------------------------------------------------ coordinates
+def hash_first_rows(coords):
+    coords = _i32(coords)
+    n = coords.shape[0]
+    first = np.empty(n, np.int64)
+    ndup = C.c_int64(0)
+    _chk(lib().ppo_hash_first_rows(_p(coords), C.c_int64(n), _p(first), C.byref(ndup)), "hash_first_rows")
+    return first, ndup.value
+
+
+def stride_coords(coords, ts_out):
+    coords = _i32(coords)
+    n = coords.shape[0]
+    out = np.empty((max(n, 1), 4), np.int32)
+    f2c = np.empty(max(n, 1), np.int32)
+    n_out = C.c_int64(0)
+    _chk(lib().ppo_stride_coords(_p(coords), C.c_int64(n), C.c_int32(ts_out), _p(out), C.byref(n_out), _p(f2c)),
+         "stride_coords")
+    return out[: n_out.value].copy(), f2c[:n].copy()
+
+
+def kernel_map(out_coords, in_coords, ksize, step, sign):
+    out_coords = _i32(out_coords)
+    in_coords = _i32(in_coords)
+    K = ksize ** 3
+    nbr = np.empty((K, out_coords.shape[0]), np.int32)
+    _chk(lib().ppo_kernel_map(_p(out_coords), C.c_int64(out_coords.shape[0]), _p(in_coords),
+                              C.c_int64(in_coords.shape[0]), C.c_int32(ksize), C.c_int32(step), C.c_int32(sign),
+                              _p(nbr)), "kernel_map")
+    return nbr
+
+
+# ------------------------------------------------------------------ convolution
+def spconv_fwd(in0, weight, nbr, n_out, in1=None, scale=None, shift=None, relu=False, residual=None):
+    in0 = _f32(in0)
+    in1 = _f32(in1)
+    weight = _f32(weight)
+    if weight.ndim == 2:
+        weight = weight[None]
+    K, cin, cout = weight.shape
+    c0 = in0.shape[1]
+    c1 = 0 if in1 is None else in1.shape[1]
+    assert c0 + c1 == cin
+    nbr = _i32(nbr)
+    out = np.empty((n_out, cout), np.float32)
+    _chk(lib().ppo_spconv_fwd(_p(in0), C.c_int32(c0), _p(in1), C.c_int32(c1), _p(weight), _p(nbr), C.c_int32(K),
+                              C.c_int64(n_out), C.c_int32(cout), _p(_f32(scale)), _p(_f32(shift)),
+                              C.c_int32(int(relu)), _p(_f32(residual)), _p(out)), "spconv_fwd")
+    return out
+
+
+def spconv_bwd(inp, dout, weight, nbr, want_din=True, want_dw=True):
+    inp = _f32(inp)
+    dout = _f32(dout)
+    weight = _f32(weight)
+    if weight.ndim == 2:
+        weight = weight[None]
+    K, cin, cout = weight.shape
+    n_in = inp.shape[0]
+    n_out = dout.shape[0]
+    nbr = _i32(nbr)
+    din = np.empty((n_in, cin), np.float32) if want_din else None
+    dw = np.empty((K, cin, cout), np.float32) if want_dw else None
+    _chk(lib().ppo_spconv_bwd(_p(inp), C.c_int32(cin), C.c_int64(n_in), _p(dout), C.c_int32(cout), _p(weight),
+                              _p(nbr), C.c_int32(K), C.c_int64(n_out), _p(din), _p(dw)), "spconv_bwd")
+    return din, dw
+
+
+def channel_stats(x):
+    x = _f32(x)
+    n, c = x.shape
+    s = np.empty(c, np.float64)
+    ss = np.empty(c, np.float64)
+    _chk(lib().ppo_channel_stats(_p(x), C.c_int64(n), C.c_int32(c), _p(s), _p(ss)), "channel_stats")
+    return s, ss
+
+
+def affine_act(x, scale=None, shift=None, act=0, slope=0.0, residual=None):
+    x = _f32(x)
+    n, c = x.shape
+    y = np.empty_like(x)
+    _chk(lib().ppo_affine_act(_p(x), C.c_int64(n), C.c_int32(c), _p(_f32(scale)), _p(_f32(shift)), C.c_int32(act),
+                              C.c_float(slope), _p(_f32(residual)), _p(y)), "affine_act")
+    return y
+
+
+def head_mlp(x, w1, scale, shift, w2, b2, log_softmax=False, want_argmax=False):
+    x = _f32(x)
+    w1 = _f32(w1)
+    w2 = _f32(w2)
+    n, cin = x.shape
+    chid = w1.shape[0]
+    cout = w2.shape[0]
+    y = np.empty((n, cout), np.float32)
+    am = np.empty(n, np.int64) if want_argmax else None
+    _chk(lib().ppo_head_mlp(_p(x), C.c_int64(n), C.c_int32(cin), _p(w1), C.c_int32(chid), _p(_f32(scale)),
+                            _p(_f32(shift)), _p(w2), _p(_f32(b2)), C.c_int32(cout), C.c_int32(int(log_softmax)),
+                            _p(y), _p(am)), "head_mlp")
+    return (y, am) if want_argmax else y
+
+
+# ------------------------------------------------------------------ clustering
+def region_grow(pos, labels, batch, ignore_labels=(), nsample=16, radius=0.02, min_cluster_size=32):
+    """Returns list of int64 index arrays (ascending inside a cluster; reference order of clusters)."""
+    pos = _f32(pos)
+    labels = _i64(labels)
+    batch = _i64(batch)
+    ign = _i64(np.asarray(list(ignore_labels), dtype=np.int64))
+    n = pos.shape[0]
+    pc = np.empty(max(n, 1), np.int32)
+    offs = np.empty(n + 2, np.int32)
+    pts = np.empty(max(n, 1), np.int64)
+    counts = np.zeros(2, np.int32)
+    _chk(lib().ppo_region_grow(_p(pos), _p(labels), _p(batch), C.c_int64(n), _p(ign), C.c_int32(ign.shape[0]),
+                               C.c_int32(nsample), C.c_float(radius), C.c_int32(min_cluster_size), _p(pc), _p(offs),
+                               _p(pts), _p(counts)), "region_grow")
+    nc = int(counts[0])
+    return [pts[offs[i]: offs[i + 1]].copy() for i in range(nc)], pc[:n].copy()
+
+
+def meanshift(x, sample_offsets, bandwidth, min_points_exclusive=3, max_iter=300):
+    x = _f32(x)
+    m, dim = x.shape
+    so = _i64(sample_offsets)
+    ns = so.shape[0] - 1
+    labels = np.empty(max(m, 1), np.int32)
+    ncl = np.zeros(max(ns, 1), np.int32)
+    centers = np.zeros((max(m, 1), dim), np.float32)
+    _chk(lib().ppo_meanshift(_p(x), C.c_int64(m), C.c_int32(dim), _p(so), C.c_int32(ns), C.c_float(bandwidth),
+                             C.c_int32(min_points_exclusive), C.c_int32(max_iter), _p(labels), _p(ncl),
+                             _p(centers)), "meanshift")
+    return labels[:m].copy(), ncl[:ns].copy(), centers
+
+
+def group_by_key(key, n_groups, ids=None):
+    key = _i32(key)
+    n = key.shape[0]
+    offs = np.empty(n_groups + 1, np.int32)
+    out = np.empty(max(n, 1), np.int64)
+    total = C.c_int32(0)
+    _chk(lib().ppo_group_by_key(_p(key), _p(_i64(ids)), C.c_int64(n), C.c_int32(n_groups), _p(offs), _p(out),
+                                C.byref(total)), "group_by_key")
+    return offs, out[: total.value].copy()
+
+
+def segment_reduce(src, index, n_seg, reduce):
+    src = _f32(src)
+    index = _i64(index)
+    n, c = src.shape
+    code = {"sum": 0, "add": 0, "mean": 1, "max": 2}[reduce]
+    out = np.empty((n_seg, c), np.float32)
+    arg = np.empty((n_seg, c), np.int64)
+    _chk(lib().ppo_segment_reduce(_p(src), _p(index), C.c_int64(n), C.c_int32(c), C.c_int64(n_seg), C.c_int32(code),
+                                  _p(out), _p(arg)), "segment_reduce")
+    return out, arg
+
+
+def clusters_to_csr(clusters):
+    offs = np.zeros(len(clusters) + 1, np.int32)
+    for i, c in enumerate(clusters):
+        offs[i + 1] = offs[i] + len(c)
+    pts = np.concatenate([np.asarray(c, np.int64) for c in clusters]) if clusters else np.zeros(0, np.int64)
+    return offs, _i64(pts)
+
+
+def gt_layout(gt_instances, batch):
+    """Per-sample GT counts / sizes in the layout torch_points_kernels.instance_iou uses."""
+    gt_instances = _i64(gt_instances)
+    batch = _i64(batch)
+    nb = int(batch.max()) + 1 if batch.size else 0
+    gt_off = np.zeros(nb + 1, np.int32)
+    sizes = []
+    for b in range(nb):
+        g = gt_instances[batch == b]
+        k = int(g.max()) if g.size else 0
+        gt_off[b + 1] = gt_off[b] + k
+        for i in range(1, k + 1):
+            sizes.append(int((g == i).sum()))
+    return gt_off, np.asarray(sizes, np.int32)
+
+
+def instance_iou(clusters, gt_instances, batch):
+    offs, pts = clusters_to_csr(clusters)
+    gt_off, gt_sizes = gt_layout(gt_instances, batch)
+    total_gt = int(gt_off[-1])
+    iou = np.zeros((len(clusters), max(total_gt, 1)), np.float32)
+    _chk(lib().ppo_instance_iou(_p(offs), _p(pts), C.c_int32(len(clusters)), _p(_i64(gt_instances)), _p(_i64(batch)),
+                                _p(gt_off), _p(gt_sizes), C.c_int32(total_gt), _p(iou)), "instance_iou")
+    return iou[:, :total_gt]
+
+
+def proposal_intersections(clusters, n_points):
+    offs, pts = clusters_to_csr(clusters)
+    n = len(clusters)
+    inter = np.zeros((n, n), np.int32)
+    _chk(lib().ppo_proposal_intersections(_p(offs), _p(pts), C.c_int32(n), C.c_int64(n_points), _p(inter)),
+         "proposal_intersections")
+    return inter

@@ -1,0 +1,182 @@
+"""Generates the committed golden fixtures in tests/golden/ by running the REFERENCE's own Python
+(importable pieces only) in the build container.  Run:  python tests/golden/make_golden.py
+
+Not needed at test time -- /root/reference does not exist on the GPU box; only the .npz files travel.
+What it pins:
+  meanshift_cases.npz  <- torch_points3d/utils/meanshift_cluster.py:9-18  (sklearn MeanShift, bin_seeding)
+  loss_cases.npz       <- torch_points3d/core/losses/panoptic_losses.py (offset_loss, discriminative_loss,
+                          instance_iou_loss) imported by file path with stub third-party modules
+  nms_cases.npz        <- torch_points3d/models/panoptic/structure_3heads.py get_instances / NMS
+                          (Tensor.cuda patched to identity)
+Fixtures hold inputs and expected outputs only (no reference source text).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PP_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def canon(labels):
+    """relabel by first appearance so partitions compare bit-exactly"""
+    labels = np.asarray(labels)
+    out = np.full(labels.shape, -1, np.int64)
+    seen = {}
+    for i, l in enumerate(labels.tolist()):
+        if l < 0:
+            continue
+        if l not in seen:
+            seen[l] = len(seen)
+        out[i] = seen[l]
+    return out
+
+
+def blobs(rng, n, dim, n_inst, spread=3.0, sigma=0.15):
+    cen = rng.normal(0, spread, size=(n_inst, dim))
+    ids = rng.integers(0, n_inst, size=n)
+    x = cen[ids] + rng.normal(0, sigma, size=(n, dim))
+    return x.astype(np.float32), ids
+
+
+def make_meanshift():
+    ms = _load(os.path.join(REF, "torch_points3d/utils/meanshift_cluster.py"), "ref_meanshift_cluster")
+    rng = np.random.default_rng(2022)
+    cases = {}
+    specs = [("a", 2000, 5, 12, 0.6), ("b", 2000, 5, 30, 0.6), ("c", 1500, 5, 6, 0.6), ("d3", 1200, 3, 8, 0.6),
+             ("wide", 1500, 5, 10, 1.0)]
+    for name, n, dim, k, bw in specs:
+        x, _ = blobs(rng, n, dim, k)
+        lab = ms.meanshift_cluster(x, bw).numpy()
+        cases["x_" + name] = x
+        cases["bw_" + name] = np.float32(bw)
+        cases["labels_" + name] = lab.astype(np.int64)
+    # degenerate: 4 points (the smallest sample the wrapper clusters: > 3 points)
+    x = np.array([[0, 0, 0, 0, 0], [0.1, 0, 0, 0, 0], [5, 5, 5, 5, 5], [5.1, 5, 5, 5, 5]], np.float32)
+    cases["x_tiny"] = x
+    cases["bw_tiny"] = np.float32(0.6)
+    cases["labels_tiny"] = ms.meanshift_cluster(x, 0.6).numpy().astype(np.int64)
+    # every point its own bin -> "using data points as seeds" branch
+    x = (rng.normal(0, 20, size=(40, 5))).astype(np.float32)
+    cases["x_sparse"] = x
+    cases["bw_sparse"] = np.float32(0.6)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cases["labels_sparse"] = ms.meanshift_cluster(x, 0.6).numpy().astype(np.int64)
+    cases["names"] = np.array([s[0] for s in specs] + ["tiny", "sparse"])
+    np.savez_compressed(os.path.join(OUT, "meanshift_cases.npz"), **cases)
+    print("meanshift:", {k: int(cases["labels_" + k].max()) + 1 for k in cases["names"]})
+
+
+def _stub_modules():
+    tpk = types.ModuleType("torch_points_kernels")
+
+    def instance_iou(clusters, gt, batch):
+        # brute-force definition -- only used to produce golden values
+        nb = int(batch.max()) + 1
+        ks = [int(gt[batch == b].max()) for b in range(nb)]
+        off = np.concatenate([[0], np.cumsum(ks)])
+        out = torch.zeros(len(clusters), int(off[-1]))
+        for p, c in enumerate(clusters):
+            b = int(batch[c[0]])
+            for g in range(1, ks[b] + 1):
+                gm = (gt == g) & (batch == b)
+                inter = int((gt[c] == g).sum())
+                out[p, off[b] + g - 1] = inter / float(len(c) + int(gm.sum()) - inter)
+        return out
+
+    tpk.instance_iou = instance_iou
+    sys.modules["torch_points_kernels"] = tpk
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter(src, index, dim=0, reduce="sum"):
+        n = int(index.max()) + 1
+        shape = (n,) + tuple(src.shape[1:])
+        idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        red = {"sum": "sum", "add": "sum", "mean": "mean", "max": "amax"}[reduce]
+        return torch.zeros(shape, dtype=src.dtype).scatter_reduce(0, idx, src, red, include_self=False)
+
+    ts.scatter = scatter
+    sys.modules["torch_scatter"] = ts
+    nb = types.ModuleType("numba")
+    nb.prange = range
+    sys.modules["numba"] = nb
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def make_losses():
+    _stub_modules()
+    L = _load(os.path.join(REF, "torch_points3d/core/losses/panoptic_losses.py"), "ref_panoptic_losses")
+    g = torch.Generator().manual_seed(0)
+    n = 1000
+    batch = torch.cat([torch.zeros(n // 2), torch.ones(n - n // 2)]).long()
+    inst = torch.randint(0, 6, (n,), generator=g)  # 0 = no instance, 1..5
+    pred_off = torch.randn(n, 3, generator=g)
+    gt_off = torch.randn(n, 3, generator=g)
+    embed = torch.randn(n, 5, generator=g)
+    mask = inst > 0
+    ol = L.offset_loss(pred_off[mask], gt_off[mask], int(mask.sum()))
+    dl = L.discriminative_loss(embed[mask], inst[mask], batch[mask], 5)
+    # proposals: 12 random subsets inside one batch element each
+    clusters = []
+    for p in range(12):
+        b = p % 2
+        pool = torch.nonzero(batch == b).view(-1)
+        sel = pool[torch.randperm(pool.numel(), generator=g)[: 30 + 5 * p]]
+        clusters.append(torch.sort(sel)[0])
+    scores = torch.rand(12, generator=g)
+    ious = L.instance_ious(clusters, scores, inst, batch, None, False)
+    sl = L.instance_iou_loss(ious, clusters, scores, inst, batch, 0.25, 0.75)
+    np.savez_compressed(
+        os.path.join(OUT, "loss_cases.npz"), batch=batch.numpy(), inst=inst.numpy(), pred_off=pred_off.numpy(),
+        gt_off=gt_off.numpy(), embed=embed.numpy(),
+        offset_norm_loss=ol["offset_norm_loss"].numpy(), offset_dir_loss=ol["offset_dir_loss"].numpy(),
+        ins_loss=dl["ins_loss"].numpy(), ins_var_loss=dl["ins_var_loss"].numpy(),
+        ins_dist_loss=dl["ins_dist_loss"].numpy(), ins_reg_loss=dl["ins_reg_loss"].numpy(),
+        cluster_offsets=np.cumsum([0] + [len(c) for c in clusters]), cluster_points=torch.cat(clusters).numpy(),
+        scores=scores.numpy(), ious=ious.numpy(), score_loss=sl.numpy())
+    print("losses:", float(ol["offset_norm_loss"]), float(ol["offset_dir_loss"]), float(dl["ins_loss"]), float(sl))
+
+
+def make_nms():
+    _stub_modules()
+    S = _load(os.path.join(REF, "torch_points3d/models/panoptic/structure_3heads.py"), "ref_structure_3heads")
+    g = torch.Generator().manual_seed(1)
+    n = 4000
+    clusters = []
+    for p in range(30):
+        c0 = int(torch.randint(0, n - 600, (1,), generator=g))
+        size = int(torch.randint(5, 400, (1,), generator=g))
+        idx = c0 + torch.randperm(600, generator=g)[:size]
+        clusters.append(torch.sort(idx)[0])
+    scores = torch.rand(30, generator=g)
+    res = S.PanopticResults(semantic_logits=torch.zeros(n, 9), offset_logits=None, embed_logits=None,
+                            cluster_scores=scores, mask_scores=None, clusters=clusters, cluster_type=None)
+    out = {}
+    for tag, kw in [("default", {}), ("tracker", dict(min_cluster_points=10)),
+                    ("loose", dict(nms_threshold=0.6, min_cluster_points=0, min_score=0.0))]:
+        ids, cl = res.get_instances(**kw)
+        out["ids_" + tag] = np.asarray([int(i) for i in ids], np.int64)
+        out["sizes_" + tag] = np.asarray([len(c) for c in cl], np.int64)
+    np.savez_compressed(os.path.join(OUT, "nms_cases.npz"), n=np.int64(n),
+                        cluster_offsets=np.cumsum([0] + [len(c) for c in clusters]),
+                        cluster_points=torch.cat(clusters).numpy(), scores=scores.numpy(), **out)
+    print("nms:", {k: v.tolist() for k, v in out.items() if k.startswith("ids")})
+
+
+if __name__ == "__main__":
+    make_meanshift()
+    make_losses()
+    make_nms()

@@ -1,0 +1,306 @@
+"""CPU tests: the oracle against golden vectors from the reference's own Python (tests/golden/*.npz) and
+against independent brute-force definitions (tests/bruteforce.py).  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bruteforce as bf
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------- coordinates / maps
+@pytest.mark.parametrize("ts", [2, 4])
+def test_stride_coords_first_appearance(oracle, ts):
+    rng = np.random.default_rng(1)
+    coords = bf.surface_coords(rng)
+    coords[:, 1:] *= ts // 2
+    out, f2c = oracle.stride_coords(coords, ts)
+    ref_out, ref_f2c = bf.stride_coords_ref(coords, ts)
+    assert np.array_equal(out, ref_out)
+    assert np.array_equal(f2c, ref_f2c)
+
+
+def test_hash_duplicates(oracle):
+    rng = np.random.default_rng(2)
+    coords = bf.surface_coords(rng, dup=True)
+    first, ndup = oracle.hash_first_rows(coords)
+    _, idx, inv = np.unique(coords, axis=0, return_index=True, return_inverse=True)
+    assert ndup == len(coords) - len(idx)
+    assert np.array_equal(first, idx[inv.reshape(-1)])
+
+
+@pytest.mark.parametrize("ksize,step,sign", [(3, 1, 1), (3, 1, -1), (1, 1, 1)])
+def test_kernel_map_same_level(oracle, ksize, step, sign):
+    rng = np.random.default_rng(3)
+    coords = bf.surface_coords(rng)
+    nbr = oracle.kernel_map(coords, coords, ksize, step, sign)
+    assert np.array_equal(nbr, bf.kernel_map_ref(coords, coords, ksize, step, sign))
+    if ksize == 3:
+        # symmetry used by the input-gradient trick: in = out + d  <=>  out = in - d
+        K = 27
+        o = np.arange(len(coords))
+        for k in range(K):
+            r = nbr[k]
+            ok = r >= 0
+            assert np.array_equal(nbr[K - 1 - k][r[ok]], o[ok])
+
+
+def test_kernel_map_strided_and_transposed(oracle):
+    rng = np.random.default_rng(4)
+    fine = bf.surface_coords(rng)
+    coarse, f2c = oracle.stride_coords(fine, 2)
+    down = oracle.kernel_map(coarse, fine, 3, 1, 1)  # coarse out <- fine in
+    up = oracle.kernel_map(fine, coarse, 3, 1, -1)  # fine out <- coarse in (ME swapped map)
+    assert np.array_equal(down, bf.kernel_map_ref(coarse, fine, 3, 1, 1))
+    assert np.array_equal(up, bf.kernel_map_ref(fine, coarse, 3, 1, -1))
+    pairs_down = {(int(down[k, o]), o, k) for k in range(27) for o in range(len(coarse)) if down[k, o] >= 0}
+    pairs_up = {(i, int(up[k, i]), k) for k in range(27) for i in range(len(fine)) if up[k, i] >= 0}
+    assert pairs_down == pairs_up  # transposed conv = same (fine, coarse, offset) triples, roles swapped
+    # every fine voxel reaches its own coarse parent
+    assert all(any(up[k, i] == f2c[i] for k in range(27)) for i in range(len(fine)))
+
+
+# ---------------------------------------------------------------- sparse conv vs dense conv3d (float64)
+def _dense_check(oracle, cin, cout, stride, ksize, transposed=False):
+    rng = np.random.default_rng(5)
+    G = 12
+    occ = rng.random((G, G, G)) < 0.3
+    xyz = np.argwhere(occ).astype(np.int32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    coords = np.concatenate([np.zeros((len(xyz), 1), np.int32), xyz], 1)
+    feats = rng.normal(size=(len(xyz), cin)).astype(np.float32)
+    K = ksize ** 3
+    W = rng.normal(size=(K, cin, cout)).astype(np.float32) * 0.2
+    dense = np.zeros((cin, G, G, G), np.float64)
+    dense[:, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = feats.T
+    # W[k] with k=(dx+1)+3(dy+1)+9(dz+1)  ->  torch weight [cout,cin,kx,ky,kz] indexed by (dx,dy,dz)
+    if ksize == 3:
+        wt = W.reshape(3, 3, 3, cin, cout)  # [dz,dy,dx,ci,co]
+        wt = np.transpose(wt, (4, 3, 2, 1, 0)).astype(np.float64)  # [co,ci,dx,dy,dz]
+    else:
+        wt = np.transpose(W.reshape(1, 1, 1, cin, cout), (4, 3, 2, 1, 0)).astype(np.float64)
+    x = torch.from_numpy(dense)[None]
+    if stride == 1:
+        out_coords = coords
+        if transposed:  # mirrored offsets: out[v] = sum_d W_d in[v-d]
+            wt = wt[:, :, ::-1, ::-1, ::-1].copy()
+        y = torch.nn.functional.conv3d(x, torch.from_numpy(wt), padding=ksize // 2)[0].numpy()
+        nbr = oracle.kernel_map(out_coords, coords, ksize, 1, -1 if transposed else 1)
+        got = oracle.spconv_fwd(feats, W, nbr, len(out_coords))
+        want = y[:, xyz[:, 0], xyz[:, 1], xyz[:, 2]].T
+    else:
+        out_coords, _ = oracle.stride_coords(coords, 2)
+        y = torch.nn.functional.conv3d(x, torch.from_numpy(wt), padding=1)[0].numpy()  # centred at every site
+        nbr = oracle.kernel_map(out_coords, coords, 3, 1, 1)
+        got = oracle.spconv_fwd(feats, W, nbr, len(out_coords))
+        oc = out_coords[:, 1:]
+        want = y[:, oc[:, 0], oc[:, 1], oc[:, 2]].T
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,stride,ksize,tr", [(4, 16, 1, 3, False), (16, 32, 2, 3, False), (16, 32, 1, 1, False),
+                                                       (16, 16, 1, 3, True)])
+def test_spconv_matches_dense_conv3d(oracle, cin, cout, stride, ksize, tr):
+    _dense_check(oracle, cin, cout, stride, ksize, tr)
+
+
+def test_spconv_transposed_stride2_matches_conv_transpose3d(oracle):
+    """ME transposed conv onto the existing fine map == dense conv_transpose3d sampled at the fine sites."""
+    rng = np.random.default_rng(6)
+    G = 12
+    occ = rng.random((G, G, G)) < 0.3
+    xyz = np.argwhere(occ).astype(np.int32)
+    fine = np.concatenate([np.zeros((len(xyz), 1), np.int32), xyz], 1)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    cin, cout = 8, 16
+    feats = rng.normal(size=(len(coarse), cin)).astype(np.float32)
+    W = rng.normal(size=(27, cin, cout)).astype(np.float32) * 0.2
+    nbr = oracle.kernel_map(fine, coarse, 3, 1, -1)
+    got = oracle.spconv_fwd(feats, W, nbr, len(fine))
+    # dense: place coarse features on the fine grid at their (even) coordinates, correlate with mirrored kernel
+    dense = np.zeros((cin, G, G, G), np.float64)
+    cc = coarse[:, 1:]
+    dense[:, cc[:, 0], cc[:, 1], cc[:, 2]] = feats.T
+    wt = np.transpose(W.reshape(3, 3, 3, cin, cout), (4, 3, 2, 1, 0)).astype(np.float64)[:, :, ::-1, ::-1, ::-1].copy()
+    y = torch.nn.functional.conv3d(torch.from_numpy(dense)[None], torch.from_numpy(wt), padding=1)[0].numpy()
+    want = y[:, xyz[:, 0], xyz[:, 1], xyz[:, 2]].T
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_spconv_epilogue_cat_and_backward(oracle):
+    rng = np.random.default_rng(7)
+    coords = bf.surface_coords(rng, n=300)
+    n = len(coords)
+    nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
+    a = rng.normal(size=(n, 16)).astype(np.float32)
+    b = rng.normal(size=(n, 16)).astype(np.float32)
+    W = (rng.normal(size=(27, 32, 16)) * 0.1).astype(np.float32)
+    sc = rng.normal(size=16).astype(np.float32)
+    sh = rng.normal(size=16).astype(np.float32)
+    res = rng.normal(size=(n, 16)).astype(np.float32)
+    cat = np.concatenate([a, b], 1)
+    plain = oracle.spconv_fwd(cat, W, nbr, n)
+    fused = oracle.spconv_fwd(a, W, nbr, n, in1=b, scale=sc, shift=sh, relu=True, residual=res)
+    np.testing.assert_allclose(fused, np.maximum(plain * sc + sh, 0) + res, rtol=1e-5, atol=1e-5)
+    # backward vs torch autograd on the gathered formulation
+    x = torch.tensor(cat, dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    out = torch.zeros(n, 16, dtype=torch.float64)
+    for k in range(27):
+        r = torch.from_numpy(nbr[k].astype(np.int64))
+        ok = r >= 0
+        out = out.index_add(0, torch.nonzero(ok).view(-1), x[r[ok]] @ w[k])
+    g = torch.tensor(rng.normal(size=(n, 16)))
+    out.backward(g)
+    din, dw = oracle.spconv_bwd(cat, g.numpy().astype(np.float32), W, nbr)
+    np.testing.assert_allclose(din, x.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw, w.grad.numpy(), rtol=1e-4, atol=1e-3)
+    # input-gradient trick the HIP path uses: din = conv(dout, W^T) over the mirrored map
+    WT = np.ascontiguousarray(np.transpose(W, (0, 2, 1)))
+    din2 = oracle.spconv_fwd(g.numpy().astype(np.float32), WT, nbr[::-1].copy(), n)
+    np.testing.assert_allclose(din2, din, rtol=1e-4, atol=1e-4)
+
+
+def test_head_mlp_matches_torch(oracle):
+    torch.manual_seed(0)
+    x = torch.randn(200, 16)
+    lin1 = torch.nn.Linear(16, 16, bias=False)
+    bn = torch.nn.BatchNorm1d(16)
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2)
+    bn.weight.data.normal_()
+    bn.bias.data.normal_()
+    lin2 = torch.nn.Linear(16, 9)
+    net = torch.nn.Sequential(lin1, bn, torch.nn.LeakyReLU(0.2), lin2, torch.nn.LogSoftmax(-1)).eval()
+    with torch.no_grad():
+        want = net(x)
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+    y, am = oracle.head_mlp(x.numpy(), lin1.weight.detach().numpy(), scale.numpy(), shift.numpy(),
+                            lin2.weight.detach().numpy(), lin2.bias.detach().numpy(), log_softmax=True, want_argmax=True)
+    np.testing.assert_allclose(y, want.numpy(), rtol=1e-4, atol=1e-5)
+    assert np.array_equal(am, want.argmax(1).numpy())
+
+
+# ---------------------------------------------------------------- region growing
+def _blobs3(rng, n_blobs, pts, spread, sigma):
+    cen = rng.uniform(-spread, spread, size=(n_blobs, 3))
+    ids = rng.integers(0, n_blobs, size=pts)
+    return (cen[ids] + rng.normal(0, sigma, size=(pts, 3))).astype(np.float32), ids
+
+
+@pytest.mark.parametrize("nsample", [200, 16, 4])
+def test_region_grow_literal(oracle, nsample):
+    rng = np.random.default_rng(8)
+    pos, _ = _blobs3(rng, 12, 900, 3.0, 0.12)
+    labels = rng.integers(0, 4, size=900)
+    batch = np.sort(rng.integers(0, 2, size=900))
+    ignore = [0]
+    got, pc = oracle.region_grow(pos, labels, batch, ignore, nsample=nsample, radius=0.18, min_cluster_size=5)
+    want = bf.region_grow_ref(pos, labels, batch, ignore, nsample, 0.18, 5)
+    assert len(got) == len(want) and len(want) > 0
+    for g, w in zip(got, want):  # same clusters in the same (reference) order
+        assert np.array_equal(g, w)
+    for i, c in enumerate(got):
+        assert np.all(pc[c] == i)
+    assert (pc >= 0).sum() == sum(len(c) for c in got)
+
+
+def test_region_grow_truncation_is_order_dependent(oracle):
+    """A pile-up denser than nsample: only what the seed's list reaches is grouped (App. C fact 1)."""
+    rng = np.random.default_rng(9)
+    pos = rng.normal(0, 0.01, size=(300, 3)).astype(np.float32)  # all mutually within r
+    labels = np.ones(300, np.int64)
+    batch = np.zeros(300, np.int64)
+    got, _ = oracle.region_grow(pos, labels, batch, [], nsample=50, radius=0.5, min_cluster_size=10)
+    assert len(got) == 1 and np.array_equal(got[0], np.arange(50))
+    full, _ = oracle.region_grow(pos, labels, batch, [], nsample=400, radius=0.5, min_cluster_size=10)
+    assert len(full) == 1 and len(full[0]) == 300
+
+
+def test_region_grow_min_index_ancestor_equivalence(oracle):
+    """The parallel formulation the HIP kernel uses: cluster id of v = smallest index that reaches v
+    through directed (truncated) neighbour lists.  Checked against the literal sequential algorithm."""
+    rng = np.random.default_rng(10)
+    pos, _ = _blobs3(rng, 5, 600, 1.0, 0.08)
+    labels = np.ones(600, np.int64)
+    batch = np.zeros(600, np.int64)
+    nsample, radius = 8, 0.12
+    want = bf.region_grow_ref(pos, labels, batch, [], nsample, radius, 1)
+    d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
+    nb = [np.nonzero(d2[a] < np.float32(radius) ** 2)[0][:nsample] for a in range(600)]
+    L = np.arange(600)
+    changed = True
+    while changed:
+        changed = False
+        for k in range(600):
+            for j in nb[k]:
+                if L[k] < L[j]:
+                    L[j] = L[k]
+                    changed = True
+    got = [np.nonzero(L == r)[0] for r in np.unique(L)]
+    assert bf.canon_clusters(got) == bf.canon_clusters(want)
+
+
+# ---------------------------------------------------------------- mean shift vs the reference worker (sklearn)
+def test_meanshift_matches_reference_goldens(oracle):
+    z = np.load(os.path.join(GOLD, "meanshift_cases.npz"))
+    for name in z["names"].tolist():
+        x = z["x_" + name]
+        labels, ncl, centers = oracle.meanshift(x, [0, len(x)], float(z["bw_" + name]))
+        want = z["labels_" + name]
+        assert ncl[0] == want.max() + 1, name
+        assert np.array_equal(bf.canon_partition(labels), bf.canon_partition(want)), name
+        # label ids follow sklearn's (count, centre) descending order -> identical ids when counts differ
+        sizes = np.bincount(want)
+        if len(np.unique(sizes)) == len(sizes):
+            assert np.array_equal(labels, want), name
+
+
+def test_meanshift_skips_small_samples(oracle):
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(10, 5)).astype(np.float32)
+    labels, ncl, _ = oracle.meanshift(x, [0, 3, 10], 0.6)
+    assert np.all(labels[:3] == -1) and ncl[0] == 0 and ncl[1] >= 1 and np.all(labels[3:] >= 0)
+
+
+# ---------------------------------------------------------------- scatter / iou / intersections
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_segment_reduce_matches_torch(oracle, reduce):
+    rng = np.random.default_rng(12)
+    src = rng.normal(size=(500, 16)).astype(np.float32)
+    index = rng.integers(0, 37, size=500)
+    index[index == 5] = 6  # leave an empty segment
+    out, arg = oracle.segment_reduce(src, index, 37, reduce)
+    idx = torch.from_numpy(index)[:, None].expand(-1, 16)
+    red = {"sum": "sum", "mean": "mean", "max": "amax"}[reduce]
+    want = torch.zeros(37, 16).scatter_reduce(0, idx, torch.from_numpy(src), red, include_self=False)
+    np.testing.assert_allclose(out, want.numpy(), rtol=1e-5, atol=1e-5)
+    if reduce == "max":
+        assert np.all(out[5] == 0)
+        cols = np.arange(16)
+        for s in [0, 6, 36]:
+            assert np.array_equal(src[arg[s], cols], out[s])
+
+
+def test_instance_iou_and_losses_match_reference_goldens(oracle):
+    z = np.load(os.path.join(GOLD, "loss_cases.npz"))
+    offs = z["cluster_offsets"]
+    clusters = [z["cluster_points"][offs[i]: offs[i + 1]] for i in range(len(offs) - 1)]
+    iou = oracle.instance_iou(clusters, z["inst"], z["batch"])
+    np.testing.assert_allclose(iou, z["ious"], rtol=1e-6, atol=1e-7)
+
+
+def test_proposal_intersections_match_dense_mm(oracle):
+    z = np.load(os.path.join(GOLD, "nms_cases.npz"))
+    offs = z["cluster_offsets"]
+    clusters = [z["cluster_points"][offs[i]: offs[i + 1]] for i in range(len(offs) - 1)]
+    n = int(z["n"])
+    inter = oracle.proposal_intersections(clusters, n)
+    mask = np.zeros((len(clusters), n), np.float32)
+    for i, c in enumerate(clusters):
+        mask[i, c] = 1
+    assert np.array_equal(inter, (mask @ mask.T).astype(np.int32))
