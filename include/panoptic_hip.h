@@ -171,8 +171,10 @@ int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n, int32_t n
  * reduce: 0 sum, 1 mean, 2 max.  index int64 [n] in [0,n_seg).  out [n_seg,c]; empty segments -> 0.
  * arg (int64 [n_seg,c], may be NULL) receives the arg-max row for reduce=2 (needed by its backward).
  * ---------------------------------------------------------------------------------------------- */
+size_t pp_segment_reduce_workspace(int64_t n_seg);
 int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
-                      int32_t reduce, float* out, int64_t* arg, pp_stream_t stream);
+                      int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
+                      pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K10 instance IoU                replaces: torch_points_kernels.instance_iou,

@@ -1,0 +1,80 @@
+"""ctypes binding of libpanoptic_hip.so (C-ABI declared in include/panoptic_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be resolved this
+module raises, and every op built on it fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpanoptic_hip.so")
+
+PP_OK = 0
+_STATUS = {1: "PP_ERR_INVALID", 2: "PP_ERR_RANGE", 3: "PP_ERR_HIP", 4: "PP_ERR_WORKSPACE"}
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+sz = C.c_size_t
+
+# name -> (restype, argtypes); kept in the order of include/panoptic_hip.h
+SIGNATURES = {
+    "pp_version": (C.c_char_p, []),
+    "pp_last_error": (C.c_char_p, []),
+    "pp_triad": (C.c_int, [vp, vp, vp, f32, i64, vp]),
+    "pp_hash_capacity": (i64, [i64]),
+    "pp_hash_build": (C.c_int, [vp, i64, vp, vp, i64, vp, vp]),
+    "pp_stride_coords_workspace": (sz, [i64]),
+    "pp_stride_coords": (C.c_int, [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, sz, vp, vp]),
+    "pp_kernel_map": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp]),
+    "pp_packed_weight_floats": (sz, [i32, i32, i32]),
+    "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
+    "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp]),
+    "pp_spconv_bwd_weight": (C.c_int, [vp, i32, vp, i32, vp, i32, i64, vp, vp]),
+    "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),
+    "pp_affine_act": (C.c_int, [vp, i64, i32, vp, vp, i32, f32, vp, vp, vp]),
+    "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
+    "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "pp_region_grow_workspace": (sz, [i64, i32]),
+    "pp_region_grow": (C.c_int, [vp, vp, vp, i64, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_meanshift_workspace": (sz, [i64, i32, i32]),
+    "pp_meanshift": (C.c_int, [vp, i64, i32, vp, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_group_by_key_workspace": (sz, [i64]),
+    "pp_group_by_key": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_segment_reduce_workspace": (sz, [i64]),
+    "pp_segment_reduce": (C.c_int, [vp, vp, i64, i32, i64, i32, vp, vp, vp, sz, vp]),
+    "pp_instance_iou": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "pp_proposal_intersections_workspace": (sz, [i64, i64]),
+    "pp_proposal_intersections": (C.c_int, [vp, vp, i32, i64, vp, vp, sz, vp]),
+}
+
+_lib = None
+
+
+class PanopticHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is not built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PanopticHipError(
+            "libpanoptic_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C panopticsegforlargescalepointcloud_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != PP_OK:
+        msg = load().pp_last_error().decode("utf-8", "replace")
+        raise PanopticHipError("%s failed: %s (%s)" % (what, _STATUS.get(rc, rc), msg))

@@ -1,0 +1,111 @@
+// Shared helpers of libpanoptic_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/panoptic_hip.h"
+
+#define PP_WAVE 64
+#define PP_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+void pp_set_error(const char* fmt, ...);
+
+#define PP_HIP(call)                                                                  \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      pp_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+      return PP_ERR_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define PP_LAUNCH_CHECK() PP_HIP(hipGetLastError())
+
+#define PP_REQUIRE(cond, msg)                       \
+  do {                                              \
+    if (!(cond)) {                                  \
+      pp_set_error("%s:%d %s", __FILE__, __LINE__, msg); \
+      return PP_ERR_INVALID;                        \
+    }                                               \
+  } while (0)
+
+static inline hipStream_t pp_s(pp_stream_t s) { return (hipStream_t)s; }
+static inline unsigned pp_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+static inline size_t pp_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- 64-bit coordinate key: batch 16 bits, x/y/z 16 bits each (offset 32768) ----
+__host__ __device__ inline bool pp_key_ok(int b, int x, int y, int z) {
+  return ((unsigned)b < 65536u) && ((unsigned)(x + 32768) < 65536u) && ((unsigned)(y + 32768) < 65536u) &&
+         ((unsigned)(z + 32768) < 65536u);
+}
+__host__ __device__ inline uint64_t pp_key_pack(int b, int x, int y, int z) {
+  return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(x + 32768) << 32) |
+         ((uint64_t)(uint16_t)(y + 32768) << 16) | (uint64_t)(uint16_t)(z + 32768);
+}
+__host__ __device__ inline uint64_t pp_mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+__device__ inline int pp_floor_div(int a, int b) {
+  int q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}
+
+// open-addressing lookup: returns slot holding `key`, or -1
+__device__ inline int64_t pp_hash_find_slot(const uint64_t* __restrict__ keys, int64_t cap, uint64_t key) {
+  uint64_t mask = (uint64_t)cap - 1;
+  uint64_t s = pp_mix64(key) & mask;
+  for (;;) {
+    uint64_t k = keys[s];
+    if (k == key) return (int64_t)s;
+    if (k == PP_EMPTY_KEY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+// insert-or-find: returns slot
+__device__ inline int64_t pp_hash_insert_slot(uint64_t* keys, int64_t cap, uint64_t key) {
+  uint64_t mask = (uint64_t)cap - 1;
+  uint64_t s = pp_mix64(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS((unsigned long long*)&keys[s], (unsigned long long)PP_EMPTY_KEY,
+                                       (unsigned long long)key);
+    if (prev == PP_EMPTY_KEY || prev == key) return (int64_t)s;
+    s = (s + 1) & mask;
+  }
+}
+
+// internal device primitives (pp_scan.hip)
+size_t pp_scan_workspace(int64_t n);
+// exclusive prefix sum of int32; total (device int32[1], may be NULL) receives the grand total
+int pp_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
+size_t pp_sort_pairs_workspace(int64_t n);
+// stable LSD radix sort of (key,value) pairs on bits [0,end_bit); results land in keys_out/vals_out
+int pp_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
+                      int64_t n, int end_bit, void* ws, size_t ws_bytes, hipStream_t stream);
+int pp_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
+                      int64_t n, int end_bit, void* ws, size_t ws_bytes, hipStream_t stream);
+
+// bump allocator over a caller-provided workspace
+struct PPArena {
+  char* base;
+  size_t size;
+  size_t used;
+  PPArena(void* p, size_t n) : base((char*)p), size(n), used(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = pp_align(count * sizeof(T));
+    if (used + bytes > size) return nullptr;
+    T* r = (T*)(base + used);
+    used += bytes;
+    return r;
+  }
+  size_t left() const { return size - used; }
+  void* cur() const { return base + used; }
+};

@@ -1,0 +1,197 @@
+// K1-K3: coordinate hash, strided output coordinates, kernel maps.  Pure integer, HBM/L2 bound.
+// Semantics follow SURVEY.md 8c / oracle/panoptic_oracle.c (ppo_hash_first_rows, ppo_stride_coords,
+// ppo_kernel_map); reference call sites: torch_points3d/applications/minkowski.py:121-122,
+// torch_points3d/modules/MinkowskiEngine/api_modules.py:30-51,256-271.
+#include "pp_common.h"
+
+extern "C" int64_t pp_hash_capacity(int64_t n) {
+  int64_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+__global__ __launch_bounds__(256) void k_hash_fill(uint64_t* keys, int32_t* vals, int64_t cap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) {
+    keys[i] = PP_EMPTY_KEY;
+    vals[i] = 0x7FFFFFFF;
+  }
+}
+
+// insert key of (optionally quantised) row i with value min(row index); slot_of_row optional
+__global__ __launch_bounds__(256) void k_hash_insert_min(const int4* __restrict__ coords, int64_t n, int ts,
+                                                         uint64_t* keys, int32_t* vals, int64_t cap,
+                                                         int32_t* slot_of_row, int32_t* info) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  if (ts > 1) {
+    c.y = pp_floor_div(c.y, ts) * ts;
+    c.z = pp_floor_div(c.z, ts) * ts;
+    c.w = pp_floor_div(c.w, ts) * ts;
+  }
+  if (!pp_key_ok(c.x, c.y, c.z, c.w)) {
+    atomicAdd(&info[1], 1);
+    if (slot_of_row) slot_of_row[i] = -1;
+    return;
+  }
+  int64_t s = pp_hash_insert_slot(keys, cap, pp_key_pack(c.x, c.y, c.z, c.w));
+  atomicMin(&vals[s], (int32_t)i);
+  if (slot_of_row) slot_of_row[i] = (int32_t)s;
+}
+
+__global__ __launch_bounds__(256) void k_count_dups(const int4* __restrict__ coords, int64_t n,
+                                                    const uint64_t* __restrict__ keys,
+                                                    const int32_t* __restrict__ vals, int64_t cap, int32_t* info) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  if (!pp_key_ok(c.x, c.y, c.z, c.w)) return;
+  int64_t s = pp_hash_find_slot(keys, cap, pp_key_pack(c.x, c.y, c.z, c.w));
+  if (s >= 0 && vals[s] != (int32_t)i) atomicAdd(&info[0], 1);
+}
+
+extern "C" int pp_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
+                             int32_t* info, pp_stream_t stream) {
+  PP_REQUIRE(keys && vals && info, "pp_hash_build: null table");
+  PP_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "pp_hash_build: cap must be a power of two >= 2n");
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, keys, vals,
+                     cap);
+  PP_LAUNCH_CHECK();
+  if (n > 0) {
+    hipLaunchKernelGGL(k_hash_insert_min, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, 1, keys,
+                       vals, cap, (int32_t*)nullptr, info);
+    PP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_count_dups, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, keys, vals, cap,
+                       info);
+    PP_LAUNCH_CHECK();
+  }
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: strided coordinates in first-appearance order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_leaders(int64_t n, const int32_t* __restrict__ slot_of_row,
+                                                      const int32_t* __restrict__ vals, int32_t* lead_row,
+                                                      int32_t* flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t s = slot_of_row[i];
+  int32_t lr = s >= 0 ? vals[s] : -1;
+  lead_row[i] = lr;
+  flag[i] = (lr == (int32_t)i) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_emit_coarse(const int4* __restrict__ coords, int64_t n, int ts,
+                                                     const int32_t* __restrict__ slot_of_row,
+                                                     const int32_t* __restrict__ lead_row,
+                                                     const int32_t* __restrict__ rank, int32_t* vals,
+                                                     int4* out_coords, int32_t* fine_to_coarse) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t lr = lead_row[i];
+  if (lr < 0) {
+    if (fine_to_coarse) fine_to_coarse[i] = -1;
+    return;
+  }
+  int32_t r = rank[lr];
+  if (fine_to_coarse) fine_to_coarse[i] = r;
+  if (lr == (int32_t)i) {
+    int4 c = coords[i];
+    c.y = pp_floor_div(c.y, ts) * ts;
+    c.z = pp_floor_div(c.z, ts) * ts;
+    c.w = pp_floor_div(c.w, ts) * ts;
+    out_coords[r] = c;
+    vals[slot_of_row[i]] = r;  // table now maps coarse key -> coarse row
+  }
+}
+
+extern "C" size_t pp_stride_coords_workspace(int64_t n) {
+  return 4 * pp_align((size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)) + pp_scan_workspace(n) + 1024;
+}
+
+extern "C" int pp_stride_coords(const int32_t* coords, int64_t n, int32_t ts_out, uint64_t* keys, int32_t* vals,
+                                int64_t cap, int32_t* out_coords, int32_t* n_out, int32_t* fine_to_coarse,
+                                void* workspace, size_t workspace_bytes, int32_t* info, pp_stream_t stream) {
+  PP_REQUIRE(ts_out >= 1, "pp_stride_coords: ts_out must be >= 1");
+  PP_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "pp_stride_coords: cap must be a power of two >= 2n");
+  if (workspace_bytes < pp_stride_coords_workspace(n)) return PP_ERR_WORKSPACE;
+  hipStream_t s = pp_s(stream);
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* slot_of_row = ar.take<int32_t>((size_t)std::max<int64_t>(n, 1));
+  int32_t* lead_row = ar.take<int32_t>((size_t)std::max<int64_t>(n, 1));
+  int32_t* flag = ar.take<int32_t>((size_t)std::max<int64_t>(n, 1));
+  int32_t* rank = ar.take<int32_t>((size_t)std::max<int64_t>(n, 1));
+  PP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, keys, vals,
+                     cap);
+  PP_LAUNCH_CHECK();
+  if (n == 0) {
+    PP_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), s));
+    return PP_OK;
+  }
+  unsigned nb = pp_blocks(n, 256);
+  hipLaunchKernelGGL(k_hash_insert_min, dim3(nb), dim3(256), 0, s, (const int4*)coords, n, ts_out, keys, vals, cap,
+                     slot_of_row, info);
+  PP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_mark_leaders, dim3(nb), dim3(256), 0, s, n, slot_of_row, vals, lead_row, flag);
+  PP_LAUNCH_CHECK();
+  int rc = pp_exclusive_scan_i32(flag, rank, n, n_out, ar.cur(), ar.left(), s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_emit_coarse, dim3(nb), dim3(256), 0, s, (const int4*)coords, n, ts_out, slot_of_row, lead_row,
+                     rank, vals, (int4*)out_coords, fine_to_coarse);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: kernel map.  One thread per output row, 27 independent probes (ILP), offset-major coalesced stores.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_kernel_map(const int4* __restrict__ out_coords, int64_t n_out,
+                                                    const uint64_t* __restrict__ keys,
+                                                    const int32_t* __restrict__ vals, int64_t cap, int step,
+                                                    int32_t* __restrict__ nbr) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  int4 c = out_coords[o];
+  constexpr int K = KS * KS * KS;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    int dx = 0, dy = 0, dz = 0;
+    if (KS == 3) {
+      dx = k % 3 - 1;
+      dy = (k / 3) % 3 - 1;
+      dz = k / 9 - 1;
+    }
+    int x = c.y + dx * step, y = c.z + dy * step, z = c.w + dz * step;
+    int32_t r = -1;
+    if (pp_key_ok(c.x, x, y, z)) {
+      int64_t s = pp_hash_find_slot(keys, cap, pp_key_pack(c.x, x, y, z));
+      if (s >= 0) r = vals[s];
+    }
+    nbr[(int64_t)k * n_out + o] = r;
+  }
+}
+
+extern "C" int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys, const int32_t* vals,
+                             int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr,
+                             pp_stream_t stream) {
+  PP_REQUIRE(ksize == 1 || ksize == 3, "pp_kernel_map: ksize must be 1 or 3");
+  PP_REQUIRE(sign == 1 || sign == -1, "pp_kernel_map: sign must be +1 or -1");
+  if (n_out == 0) return PP_OK;
+  hipStream_t s = pp_s(stream);
+  unsigned nb = pp_blocks(n_out, 256);
+  if (ksize == 3)
+    hipLaunchKernelGGL(k_kernel_map<3>, dim3(nb), dim3(256), 0, s, (const int4*)out_coords, n_out, keys, vals, cap,
+                       sign * step, nbr);
+  else
+    hipLaunchKernelGGL(k_kernel_map<1>, dim3(nb), dim3(256), 0, s, (const int4*)out_coords, n_out, keys, vals, cap, 0,
+                       nbr);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -1,0 +1,312 @@
+// K4/K5: sparse convolution on CDNA4 matrix cores (exact-f32 MFMA, v_mfma_f32_16x16x4_f32).
+//
+// Output-stationary implicit GEMM: a wave owns 32 output rows x (NTW*16) output channels and walks the
+// kernel offsets k and input-channel steps; its A fragments are GATHERED straight from the input rows
+// named by the kernel map (float4 per lane = 16 B, a full 64 B row segment per 4 lanes), its B fragments
+// are read from weights pre-packed into MFMA fragment order (one coalesced 1 KiB load per wave).
+// No atomics, no scatter: every output row is written exactly once, in a fixed summation order, with the
+// folded BatchNorm / ReLU / residual epilogue fused (reference: MinkowskiConvolution -> MinkowskiBatchNorm
+// -> MinkowskiReLU, torch_points3d/modules/MinkowskiEngine/api_modules.py:30-54,76-82,259-270; ME.cat of
+// the skip connection api_modules.py:308 is the second source pointer).
+//
+// MFMA operand maps (guide 3, 16x16x4 f32): A lane l -> A[i=l&15][kk=l>>4]; B lane l -> B[kk=l>>4][j=l&15];
+// D reg r of lane l -> D[row=4*(l>>4)+r][col=l&15].  With a float4 per lane, MFMA #t of a 16-channel
+// step consumes channels {t, 4+t, 8+t, 12+t}: lane (i,q) feeds A[i][4q+t], lane (j,q) feeds W[4q+t][j].
+#include "pp_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+//   mode16 (cin % 16 == 0): packed[k][s][jt][lane][t] = W[k][16s + 4(lane>>4) + t][16jt + (lane&15)]
+//   mode4  (otherwise, cin % 4 == 0): packed[k][s4][jt][lane] = W[k][4s4 + (lane>>4)][16jt + (lane&15)]
+//   transpose_w: W[k][a][b] read as W[k][b][a] (cin/cout given for the PACKED orientation)
+// ---------------------------------------------------------------------------------------------
+static inline int pp_nt(int cout) { return (cout + 15) / 16; }
+
+extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) {
+  int NT = pp_nt(cout);
+  if (cin % 16 == 0) return (size_t)K * (cin / 16) * NT * 256;
+  return (size_t)K * ((cin + 3) / 4) * NT * 64;
+}
+
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int K, int cin, int cout,
+                                                     int transpose_w, float* __restrict__ packed, int64_t total) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int NT = (cout + 15) / 16;
+  int k, ci, co;
+  if (cin % 16 == 0) {
+    int t = (int)(e & 3);
+    int lane = (int)((e >> 2) & 63);
+    int64_t r = e >> 8;
+    int jt = (int)(r % NT);
+    r /= NT;
+    int S = cin / 16;
+    int s = (int)(r % S);
+    k = (int)(r / S);
+    ci = 16 * s + 4 * (lane >> 4) + t;
+    co = 16 * jt + (lane & 15);
+  } else {
+    int lane = (int)(e & 63);
+    int64_t r = e >> 6;
+    int jt = (int)(r % NT);
+    r /= NT;
+    int S4 = (cin + 3) / 4;
+    int s4 = (int)(r % S4);
+    k = (int)(r / S4);
+    ci = 4 * s4 + (lane >> 4);
+    co = 16 * jt + (lane & 15);
+  }
+  float v = 0.f;
+  if (ci < cin && co < cout) {
+    // source layout: not transposed [K][cin][cout]; transposed: the ME tensor is [K][cout][cin]
+    v = transpose_w ? w[((int64_t)k * cout + co) * cin + ci] : w[((int64_t)k * cin + ci) * cout + co];
+  }
+  packed[e] = v;
+}
+
+extern "C" int pp_pack_weight(const float* weight, int32_t K, int32_t cin, int32_t cout, int32_t transpose_w,
+                              float* packed, pp_stream_t stream) {
+  PP_REQUIRE(weight && packed, "pp_pack_weight: null pointer");
+  PP_REQUIRE(cin % 4 == 0, "pp_pack_weight: cin must be a multiple of 4");
+  int64_t total = (int64_t)pp_packed_weight_floats(K, cin, cout);
+  hipLaunchKernelGGL(k_pack_weight, dim3(pp_blocks(total, 256)), dim3(256), 0, pp_s(stream), weight, K, cin, cout,
+                     transpose_w, packed, total);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward kernel.  block = 4 waves = 128 output rows; grid.y = output-channel tile groups.
+// ---------------------------------------------------------------------------------------------
+struct SpconvArgs {
+  const float* in0;
+  const float* in1;
+  const float* wp;
+  const int32_t* nbr;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  float* out;
+  int64_t n_out;
+  int c0, c1, K, cout, NT, relu;
+};
+
+template <int NTW, bool MODE16>
+__global__ __launch_bounds__(256) void k_spconv_fwd(SpconvArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  if (row_base >= a.n_out) return;  // wave-uniform
+  const int jt0 = blockIdx.y * NTW;
+  const int64_t r0 = row_base + i, r1 = row_base + 16 + i;
+  const bool v0 = r0 < a.n_out, v1 = r1 < a.n_out;
+
+  f32x4 acc[2][NTW];
+#pragma unroll
+  for (int jt = 0; jt < NTW; ++jt) {
+    acc[0][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int cin = a.c0 + a.c1;
+  for (int k = 0; k < a.K; ++k) {
+    int a0 = -1, a1 = -1;
+    if (a.nbr) {
+      if (v0) a0 = a.nbr[(int64_t)k * a.n_out + r0];
+      if (v1) a1 = a.nbr[(int64_t)k * a.n_out + r1];
+    } else {
+      if (v0) a0 = (int)r0;
+      if (v1) a1 = (int)r1;
+    }
+    if (__ballot((a0 >= 0) || (a1 >= 0)) == 0ull) continue;  // no row of this wave has that neighbour
+    if (MODE16) {
+      const int S0 = a.c0 >> 4, S = cin >> 4;
+      const float* wk = a.wp + (int64_t)k * S * a.NT * 256;
+      for (int s = 0; s < S; ++s) {
+        const float* src;
+        int cs, ss;
+        if (s < S0) {
+          src = a.in0; cs = a.c0; ss = s;
+        } else {
+          src = a.in1; cs = a.c1; ss = s - S0;
+        }
+        f32x4 A0 = (f32x4){0.f, 0.f, 0.f, 0.f}, A1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a0 >= 0) A0 = *(const f32x4*)(src + (int64_t)a0 * cs + ss * 16 + q * 4);
+        if (a1 >= 0) A1 = *(const f32x4*)(src + (int64_t)a1 * cs + ss * 16 + q * 4);
+        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 256 + lane * 4;
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt) {
+          if (jt0 + jt < a.NT) {
+            f32x4 B = *(const f32x4*)(ws + jt * 256);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[t], B[t], acc[0][jt], 0, 0, 0);
+              acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], B[t], acc[1][jt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
+      const int S4 = (cin + 3) >> 2;
+      const float* wk = a.wp + (int64_t)k * S4 * a.NT * 64;
+      for (int s = 0; s < S4; ++s) {
+        const int ch = 4 * s + q;
+        float A0 = 0.f, A1 = 0.f;
+        if (ch < cin) {
+          const float* src = ch < a.c0 ? a.in0 : a.in1;
+          const int cs = ch < a.c0 ? a.c0 : a.c1;
+          const int cc = ch < a.c0 ? ch : ch - a.c0;
+          if (a0 >= 0) A0 = src[(int64_t)a0 * cs + cc];
+          if (a1 >= 0) A1 = src[(int64_t)a1 * cs + cc];
+        }
+        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 64 + lane;
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt) {
+          if (jt0 + jt < a.NT) {
+            float B = ws[jt * 64];
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B, acc[1][jt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane (col = i, row group = q) holds rows 4q+r of each 16-row tile
+#pragma unroll
+  for (int jt = 0; jt < NTW; ++jt) {
+    const int col = (jt0 + jt) * 16 + i;
+    if (jt0 + jt < a.NT && col < a.cout) {
+      const float sc = a.scale ? a.scale[col] : 1.f;
+      const float sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row_base + rt * 16 + q * 4 + r;
+          if (row < a.n_out) {
+            float v = acc[rt][jt][r] * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.residual) v += a.residual[row * a.cout + col];
+            a.out[row * a.cout + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool MODE16>
+static void launch_fwd(int ntw, dim3 grid, hipStream_t s, const SpconvArgs& a) {
+  switch (ntw) {
+    case 1: hipLaunchKernelGGL((k_spconv_fwd<1, MODE16>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_spconv_fwd<2, MODE16>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_spconv_fwd<3, MODE16>), grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_spconv_fwd<4, MODE16>), grid, dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_spconv_fwd<5, MODE16>), grid, dim3(256), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((k_spconv_fwd<6, MODE16>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((k_spconv_fwd<7, MODE16>), grid, dim3(256), 0, s, a); break;
+  }
+}
+
+extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
+                             const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
+                             const float* shift, int32_t relu, const float* residual, float* out,
+                             pp_stream_t stream) {
+  PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
+  PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
+  PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
+  PP_REQUIRE((c0 + c1) % 4 == 0, "pp_spconv_fwd: cin must be a multiple of 4");
+  const bool mode16 = ((c0 + c1) % 16 == 0);
+  if (mode16) PP_REQUIRE(c0 % 16 == 0, "pp_spconv_fwd: with cin % 16 == 0 both sources must be multiples of 16");
+  if (n_out == 0) return PP_OK;
+  SpconvArgs a;
+  a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
+  a.residual = residual; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
+  a.NT = pp_nt(cout); a.relu = relu;
+  int groups = (a.NT + 6) / 7;
+  int ntw = (a.NT + groups - 1) / groups;
+  groups = (a.NT + ntw - 1) / ntw;
+  dim3 grid(pp_blocks(n_out, 128), (unsigned)groups);
+  if (mode16)
+    launch_fwd<true>(ntw, grid, pp_s(stream), a);
+  else
+    launch_fwd<false>(ntw, grid, pp_s(stream), a);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 weight gradient: dW[k] = sum_o in[nbr[k][o]]^T dout[o]
+// MFMA with the reduction (rows) as the K dimension: A[i=ci][kk=row] , B[kk=row][j=co].
+// grid = (row chunks, K offsets, ci tiles); each wave owns ROWS_PER_WAVE rows, one 16-wide ci tile and all
+// co tiles (<= 12), then adds its partial tile into dW with float atomics (few per wave).
+// ---------------------------------------------------------------------------------------------
+#define BWW_ROWS_PER_WAVE 512
+template <int NTO>
+__global__ __launch_bounds__(256) void k_spconv_bwd_weight(const float* __restrict__ in, int cin,
+                                                           const float* __restrict__ dout, int cout,
+                                                           const int32_t* __restrict__ nbr, int K, int64_t n_out,
+                                                           float* __restrict__ dw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int k = blockIdx.y;
+  const int ci = blockIdx.z * 16 + i;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * BWW_ROWS_PER_WAVE;
+  if (row0 >= n_out) return;
+  const int64_t row_end = row0 + BWW_ROWS_PER_WAVE < n_out ? row0 + BWW_ROWS_PER_WAVE : n_out;
+  f32x4 acc[NTO];
+#pragma unroll
+  for (int jt = 0; jt < NTO; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = row0; r < row_end; r += 4) {
+    const int64_t row = r + q;
+    float A = 0.f;
+    int src = -1;
+    if (row < row_end) src = nbr ? nbr[(int64_t)k * n_out + row] : (int)row;
+    if (__ballot(src >= 0) == 0ull) continue;
+    if (src >= 0 && ci < cin) A = in[(int64_t)src * cin + ci];
+#pragma unroll
+    for (int jt = 0; jt < NTO; ++jt) {
+      const int co = jt * 16 + i;
+      float B = 0.f;
+      if (src >= 0 && co < cout) B = dout[row * cout + co];
+      acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, B, acc[jt], 0, 0, 0);
+    }
+  }
+  // D[row = ci_local = 4q + r][col = co_local = i]
+#pragma unroll
+  for (int jt = 0; jt < NTO; ++jt) {
+    const int co = jt * 16 + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cil = blockIdx.z * 16 + 4 * q + r;
+      if (cil < cin && co < cout && acc[jt][r] != 0.f)
+        atomicAdd(&dw[((int64_t)k * cin + cil) * cout + co], acc[jt][r]);
+    }
+  }
+}
+
+extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, const float* dout, int32_t cout,
+                                    const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream) {
+  PP_REQUIRE(in && dout && dw, "pp_spconv_bwd_weight: null pointer");
+  PP_REQUIRE(nbr || K == 1, "pp_spconv_bwd_weight: a kernel map is required unless K == 1");
+  PP_REQUIRE(cout <= 192, "pp_spconv_bwd_weight: cout > 192 unsupported");
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
+  if (n_out == 0) return PP_OK;
+  dim3 grid(pp_blocks(n_out, 4 * BWW_ROWS_PER_WAVE), (unsigned)K, (unsigned)((cin + 15) / 16));
+  int nto = pp_nt(cout);
+#define BWW_CASE(N) \
+  case N: hipLaunchKernelGGL((k_spconv_bwd_weight<N>), grid, dim3(256), 0, s, in, cin, dout, cout, nbr, K, n_out, dw); break;
+  switch (nto) {
+    BWW_CASE(1) BWW_CASE(2) BWW_CASE(3) BWW_CASE(4) BWW_CASE(5) BWW_CASE(6) BWW_CASE(7) BWW_CASE(8) BWW_CASE(9)
+    BWW_CASE(10) BWW_CASE(11)
+    default: hipLaunchKernelGGL((k_spconv_bwd_weight<12>), grid, dim3(256), 0, s, in, cin, dout, cout, nbr, K, n_out, dw);
+  }
+#undef BWW_CASE
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

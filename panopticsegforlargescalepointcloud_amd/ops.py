@@ -1,0 +1,330 @@
+"""Torch-tensor front-end of the C-ABI (device pointers + the current HIP stream).
+
+PyTorch is plumbing here (allocation, streams); every op below is one or a few launches of the hand-written
+gfx950 kernels in csrc/.  All tensors must live on a HIP device; there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t, dtype, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.PanopticHipError("%s must be a HIP device tensor (there is no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def version():
+    return _lib.load().pp_version().decode()
+
+
+def triad(a, b, c, s):
+    lib = _lib.load()
+    _lib.check(lib.pp_triad(_ptr(a), _ptr(b), _ptr(c), s, a.numel(), _stream()), "pp_triad")
+
+
+# ------------------------------------------------------------------------------------------ coordinates
+class HashTable:
+    """Open-addressing coordinate hash living in HBM (keys uint64 as int64 storage, vals int32)."""
+
+    def __init__(self, n, device):
+        lib = _lib.load()
+        self.cap = int(lib.pp_hash_capacity(int(n)))
+        self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)
+        self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
+
+
+def hash_build(coords):
+    """coords int32 [n,4] -> (HashTable, n_duplicates, n_out_of_range)."""
+    lib = _lib.load()
+    coords = _need(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    table = HashTable(n, coords.device)
+    info = torch.zeros(2, dtype=torch.int32, device=coords.device)
+    _lib.check(lib.pp_hash_build(_ptr(coords), n, _ptr(table.keys), _ptr(table.vals), table.cap, _ptr(info), _stream()),
+               "pp_hash_build")
+    ndup, nrange = info.tolist()
+    if nrange:
+        raise _lib.PanopticHipError("%d coordinates outside the packable range (batch < 65536, |xyz| < 32768)" % nrange)
+    return table, ndup
+
+
+def stride_coords(coords, ts_out):
+    """-> (out_coords [n_out,4] int32 in first-appearance order, HashTable of out_coords, fine_to_coarse [n])."""
+    lib = _lib.load()
+    coords = _need(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    dev = coords.device
+    table = HashTable(n, dev)
+    out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    f2c = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    wsb = lib.pp_stride_coords_workspace(n)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_stride_coords(_ptr(coords), n, int(ts_out), _ptr(table.keys), _ptr(table.vals), table.cap, _ptr(out),
+                                    _ptr(n_out), _ptr(f2c), _ptr(ws), wsb, _ptr(info), _stream()), "pp_stride_coords")
+    k = int(n_out.item())
+    if int(info[1].item()):
+        raise _lib.PanopticHipError("coordinates outside the packable range")
+    return out[:k], table, f2c[:n]
+
+
+def kernel_map(out_coords, table, ksize, step, sign):
+    """nbr int32 [K, n_out]: row in `table`'s map of out_coords + sign*offset*step (or -1)."""
+    lib = _lib.load()
+    out_coords = _need(out_coords, torch.int32, "out_coords")
+    n_out = out_coords.shape[0]
+    K = ksize ** 3
+    nbr = torch.empty((K, n_out), dtype=torch.int32, device=out_coords.device)
+    _lib.check(lib.pp_kernel_map(_ptr(out_coords), n_out, _ptr(table.keys), _ptr(table.vals), table.cap, ksize, int(step),
+                                 int(sign), _ptr(nbr), _stream()), "pp_kernel_map")
+    return nbr
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def pack_weight(weight, transpose=False):
+    """ME-layout kernel [K,Cin,Cout] (or [Cin,Cout]) -> MFMA fragment order.  transpose=True packs W_k^T."""
+    lib = _lib.load()
+    w = _need(weight.detach(), torch.float32, "weight")
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, cin, cout = w.shape
+    if transpose:
+        cin, cout = cout, cin
+    packed = torch.empty(lib.pp_packed_weight_floats(K, cin, cout), dtype=torch.float32, device=w.device)
+    _lib.check(lib.pp_pack_weight(_ptr(w), K, cin, cout, int(transpose), _ptr(packed), _stream()), "pp_pack_weight")
+    return packed
+
+
+def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None):
+    lib = _lib.load()
+    in0 = _need(in0, torch.float32, "in0")
+    in1 = _need(in1, torch.float32, "in1")
+    c0 = in0.shape[1]
+    c1 = 0 if in1 is None else in1.shape[1]
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=in0.device)
+    scale = _need(scale, torch.float32, "scale")
+    shift = _need(shift, torch.float32, "shift")
+    residual = _need(residual, torch.float32, "residual")
+    _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
+                                 _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd")
+    return out
+
+
+def spconv_bwd_weight(inp, dout, nbr, K):
+    lib = _lib.load()
+    inp = _need(inp, torch.float32, "in")
+    dout = _need(dout, torch.float32, "dout")
+    cin, cout = inp.shape[1], dout.shape[1]
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=inp.device)
+    _lib.check(lib.pp_spconv_bwd_weight(_ptr(inp), cin, _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw),
+                                        _stream()), "pp_spconv_bwd_weight")
+    return dw
+
+
+def channel_stats(x):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    n, c = x.shape
+    s = torch.empty(c, dtype=torch.float64, device=x.device)
+    ss = torch.empty(c, dtype=torch.float64, device=x.device)
+    _lib.check(lib.pp_channel_stats(_ptr(x), n, c, _ptr(s), _ptr(ss), _stream()), "pp_channel_stats")
+    return s, ss
+
+
+def bn_bwd_reduce(x, dy):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    dy = _need(dy, torch.float32, "dy")
+    n, c = x.shape
+    a = torch.empty(c, dtype=torch.float64, device=x.device)
+    b = torch.empty(c, dtype=torch.float64, device=x.device)
+    _lib.check(lib.pp_bn_bwd_reduce(_ptr(x), _ptr(dy), n, c, _ptr(a), _ptr(b), _stream()), "pp_bn_bwd_reduce")
+    return a, b
+
+
+def affine_act(x, scale=None, shift=None, act=0, slope=0.0, residual=None):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    n, c = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.pp_affine_act(_ptr(x), n, c, _ptr(_need(scale, torch.float32, "scale")),
+                                 _ptr(_need(shift, torch.float32, "shift")), int(act), float(slope),
+                                 _ptr(_need(residual, torch.float32, "residual")), _ptr(y), _stream()), "pp_affine_act")
+    return y
+
+
+def head_mlp(x, w1, scale, shift, w2, b2, log_softmax=False, want_argmax=False):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    n, cin = x.shape
+    chid, cout = w1.shape[0], w2.shape[0]
+    y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    am = torch.empty(n, dtype=torch.int64, device=x.device) if want_argmax else None
+    _lib.check(lib.pp_head_mlp(_ptr(x), n, cin, _ptr(_need(w1, torch.float32, "w1")), chid,
+                               _ptr(_need(scale, torch.float32, "scale")), _ptr(_need(shift, torch.float32, "shift")),
+                               _ptr(_need(w2, torch.float32, "w2")), _ptr(_need(b2, torch.float32, "b2")), cout,
+                               int(bool(log_softmax)), _ptr(y), _ptr(am), _stream()), "pp_head_mlp")
+    return (y, am) if want_argmax else y
+
+
+# ------------------------------------------------------------------------------------------ clustering
+class ClusterCSR:
+    """Proposals as CSR: offsets int32 [n+1] (device), points int64 [total] (device)."""
+
+    def __init__(self, offsets, points, n):
+        self.offsets = offsets
+        self.points = points
+        self.n = int(n)
+
+    def sizes(self):
+        return (self.offsets[1: self.n + 1] - self.offsets[: self.n]).to(torch.int64)
+
+    def to_list(self):
+        if self.n == 0:
+            return []
+        return list(torch.split(self.points, self.sizes().tolist()))
+
+    @staticmethod
+    def from_list(clusters, device):
+        n = len(clusters)
+        sizes = torch.tensor([0] + [int(c.numel()) for c in clusters], dtype=torch.int64)
+        offsets = torch.cumsum(sizes, 0).to(torch.int32).to(device)
+        points = (torch.cat([c.reshape(-1).to(device=device, dtype=torch.int64) for c in clusters]) if n else
+                  torch.zeros(0, dtype=torch.int64, device=device))
+        return ClusterCSR(offsets, points.contiguous(), n)
+
+    @staticmethod
+    def concat(parts):
+        parts = [p for p in parts if p is not None]
+        dev = parts[0].offsets.device
+        offs = [torch.zeros(1, dtype=torch.int32, device=dev)]
+        base = 0
+        for p in parts:
+            offs.append(p.offsets[1: p.n + 1] + base)
+            base += int(p.points.numel())
+        return ClusterCSR(torch.cat(offs), torch.cat([p.points for p in parts]), sum(p.n for p in parts))
+
+
+def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_cluster_size, num_classes):
+    lib = _lib.load()
+    pos = _need(pos, torch.float32, "pos")
+    labels = _need(labels, torch.int64, "labels")
+    batch = _need(batch, torch.int64, "batch")
+    dev = pos.device
+    n = pos.shape[0]
+    ign = _need(ignore_labels.to(device=dev, dtype=torch.int64), torch.int64, "ignore_labels")
+    pc = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    offs = torch.empty(n + 2, dtype=torch.int32, device=dev)
+    pts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    wsb = lib.pp_region_grow_workspace(n, int(nsample))
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_region_grow(_ptr(pos), _ptr(labels), _ptr(batch), n, _ptr(ign), ign.numel(), int(num_classes),
+                                  int(nsample), float(radius), int(min_cluster_size), _ptr(pc), _ptr(offs), _ptr(pts),
+                                  _ptr(counts), _ptr(ws), wsb, _stream()), "pp_region_grow")
+    nc, npts = counts.tolist()
+    return ClusterCSR(offs[: nc + 1], pts[:npts], nc), pc[:n]
+
+
+def meanshift(x, sample_offsets, bandwidth, min_points_exclusive=3, max_iter=300, want_centers=False):
+    """x [m,dim] float32 (points of a sample contiguous); sample_offsets: python list / CPU tensor [ns+1]."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    m, dim = x.shape
+    dev = x.device
+    so = [int(v) for v in (sample_offsets.tolist() if torch.is_tensor(sample_offsets) else sample_offsets)]
+    ns = len(so) - 1
+    so_arr = (C.c_int64 * (ns + 1))(*so)
+    labels = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    ncl = torch.zeros(max(ns, 1), dtype=torch.int32, device=dev)
+    centers = torch.zeros((max(m, 1), dim), dtype=torch.float32, device=dev) if want_centers else None
+    wsb = lib.pp_meanshift_workspace(m, dim, ns)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_meanshift(_ptr(x), m, dim, C.cast(so_arr, C.c_void_p), ns, float(bandwidth),
+                                int(min_points_exclusive), int(max_iter), _ptr(labels), _ptr(ncl), _ptr(centers), _ptr(ws),
+                                wsb, _stream()), "pp_meanshift")
+    return labels[:m], ncl[:ns], centers
+
+
+def group_by_key(key, n_groups, ids=None):
+    lib = _lib.load()
+    key = _need(key, torch.int32, "key")
+    n = key.shape[0]
+    dev = key.device
+    ids = _need(ids, torch.int64, "ids")
+    offs = torch.empty(n_groups + 1, dtype=torch.int32, device=dev)
+    out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.pp_group_by_key_workspace(max(n, n_groups))
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_group_by_key(_ptr(key), _ptr(ids), n, int(n_groups), _ptr(offs), _ptr(out), _ptr(total), _ptr(ws),
+                                   wsb, _stream()), "pp_group_by_key")
+    return offs, out, total
+
+
+def segment_reduce(src, index, n_seg, reduce, want_arg=False):
+    lib = _lib.load()
+    src = _need(src, torch.float32, "src")
+    index = _need(index, torch.int64, "index")
+    n, c = src.shape
+    dev = src.device
+    out = torch.empty((n_seg, c), dtype=torch.float32, device=dev)
+    arg = torch.empty((n_seg, c), dtype=torch.int64, device=dev) if want_arg else None
+    wsb = lib.pp_segment_reduce_workspace(n_seg)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_segment_reduce(_ptr(src), _ptr(index), n, c, int(n_seg), _REDUCE[reduce], _ptr(out), _ptr(arg),
+                                     _ptr(ws), wsb, _stream()), "pp_segment_reduce")
+    return (out, arg) if want_arg else out
+
+
+def instance_iou_csr(csr, gt_instances, batch, gt_offsets, gt_sizes):
+    lib = _lib.load()
+    dev = gt_instances.device
+    total_gt = int(gt_sizes.numel())
+    iou = torch.zeros((csr.n, max(total_gt, 1)), dtype=torch.float32, device=dev)
+    if csr.n and total_gt:
+        iou = torch.empty((csr.n, total_gt), dtype=torch.float32, device=dev)
+        _lib.check(lib.pp_instance_iou(_ptr(csr.offsets), _ptr(csr.points), csr.n,
+                                       _ptr(_need(gt_instances, torch.int64, "gt_instances")),
+                                       _ptr(_need(batch, torch.int64, "batch")),
+                                       _ptr(_need(gt_offsets, torch.int32, "gt_offsets")),
+                                       _ptr(_need(gt_sizes, torch.int32, "gt_sizes")), total_gt, _ptr(iou), _stream()),
+                   "pp_instance_iou")
+    return iou[:, :total_gt]
+
+
+def proposal_intersections(csr, n_points):
+    lib = _lib.load()
+    dev = csr.offsets.device
+    inter = torch.zeros((csr.n, csr.n), dtype=torch.int32, device=dev)
+    if csr.n == 0:
+        return inter
+    total = int(csr.points.numel())
+    wsb = lib.pp_proposal_intersections_workspace(total, int(n_points))
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_proposal_intersections(_ptr(csr.offsets), _ptr(csr.points), csr.n, int(n_points), _ptr(inter),
+                                             _ptr(ws), wsb, _stream()), "pp_proposal_intersections")
+    return inter
