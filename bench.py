@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: end-to-end points/sec of the panoptic hot path
+(hash + kernel maps -> sparse U-Net forward -> heads -> region growing + mean shift -> ScorerUnet -> NMS / instance
+labels) on the synthetic 10M-point urban scene cut into 64 overlapping cylinder tiles (configs[3]).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over the whole scene: every rank runs its shard of the 64 tiles (tiles_per_batch
+cylinders per launch sequence) and, for N > 1, ONE RCCL all-gather of the per-tile instance labels closes the step
+(strong scaling: the scene is fixed, tiles are sharded).  Inputs (and the synthetic head statistics used for grouping,
+see DESIGN.md "what is measured") are resident in HBM before the timed region.  Random-init weights, synthetic data.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel pp_spconv_fwd, HIP
+events on the launch stream, algorithmic bytes/flops per SURVEY.md 8d) and `cpu_baseline` (CPU oracle + sklearn
+MeanShift on a bounded sample; N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s   MI355X_MICROARCH.md chip-level parameters
+FP32_MFMA_PEAK = 157.3e12  # FLOP/s (v_mfma_f32_16x16x4_f32 = fp32 vector rate)
+
+
+def env_int(name, default):
+    return int(os.environ.get(name, default))
+
+
+def build_scene(total_points, grid, voxel, seed):
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    # overlapping cylinders feed each scene voxel ~2x: size the scene so the tiles sum to ~total_points
+    scene = syn.urban_scene(int(total_points / 2.0), voxel=voxel, seed=seed)
+    tiles, radius = syn.cylinder_tiles(scene, grid)
+    fed = sum(len(t) for t in tiles)
+    # one correction pass so the fed total lands within a few % of the target
+    if abs(fed - total_points) / total_points > 0.03:
+        scene = syn.urban_scene(int(total_points / 2.0 * total_points / fed), voxel=voxel, seed=seed)
+        tiles, radius = syn.cylinder_tiles(scene, grid)
+    return scene, tiles, radius
+
+
+def build_model(device, voxel):
+    from panopticsegforlargescalepointcloud_amd.config import load_model_config
+    from panopticsegforlargescalepointcloud_amd.panoptic import PointGroup3heads
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+
+    class DS:
+        feature_dimension = 4
+        num_classes = syn.NPM3D_NUM_CLASSES
+        stuff_classes = torch.tensor(syn.NPM3D_STUFF)
+
+    cfg = load_model_config(os.path.join(ROOT, "conf", "panoptic_3heads.yaml"), "PointGroup-PAPER", data={"grid_size": voxel})
+    torch.manual_seed(2022)  # Trainer.set_seed, torch_points3d/trainer.py:278-282
+    model = PointGroup3heads(cfg, "dummy", DS, None)
+    # non-trivial BN statistics so folded scale/shift are not the identity
+    g = torch.Generator().manual_seed(7)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.05)
+            m.running_var.copy_(1.0 + 0.1 * torch.rand(m.running_var.shape, generator=g))
+    return model.to(device).eval(), cfg, DS
+
+
+def cpu_baseline(model, cfg, DS, scene, tiles, voxel):
+    """Oracle (C/OpenMP restatement) U-Net + heads + region growing + scorer, with the reference's real dependency
+    (sklearn MeanShift) for the embedding clustering, on ONE tile.  Reported baseline only."""
+    from oracle import pipeline as opipe
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    t = int(np.argsort([len(x) for x in tiles])[len(tiles) // 2])  # median-size tile
+    b = syn.tile_batch(scene, tiles, [t])
+    rng = np.random.default_rng(99)
+    cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, rng)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    opt = {"cluster_radius_search": cfg.cluster_radius_search, "cluster_type": cfg.cluster_type, "bandwidth": cfg.bandwidth}
+    try:
+        import sklearn  # noqa: F401
+        use_sk = True
+    except Exception:
+        use_sk = False
+    timings = {}
+    t0 = time.perf_counter()
+    out = opipe.forward(sd, b, opt, DS.num_classes, syn.NPM3D_STUFF, override=(cls, off, emb), use_sklearn_meanshift=use_sk,
+                        timings=timings)
+    opipe.instance_labels(out, len(b["pos"]), b["batch"])
+    dt = time.perf_counter() - t0
+    n = len(b["pos"])
+    return {"value": n / dt, "unit": "points/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 of %d tiles (%d voxels, %.1f s): C/OpenMP oracle U-Net+heads+region_grow+scorer, %s MeanShift"
+                      % (len(tiles), n, dt, "sklearn" if use_sk else "oracle"),
+            "stages_s": {k: round(v, 3) for k, v in timings.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=env_int("PP_BENCH_POINTS", 10_000_000))
+    ap.add_argument("--grid", type=int, default=env_int("PP_BENCH_GRID", 8))
+    ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 8))
+    ap.add_argument("--voxel", type=float, default=0.05)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+
+    from panopticsegforlargescalepointcloud_amd import ops, synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.scene import TileRunner, exchange_tile_results, shard_tiles
+
+    t_gen = time.perf_counter()
+    scene, tiles, radius = build_scene(args.points, args.grid, args.voxel, 2022)
+    sizes = [len(t) for t in tiles]
+    total_points = int(sum(sizes))
+    shards = shard_tiles(sizes, world)
+    mine = shards[rank]
+    model, cfg, DS = build_model(device, args.voxel)
+    runner = TileRunner(model, device)
+
+    # resident inputs: tile batches + synthetic head statistics (HBM) before the timed region
+    rng = np.random.default_rng(2022 + rank)
+    batches = []
+    for i in range(0, len(mine), args.tiles_per_batch):
+        ids = mine[i: i + args.tiles_per_batch]
+        b = syn.tile_batch(scene, tiles, ids)
+        cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, rng)
+        dev_b = {k: torch.from_numpy(v).to(device) for k, v in b.items()}
+        override = (torch.from_numpy(cls).to(device), torch.from_numpy(off).to(device), torch.from_numpy(emb).to(device))
+        starts = np.concatenate([[0], np.cumsum([len(tiles[t]) for t in ids])])
+        batches.append((ids, dev_b, override, starts))
+    t_gen = time.perf_counter() - t_gen
+
+    stats = {"proposals": 0, "instances": 0}
+
+    def step(profile=False):
+        local = {}
+        stats["proposals"] = stats["instances"] = 0
+        for ids, dev_b, override, starts in batches:
+            labels, res, counts = runner.run(dev_b, len(ids), override=override)
+            stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
+            stats["instances"] += sum(counts)
+            for j, t in enumerate(ids):
+                local[t] = (dev_b["origin_id"][starts[j]: starts[j + 1]], labels[starts[j]: starts[j + 1]])
+        return exchange_tile_results(local) if world > 1 else local
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILER = ops.LaunchProfiler()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.PROFILER.summarize()
+    ops.PROFILER = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # HBM triad to confirm the roofline denominator on this box
+    n_tri = 1 << 28
+    a = torch.empty(n_tri, device=device)
+    b2 = torch.ones(n_tri, device=device)
+    c2 = torch.ones(n_tri, device=device)
+    ops.triad(a, b2, c2, 2.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.triad(a, b2, c2, 2.0)
+    e1.record()
+    torch.cuda.synchronize()
+    triad_gbs = 5 * 3 * 4 * n_tri / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b2, c2
+
+    if rank == 0:
+        secs = prof["ms"] * 1e-3
+        t_hbm = prof["bytes"] / HBM_PEAK
+        t_mfma = prof["flops"] / FP32_MFMA_PEAK
+        if t_hbm >= t_mfma:
+            roof = {"bound": "hbm", "achieved": prof["bytes"] / secs / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": prof["flops"] / secs / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None  # PMC pass is a separate rocprofv3 run, see profiles/
+        roof.update({"kernel": "k_spconv_fwd", "launches_per_step": prof["launches"] // max(args.steps, 1),
+                     "avg_launch_us": 1e3 * prof["ms"] / max(prof["launches"], 1),
+                     "alg_GB_per_step": prof["bytes"] / args.steps / 1e9, "alg_TFLOP_per_step": prof["flops"] / args.steps / 1e12,
+                     "hbm_GBps": prof["bytes"] / secs / 1e9, "mfma_TFLOPs": prof["flops"] / secs / 1e12,
+                     "share_of_step_time": secs / dt, "triad_GBps_measured": triad_gbs})
+        out = {
+            "metric": "points/sec end-to-end (sparse-conv fwd + clustering), 10M-pt scene",
+            "value": total_points * args.steps / dt, "unit": "points/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic urban scene, %d overlapping cylinder tiles (r=%.1f m, 5 cm voxels), %d voxels fed "
+                                   "(%d unique scene voxels); setting IV: U-Net fwd + heads + region_grow(shifted) + MeanShift(embed) "
+                                   "+ ScorerUnet + NMS" % (len(tiles), radius, total_points, len(scene.pos)),
+                       "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
+                       "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
+                       "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
+                       "setup_s": round(t_gen, 1)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, cfg, DS, scene, tiles, args.voxel)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+"""CPU oracle of the WHOLE hot path (eval mode): sparse U-Net -> heads -> grouping -> scorer, driven by a state_dict.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).  Independent restatement of the
+network wiring of torch_points3d/applications/minkowski.py:160-196 and
+torch_points3d/modules/MinkowskiEngine/api_modules.py:9-82,235-311 on top of oracle/panoptic_oracle.c -- it does not
+import the product package's modules.  "Parity unpinned" vs MinkowskiEngine itself (see panoptic_oracle.c header).
+"""
+import time
+
+import numpy as np
+
+from . import oracle as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+class Maps:
+    """coordinate levels + kernel maps for one input (sorted-table lookups in C)."""
+
+    def __init__(self, coords):
+        self.levels = {1: np.ascontiguousarray(coords, np.int32)}
+        self.maps = {}
+
+    def ensure(self, ts_in, stride):
+        ts_out = ts_in * stride
+        if ts_out not in self.levels:
+            self.levels[ts_out], _ = O.stride_coords(self.levels[ts_in], ts_out)
+        return ts_out
+
+    def map(self, ts_from, ts_to, sign):
+        key = (ts_from, ts_to, sign)
+        if key not in self.maps:
+            self.maps[key] = O.kernel_map(self.levels[ts_to], self.levels[ts_from], 3, min(ts_from, ts_to), sign)
+        return self.maps[key]
+
+
+def _fold(sd, p):
+    w, b = _np(sd[p + ".bn.weight"]), _np(sd[p + ".bn.bias"])
+    m, v = _np(sd[p + ".bn.running_mean"]), _np(sd[p + ".bn.running_var"])
+    scale = w / np.sqrt(v + 1e-5)
+    return scale.astype(np.float32), (b - m * scale).astype(np.float32)
+
+
+def _conv_bn(sd, pconv, pbn, maps, x, ts_in, stride, transposed, relu, residual=None, in1=None):
+    W = _np(sd[pconv + ".kernel"])
+    sign = -1 if transposed else 1
+    if W.ndim == 2:
+        ts_out, nbr = ts_in, None
+    else:
+        ts_out = ts_in if stride == 1 else (ts_in // stride if transposed else maps.ensure(ts_in, stride))
+        nbr = maps.map(ts_in, ts_out, sign)
+    n_out = len(maps.levels[ts_out])
+    scale, shift = _fold(sd, pbn)
+    y = O.spconv_fwd(x, W, nbr, n_out, in1=in1, scale=scale, shift=shift, relu=relu, residual=residual)
+    return y, ts_out
+
+
+def _resblock(sd, p, maps, x, ts, transposed):
+    has_ds = (p + ".downsample.0.kernel") in sd
+    res = _conv_bn(sd, p + ".downsample.0", p + ".downsample.1", maps, x, ts, 1, transposed, False)[0] if has_ds else x
+    h, _ = _conv_bn(sd, p + ".block.0", p + ".block.1", maps, x, ts, 1, transposed, True)
+    y, _ = _conv_bn(sd, p + ".block.3", p + ".block.4", maps, h, ts, 1, transposed, True, residual=res)
+    return y
+
+
+def _level(sd, p, maps, x, ts, stride, transposed, n_blocks, skip=None):
+    y, ts = _conv_bn(sd, p + ".conv_in.0", p + ".conv_in.1", maps, x, ts, stride, transposed, True, in1=skip)
+    for b in range(n_blocks):
+        y = _resblock(sd, "%s.blocks.%d" % (p, b), maps, y, ts, transposed)
+    return y, ts
+
+
+def unet_forward(sd, prefix, down_strides, up_strides, n_blocks, coords, feats):
+    """coords int32 [N,4] (b,x,y,z), feats f32 [N,C] -> f32 [N,Cout], row-aligned with the input."""
+    maps = Maps(coords)
+    x, ts = np.ascontiguousarray(feats, np.float32), 1
+    stack = []
+    nd = len(down_strides)
+    for i in range(nd):
+        x, ts = _level(sd, "%s.down_modules.%d" % (prefix, i), maps, x, ts, down_strides[i], False, n_blocks)
+        stack.append((x, ts) if i < nd - 1 else None)
+    for i in range(len(up_strides)):
+        skip = stack.pop()
+        x, ts = _level(sd, "%s.up_modules.%d" % (prefix, i), maps, x, ts, up_strides[i], True, n_blocks,
+                       skip=None if skip is None else skip[0])
+    assert ts == 1
+    return x
+
+
+def _head(sd, p, x, log_softmax=False):
+    bn = p + ".0.0.1.batch_norm"
+    w, b = _np(sd[bn + ".weight"]), _np(sd[bn + ".bias"])
+    m, v = _np(sd[bn + ".running_mean"]), _np(sd[bn + ".running_var"])
+    scale = (w / np.sqrt(v + 1e-5)).astype(np.float32)
+    shift = (b - m * scale).astype(np.float32)
+    return O.head_mlp(x, _np(sd[p + ".0.0.0.weight"]), scale, shift, _np(sd[p + ".1.weight"]), _np(sd[p + ".1.bias"]),
+                      log_softmax=log_softmax, want_argmax=True)
+
+
+def nms(ious, scores, threshold):
+    ixs = scores.argsort()[::-1]
+    pick = []
+    while len(ixs) > 0:
+        i = ixs[0]
+        pick.append(i)
+        remove = np.where(ious[i, ixs[1:]] > threshold)[0] + 1
+        ixs = np.delete(ixs, remove)
+        ixs = np.delete(ixs, 0)
+    return pick
+
+
+def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False):
+    """cluster_single of torch_points3d/utils/meanshift_cluster.py:72-123 (one MeanShift per batch element)."""
+    out = []
+    for s in np.unique(batch):
+        m = batch == s
+        if m.sum() <= 3:
+            continue
+        x = emb[m]
+        if use_sklearn:
+            from sklearn.cluster import MeanShift
+            labels = MeanShift(bandwidth=bandwidth, bin_seeding=True).fit(x).labels_
+        else:
+            labels, _, _ = O.meanshift(x, [0, len(x)], bandwidth)
+        li = local_ind[m]
+        for l in np.unique(labels):
+            if l == -1:
+                continue
+            out.append(li[labels == l])
+    return out
+
+
+def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None):
+    """Eval forward of PointGroup3heads (setting IV / cluster_type 5 or type 1) on CPU.
+    data: dict with pos [N,3], coords [N,3], batch [N], x [N,4].  Returns dict of outputs."""
+    T = {} if timings is None else timings
+    t0 = time.perf_counter()
+    coords4 = np.concatenate([data["batch"][:, None], data["coords"]], 1).astype(np.int32)
+    feats = unet_forward(sd, "Backbone", [1, 2, 2, 2, 2, 2, 2], [2, 2, 2, 2, 2, 2, 1], 2, coords4, data["x"])
+    T["unet"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sem, pred = _head(sd, "Semantic", feats, log_softmax=True)
+    off, _ = _head(sd, "Offset", feats)
+    emb, _ = _head(sd, "Embed", feats)
+    T["heads"] = time.perf_counter() - t0
+    if override is not None:
+        pred, off, emb = override
+    ignore = [-1] + [int(c) for c in stuff_classes]
+    t0 = time.perf_counter()
+    votes, _ = O.region_grow(data["pos"] + off, pred, data["batch"], ignore, nsample=200,
+                             radius=float(opt["cluster_radius_search"]), min_cluster_size=10)
+    T["region_grow"] = time.perf_counter() - t0
+    clusters, ctype = list(votes), [0] * len(votes)
+    if int(opt["cluster_type"]) == 5:
+        t0 = time.perf_counter()
+        mask = ~np.isin(pred, ignore)
+        ms = meanshift_clusters(emb[mask], data["batch"][mask], np.nonzero(mask)[0], float(opt["bandwidth"]),
+                                use_sklearn=use_sklearn_meanshift)
+        T["meanshift"] = time.perf_counter() - t0
+        clusters += ms
+        ctype += [1] * len(ms)
+    scores = None
+    if clusters:
+        t0 = time.perf_counter()
+        pts = np.concatenate(clusters)
+        b = np.concatenate([np.full(len(c), i) for i, c in enumerate(clusters)])
+        sc_coords = np.concatenate([b[:, None], data["coords"][pts]], 1).astype(np.int32)
+        sf = unet_forward(sd, "ScorerUnet", [2, 2], [2, 2], 2, sc_coords, feats[pts])
+        cf, _ = O.segment_reduce(sf, b, len(clusters), "max")
+        w, bb = _np(sd["ScorerHead.0.weight"]), _np(sd["ScorerHead.0.bias"])
+        scores = 1.0 / (1.0 + np.exp(-(cf @ w.T + bb)[:, 0]))
+        T["scorer"] = time.perf_counter() - t0
+    return {"features": feats, "semantic_logits": sem, "offset_logits": off, "embed_logits": emb, "pred": pred,
+            "clusters": clusters, "cluster_type": np.asarray(ctype, np.uint8), "cluster_scores": scores}
+
+
+def instance_labels(out, n_points, batch, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
+    """get_instances + get_cur_ins_pre_label per batch element (tracker :326-337, structure_3heads.py:28-71)."""
+    labels = np.full(n_points, -1, np.int32)
+    clusters, scores = out["clusters"], out["cluster_scores"]
+    if not clusters:
+        return labels
+    tile = np.asarray([batch[c[0]] for c in clusters])
+    for t in np.unique(tile):
+        ids = np.nonzero(tile == t)[0]
+        cl = [clusters[i] for i in ids]
+        inter = O.proposal_intersections(cl, n_points).astype(np.float32)
+        sz = np.diag(inter).copy()
+        ious = inter / (sz[:, None] + sz[None, :] - inter)
+        sc = scores[ids]
+        pick = nms(ious, sc, nms_threshold)
+        keep = [i for i in pick if sz[i] > min_cluster_points and sc[i] > min_score]
+        order = [keep[j] for j in np.argsort(sc[keep], kind="stable")] if keep else []
+        for rank, i in enumerate(order):
+            labels[cl[i]] = rank
+    return labels

@@ -1,0 +1,433 @@
+"""MinkowskiEngine-compatible module surface backed by libpanoptic_hip.so (MI355X).
+
+Only the symbols the reference's hot path uses are provided:
+  SparseTensor(features, coordinates, device) with .F .C and `+`     applications/minkowski.py:121-122, api_modules.py:79-81
+  MinkowskiConvolution / MinkowskiConvolutionTranspose (.kernel)      api_modules.py:30-51,259-267
+  MinkowskiBatchNorm (.bn = BatchNorm1d, settable momentum)           api_modules.py:40 ; core/schedulers/bn_schedulers.py:6-31
+  MinkowskiReLU, MinkowskiNetwork, cat, utils.kaiming_normal_        api_modules.py:41,308 ; applications/minkowski.py:104-111
+  (MinkowskiLinear, MinkowskiSigmoid, MinkowskiGlobalPooling, MinkowskiBroadcastMultiplication: imported by
+   api_modules.py:176-186 for SE blocks that no panoptic config uses; provided as thin modules.)
+
+Not MinkowskiEngine's object model: one CoordinateManager per input holds flat device arrays (COO rows, an
+open-addressing hash per tensor stride, offset-major kernel maps) shared by every tensor derived from that input.
+Use as a drop-in:   import panopticsegforlargescalepointcloud_amd.MinkowskiEngine as ME
+or                  sys.modules["MinkowskiEngine"] = panopticsegforlargescalepointcloud_amd.MinkowskiEngine
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from . import utils  # noqa: F401
+
+
+# ------------------------------------------------------------------------------------------------
+# coordinate manager
+# ------------------------------------------------------------------------------------------------
+class _Level:
+    __slots__ = ("coords", "table", "n")
+
+    def __init__(self, coords, table):
+        self.coords = coords
+        self.table = table
+        self.n = coords.shape[0]
+
+
+class CoordinateManager:
+    """Coordinate levels (tensor stride -> COO rows + hash) and kernel maps, cached for one input.
+
+    map(ts_from, ts_to, ksize, sign)[k, o] = row at level ts_from of  coords[ts_to][o] + sign*offset_k*step,
+    step = min(ts_from, ts_to).  sign=+1 is a convolution, sign=-1 a transposed convolution; the map needed
+    for the input gradient of map(A->B, sign) is map(B->A, -sign)."""
+
+    def __init__(self, coords):
+        if coords.dtype != torch.int32:
+            coords = coords.to(torch.int32)
+        coords = coords.contiguous()
+        table, ndup = ops.hash_build(coords)
+        if ndup:
+            raise ValueError("%d duplicate coordinates: the input must hold one row per (batch, x, y, z) "
+                             "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
+        self.levels = {1: _Level(coords, table)}
+        self.maps = {}
+
+    def level(self, ts):
+        return self.levels[ts]
+
+    def ensure_stride(self, ts_in, stride):
+        ts_out = ts_in * stride
+        if ts_out not in self.levels:
+            src = self.levels[ts_in]
+            out, table, _ = ops.stride_coords(src.coords, ts_out)
+            self.levels[ts_out] = _Level(out, table)
+        return ts_out
+
+    def kernel_map(self, ts_from, ts_to, ksize, sign):
+        if ksize == 1:
+            if ts_from != ts_to:
+                raise NotImplementedError("1x1x1 convolutions with stride > 1 are not used by the reference path")
+            return None
+        key = (ts_from, ts_to, ksize, sign)
+        m = self.maps.get(key)
+        if m is None:
+            if ts_to not in self.levels:
+                raise ValueError("transposed convolution onto tensor stride %d: that coordinate map was never created" % ts_to)
+            m = ops.kernel_map(self.levels[ts_to].coords, self.levels[ts_from].table, ksize, min(ts_from, ts_to), sign)
+            self.maps[key] = m
+        return m
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse tensor
+# ------------------------------------------------------------------------------------------------
+class SparseTensor:
+    def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1, **kwargs):
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("SparseTensor needs coordinates or a coordinate_manager")
+            dev = torch.device(device) if device is not None else features.device
+            if dev.type != "cuda":
+                raise ops._lib.PanopticHipError("SparseTensor must live on a HIP device (no CPU fallback)")
+            coordinates = coordinates.to(dev)
+            features = features.to(dev)
+            coordinate_manager = CoordinateManager(coordinates)
+        self._F = features
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = int(tensor_stride)
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.level(self.tensor_stride).coords
+
+    @property
+    def device(self):
+        return self._F.device
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    def _like(self, feats):
+        return SparseTensor(feats, coordinate_manager=self.coordinate_manager, tensor_stride=self.tensor_stride)
+
+    def __add__(self, other):
+        if isinstance(other, SparseTensor):
+            if other.coordinate_manager is not self.coordinate_manager or other.tensor_stride != self.tensor_stride:
+                raise ValueError("SparseTensor + SparseTensor needs the same coordinate map")
+            return self._like(self._F + other._F)
+        return self._like(self._F + other)
+
+    def __repr__(self):
+        return "SparseTensor(F=%s, tensor_stride=%d)" % (tuple(self._F.shape), self.tensor_stride)
+
+
+def cat(*tensors):
+    """Channel concat on the same coordinate map (ME.cat, api_modules.py:308)."""
+    a = tensors[0]
+    for t in tensors[1:]:
+        if t.coordinate_manager is not a.coordinate_manager or t.tensor_stride != a.tensor_stride:
+            raise ValueError("ME.cat: tensors must share the coordinate map")
+    return a._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd functions (training path); eval uses the fused entry points below
+# ------------------------------------------------------------------------------------------------
+class _SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K):
+        feats = feats.contiguous()
+        packed = ops.pack_weight(kernel)
+        cout = kernel.shape[-1]
+        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K)
+        ctx.save_for_backward(feats, kernel)
+        ctx.nbr, ctx.inv_fn, ctx.K = nbr, inv_fn, K
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, kernel = ctx.saved_tensors
+        dout = dout.contiguous()
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            packed_t = ops.pack_weight(kernel, transpose=True)
+            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K)
+        if ctx.needs_input_grad[1]:
+            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K).reshape(kernel.shape)
+        return din, dw, None, None, None, None
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """y = (x - mean) * rstd * w + b with batch statistics (biased variance), stats from pp_channel_stats."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = x.contiguous()
+        n = x.shape[0]
+        s, ss = ops.channel_stats(x)
+        mean = s / n
+        var = torch.clamp(ss / n - mean * mean, min=0.0)
+        rstd = torch.rsqrt(var + eps)
+        scale = (weight.double() * rstd).float()
+        shift = (bias.double() - mean * weight.double() * rstd).float()
+        y = ops.affine_act(x, scale, shift, act=1 if relu else 0)
+        ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
+        ctx.relu = relu
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, weight, mean, rstd, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0)
+        n = x.shape[0]
+        s1, s2 = ops.bn_bwd_reduce(x, dy)  # sum(dy), sum(dy*x)
+        w = weight.double()
+        m2 = (s2 - mean * s1) * rstd / n  # mean(dy * xhat)
+        a = (w * rstd).float()
+        b = (-w * m2 * rstd * rstd).float()
+        c = (w * rstd * (-s1 / n + mean * m2 * rstd)).float()
+        t = ops.affine_act(x, b, c)
+        dx = ops.affine_act(dy, a, None, residual=t)
+        dweight = ((s2 - mean * s1) * rstd).float()
+        dbias = s1.float()
+        return dx, dweight, dbias, None, None
+
+
+class _AffineFn(torch.autograd.Function):
+    """y = act(x*scale + shift) with constant scale/shift (eval-mode BN, ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, act):
+        y = ops.affine_act(x.contiguous(), scale, shift, act=act)
+        ctx.save_for_backward(scale, y if act == 1 else None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, y = ctx.saved_tensors
+        if ctx.act == 1:
+            dy = dy * (y > 0)
+        if scale is not None:
+            dy = ops.affine_act(dy.contiguous(), scale, None)
+        return dy, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# modules
+# ------------------------------------------------------------------------------------------------
+class MinkowskiNetwork(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+
+def _to_int(v, name):
+    if isinstance(v, (list, tuple)):
+        if len(set(int(x) for x in v)) != 1:
+            raise NotImplementedError("anisotropic %s is not used by the reference path" % name)
+        v = v[0]
+    return int(v)
+
+
+class _ConvBase(nn.Module):
+    TRANSPOSED = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, kernel_generator=None,
+                 dimension=-1, **kwargs):
+        super().__init__()
+        if dimension not in (3, -1):
+            raise NotImplementedError("only 3-D sparse convolutions are implemented")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _to_int(kernel_size, "kernel_size")
+        self.stride = _to_int(stride, "stride")
+        self.dilation = _to_int(dilation, "dilation")
+        if self.kernel_size not in (1, 3):
+            raise NotImplementedError("kernel_size must be 1 or 3 (what the panoptic configs use)")
+        if self.dilation != 1:
+            raise NotImplementedError("dilation != 1 is not used by the reference path")
+        self.kernel_volume = self.kernel_size ** 3
+        shape = (self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1 else (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.zeros(1, out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = None
+
+    def reset_parameters(self):
+        # ME default: uniform(-stdv, stdv), stdv = 1/sqrt(in_channels * kernel_volume)
+        stdv = 1.0 / math.sqrt(self.in_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+
+    def packed(self):
+        k = self.kernel
+        tag = (k._version, k.data_ptr(), k.device)
+        if self._packed is None or self._packed[0] != tag:
+            self._packed = (tag, ops.pack_weight(k))
+        return self._packed[1]
+
+    def out_stride_and_map(self, x):
+        """-> (ts_out, nbr forward map, callable giving the input-gradient map)"""
+        cm = x.coordinate_manager
+        ts_in = x.tensor_stride
+        sign = -1 if self.TRANSPOSED else 1
+        if self.stride == 1:
+            ts_out = ts_in
+        elif self.TRANSPOSED:
+            if ts_in % self.stride:
+                raise ValueError("transposed convolution: tensor stride %d not divisible by stride %d" % (ts_in, self.stride))
+            ts_out = ts_in // self.stride
+        else:
+            ts_out = cm.ensure_stride(ts_in, self.stride)
+        ks = self.kernel_size
+        nbr = cm.kernel_map(ts_in, ts_out, ks, sign)
+        return ts_out, nbr, (lambda: cm.kernel_map(ts_out, ts_in, ks, -sign))
+
+    def forward(self, x):
+        ts_out, nbr, inv_fn = self.out_stride_and_map(x)
+        n_out = x.coordinate_manager.level(ts_out).n
+        feats = _SparseConvFn.apply(x.F, self.kernel, nbr, inv_fn, n_out, self.kernel_volume)
+        if self.bias is not None:
+            feats = feats + self.bias
+        return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=ts_out)
+
+    def extra_repr(self):
+        return "in=%d, out=%d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels, self.kernel_size, self.stride)
+
+
+class MinkowskiConvolution(_ConvBase):
+    TRANSPOSED = False
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    TRANSPOSED = True
+
+
+class MinkowskiBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+        self._folded = None
+
+    # bn_schedulers.py:6-31 sets `.momentum` on the module
+    @property
+    def momentum(self):
+        return self.bn.momentum
+
+    @momentum.setter
+    def momentum(self, v):
+        self.bn.momentum = v
+
+    def folded(self):
+        """(scale, shift) of the eval-mode affine map, cached until a parameter/buffer changes."""
+        bn = self.bn
+        tag = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               bn.weight.data_ptr(), bn.weight.device)
+        if self._folded is None or self._folded[0] != tag:
+            with torch.no_grad():
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+            self._folded = (tag, scale.contiguous(), shift.contiguous())
+        return self._folded[1], self._folded[2]
+
+    def features_forward(self, feats, relu=False):
+        bn = self.bn
+        if self.training or not bn.track_running_stats:
+            y, mean, var = _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu)
+            if bn.track_running_stats:
+                with torch.no_grad():
+                    n = feats.shape[0]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    unbiased = var * (n / max(n - 1, 1))
+                    bn.running_mean.mul_(1 - mom).add_(mean.float() * mom)
+                    bn.running_var.mul_(1 - mom).add_(unbiased.float() * mom)
+                    bn.num_batches_tracked += 1
+            return y
+        scale, shift = self.folded()
+        return _AffineFn.apply(feats, scale, shift, 1 if relu else 0)
+
+    def forward(self, x):
+        return x._like(self.features_forward(x.F))
+
+    def __repr__(self):
+        return "MinkowskiBatchNorm(%s)" % self.bn.extra_repr()
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return x._like(_AffineFn.apply(x.F, None, None, 1))
+
+
+class MinkowskiSigmoid(nn.Module):
+    def forward(self, x):
+        return x._like(torch.sigmoid(x.F))
+
+
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return x._like(self.linear(x.F))
+
+
+class MinkowskiGlobalPooling(nn.Module):
+    """Average of the features of each batch element (one row per batch element, tensor stride kept)."""
+
+    def forward(self, x):
+        b = x.C[:, 0].long()
+        nb = int(b.max().item()) + 1 if b.numel() else 0
+        pooled = ops.segment_reduce(x.F.contiguous(), b, nb, "mean")
+        out = SparseTensor.__new__(SparseTensor)
+        out._F, out.coordinate_manager, out.tensor_stride = pooled, x.coordinate_manager, x.tensor_stride
+        out._batch_rows = True
+        return out
+
+
+class MinkowskiBroadcastMultiplication(nn.Module):
+    def forward(self, x, pooled):
+        b = x.C[:, 0].long()
+        return x._like(x.F * pooled.F[b])
+
+
+# ------------------------------------------------------------------------------------------------
+# fused eval entry point used by the build-owned ResBlock / ResNetDown / ResNetUp
+# ------------------------------------------------------------------------------------------------
+def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
+    """Eval-mode  relu?(BN(conv(cat(x, skip)))) + residual  as ONE kernel launch (folded BN in the epilogue,
+    ME.cat fused as a second source).  x/skip/residual are SparseTensors on compatible maps."""
+    ts_out, nbr, _ = conv.out_stride_and_map(x)
+    cm = x.coordinate_manager
+    n_out = cm.level(ts_out).n
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn.folded()
+    in1 = None
+    if skip is not None:
+        if skip.coordinate_manager is not cm or skip.tensor_stride != x.tensor_stride:
+            raise ValueError("fused cat: tensors must share the coordinate map")
+        in1 = skip.F
+    res = None
+    if residual is not None:
+        if residual.tensor_stride != ts_out:
+            raise ValueError("residual on a different tensor stride")
+        res = residual.F
+    feats = ops.spconv_fwd(x.F, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1, scale=scale,
+                           shift=shift, relu=relu, residual=res)
+    if conv.bias is not None:
+        raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
+    return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

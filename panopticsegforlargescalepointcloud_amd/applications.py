@@ -1,0 +1,209 @@
+"""`Minkowski(architecture, input_nc, num_layers, config)` -- the backbone factory the reference models call
+(torch_points3d/applications/minkowski.py:25-196), rebuilt on the MI355X ME surface.
+
+Keeps: the compact-YAML assembly of torch_points3d/models/base_architectures/unet.py:400-474 (down_modules /
+inner_modules / up_modules, per-level kwargs fetched from lists), kaiming init of MinkowskiConvolution kernels and
+BN weight 1 / bias 0 (applications/minkowski.py:104-111), the forward order with the skip stack
+(applications/minkowski.py:160-196) and the row-order guarantee: output row i belongs to input row i.
+"""
+import copy
+
+import torch
+from torch import nn
+
+from . import MinkowskiEngine as ME
+from . import modules as _modules
+from .config import Config, is_list, resolve_model, to_config
+from .modules import MLP, Identity
+from . import ops
+
+SPECIAL_NAMES = ["radius", "max_num_neighbors", "block_names"]
+
+
+class Data:
+    """Attribute bag standing in for torch_geometric.data.Data / Batch (only what the path touches)."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith("_")]
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def __contains__(self, k):
+        return k in self.__dict__
+
+    def to(self, device):
+        out = Data()
+        for k, v in self.__dict__.items():
+            setattr(out, k, v.to(device) if torch.is_tensor(v) else v)
+        return out
+
+
+Batch = Data
+
+
+class GlobalBaseModule(nn.Module):
+    """Innermost module of the (unused when scorer_type == 'unet') ScorerEncoder:
+    torch_points3d/core/base_conv/message_passing.py:132-151.  MLP then per-batch-element pooling."""
+
+    def __init__(self, nn=None, aggr="max", *args, **kwargs):
+        super().__init__()
+        self.nn = MLP(nn)
+        self.aggr = "max" if aggr == "max" else "mean"
+
+    def forward(self, data, **kwargs):
+        x = self.nn(data.x)
+        nb = int(data.batch.max().item()) + 1
+        x = ops.segment_reduce(x.contiguous(), data.batch.long(), nb, self.aggr)
+        return Data(x=x, batch=torch.arange(nb, device=x.device))
+
+
+class _ModulesLib:
+    ResNetDown = _modules.ResNetDown
+    ResNetUp = _modules.ResNetUp
+    ResBlock = _modules.ResBlock
+    GlobalBaseModule = GlobalBaseModule
+
+
+def extract_output_nc(model_config):
+    if model_config.get("up_conv") is not None:
+        return model_config.up_conv.up_conv_nn[-1][-1]
+    if model_config.get("innermost") is not None:
+        return model_config.innermost.nn[-1]
+    raise ValueError("Input model_config does not match expected pattern")
+
+
+class UnwrappedUnetBasedModel(nn.Module):
+    def __init__(self, opt, model_type, dataset, modules_lib):
+        super().__init__()
+        opt = copy.deepcopy(opt)
+        self.opt = opt
+        if is_list(opt.down_conv) or "down_conv_nn" not in opt.down_conv:
+            raise NotImplementedError
+        self.down_modules = nn.ModuleList()
+        self.inner_modules = nn.ModuleList()
+        self.up_modules = nn.ModuleList()
+        if opt.get("innermost") is not None:
+            args = dict(opt.innermost)
+            cls = getattr(modules_lib, args.pop("module_name"))
+            self.inner_modules.append(cls(**args))
+        else:
+            self.inner_modules.append(Identity())
+        for i in range(len(opt.down_conv.down_conv_nn)):
+            args = self._fetch_arguments_from_list(opt.down_conv, i)
+            cls = getattr(modules_lib, args.pop("module_name"))
+            self.down_modules.append(cls(index=i, **args))
+        if opt.get("up_conv") is not None:
+            for i in range(len(opt.up_conv.up_conv_nn)):
+                args = self._fetch_arguments_from_list(opt.up_conv, i)
+                cls = getattr(modules_lib, args.pop("module_name"))
+                self.up_modules.append(cls(index=i, **args))
+
+    @staticmethod
+    def _fetch_arguments_from_list(opt, index):
+        args = {}
+        for o, v in opt.items():
+            name = str(o)
+            if is_list(v) and len(v) > 0:
+                if name[-1] == "s" and name not in SPECIAL_NAMES:
+                    name = name[:-1]
+                v_index = v[index]
+                if is_list(v_index):
+                    v_index = list(v_index)
+                args[name] = v_index
+            else:
+                args[name] = list(v) if is_list(v) else v
+        return args
+
+
+class BaseMinkowski(UnwrappedUnetBasedModel):
+    CONV_TYPE = "sparse"
+
+    def __init__(self, model_config, model_type, dataset, modules, *args, **kwargs):
+        super().__init__(model_config, model_type, dataset, modules)
+        self.weight_initialization()
+        default_output_nc = kwargs.get("default_output_nc", None) or extract_output_nc(model_config)
+        self._output_nc = default_output_nc
+        self._has_mlp_head = False
+        if "output_nc" in kwargs:
+            self._has_mlp_head = True
+            self._output_nc = kwargs["output_nc"]
+            self.mlp = MLP([default_output_nc, self.output_nc], activation=nn.LeakyReLU(0.2), bias=False)
+
+    @property
+    def has_mlp_head(self):
+        return self._has_mlp_head
+
+    @property
+    def output_nc(self):
+        return self._output_nc
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, ME.MinkowskiConvolution):
+                ME.utils.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
+            if isinstance(m, ME.MinkowskiBatchNorm):
+                nn.init.constant_(m.bn.weight, 1)
+                nn.init.constant_(m.bn.bias, 0)
+
+    def _set_input(self, data):
+        dev = self.device
+        coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
+        self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev)
+        self.xyz = data.pos.to(dev) if getattr(data, "pos", None) is not None else data.coords.to(dev)
+
+
+class MinkowskiEncoder(BaseMinkowski):
+    def forward(self, data, *args, **kwargs):
+        self._set_input(data)
+        data = self.input
+        for m in self.down_modules:
+            data = m(data)
+        out = Batch(x=data.F, batch=data.C[:, 0].long())
+        if not isinstance(self.inner_modules[0], Identity):
+            out = self.inner_modules[0](out)
+        if self.has_mlp_head:
+            out.x = self.mlp(out.x)
+        return out
+
+
+class MinkowskiUnet(BaseMinkowski):
+    def forward(self, data, *args, **kwargs):
+        self._set_input(data)
+        data = self.input
+        stack_down = []
+        for i in range(len(self.down_modules) - 1):
+            data = self.down_modules[i](data)
+            stack_down.append(data)
+        data = self.down_modules[-1](data)
+        stack_down.append(None)
+        for i in range(len(self.up_modules)):
+            data = self.up_modules[i](data, stack_down.pop())
+        out = Data(x=data.F, pos=self.xyz, batch=data.C[:, 0])
+        if self.has_mlp_head:
+            out.x = self.mlp(out.x)
+        return out
+
+
+def Minkowski(architecture=None, input_nc=None, num_layers=None, config=None, *args, **kwargs):
+    """Create a sparse U-Net / encoder backbone (reference signature, applications/minkowski.py:25-54)."""
+    if not architecture:
+        raise ValueError()
+    architecture = architecture.lower()
+    if architecture not in ("unet", "encoder"):
+        raise Exception("The provided argument model_architecture with value {} isn't within {}".format(
+            architecture, ["unet", "encoder", "decoder"]))
+    if not config:
+        raise NotImplementedError("default applications/conf/sparseconv3d/*.yaml fallbacks are not shipped; pass config=")
+    model_config = to_config(copy.deepcopy(config)) if not isinstance(config, Config) else copy.deepcopy(config)
+    resolve_model(model_config, input_nc, kwargs)
+    cls = MinkowskiUnet if architecture == "unet" else MinkowskiEncoder
+    return cls(model_config, None, None, _ModulesLib, **kwargs)

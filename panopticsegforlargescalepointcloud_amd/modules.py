@@ -1,0 +1,163 @@
+"""Build-owned mirror of the reference's sparse U-Net building blocks, on the MI355X ME surface.
+
+Same class names, constructor arguments, sub-module names (=> identical state_dict keys and shapes, SURVEY.md
+App. A) and forward semantics as
+  torch_points3d/modules/MinkowskiEngine/api_modules.py:9-82 (ResBlock), :235-285 (ResNetDown), :288-311 (ResNetUp)
+  torch_points3d/core/common_modules/base_modules.py:35-45 (MLP), :128-153 (FastBatchNorm1d), :156-164 (Seq).
+In eval mode every conv -> BN -> ReLU (+ residual, + skip concat) chain is ONE fused kernel launch
+(ME.conv_bn_act); in training mode the modules run unfused through autograd Functions.
+"""
+import sys
+
+import torch
+from torch import nn
+
+from . import MinkowskiEngine as ME
+from . import ops
+
+
+class Seq(nn.Sequential):
+    def __init__(self):
+        super().__init__()
+        self._num_modules = 0
+
+    def append(self, module):
+        self.add_module(str(self._num_modules), module)
+        self._num_modules += 1
+        return self
+
+
+class Identity(nn.Module):
+    def forward(self, data):
+        return data
+
+
+class FastBatchNorm1d(nn.Module):
+    def __init__(self, num_features, momentum=0.1, **kwargs):
+        super().__init__()
+        self.batch_norm = nn.BatchNorm1d(num_features, momentum=momentum, **kwargs)
+
+    def forward(self, x):
+        if x.dim() == 2:
+            return self.batch_norm(x)
+        if x.dim() == 3:
+            return self.batch_norm(x.permute(0, 2, 1)).permute(0, 2, 1)
+        raise ValueError("Non supported number of dimensions {}".format(x.dim()))
+
+
+def MLP(channels, activation=None, bn_momentum=0.1, bias=True):
+    activation = activation if activation is not None else nn.LeakyReLU(0.2)
+    return nn.Sequential(*[
+        nn.Sequential(nn.Linear(channels[i - 1], channels[i], bias=bias),
+                      FastBatchNorm1d(channels[i], momentum=bn_momentum), activation)
+        for i in range(1, len(channels))
+    ])
+
+
+def fused_head(head, x, log_softmax=False, want_argmax=False):
+    """Eval-mode fused launch of a head  Seq[ MLP([c, c], bias=False), Linear(c, k) (, LogSoftmax) ]
+    (PointGroup3heads.py:69-81).  Falls back to the torch modules in training mode (autograd)."""
+    mlp = head[0]
+    lin1, fbn = mlp[0][0], mlp[0][1]
+    lin2 = head[1]
+    bn = fbn.batch_norm
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        if lin1.bias is not None:
+            shift = shift + lin1.bias * scale
+    return ops.head_mlp(x.contiguous(), lin1.weight, scale.contiguous(), shift.contiguous(), lin2.weight, lin2.bias,
+                        log_softmax=log_softmax, want_argmax=want_argmax)
+
+
+class ResBlock(ME.MinkowskiNetwork):
+    """conv3-BN-ReLU-conv3-BN-ReLU, plus (1x1 conv-BN of the input | the input); ReLU BEFORE the add, none after."""
+
+    def __init__(self, input_nc, output_nc, convolution, dimension=3):
+        ME.MinkowskiNetwork.__init__(self, dimension)
+        self.block = (
+            Seq()
+            .append(convolution(in_channels=input_nc, out_channels=output_nc, kernel_size=3, stride=1, dilation=1,
+                                bias=False, dimension=dimension))
+            .append(ME.MinkowskiBatchNorm(output_nc))
+            .append(ME.MinkowskiReLU())
+            .append(convolution(in_channels=output_nc, out_channels=output_nc, kernel_size=3, stride=1, dilation=1,
+                                bias=False, dimension=dimension))
+            .append(ME.MinkowskiBatchNorm(output_nc))
+            .append(ME.MinkowskiReLU())
+        )
+        if input_nc != output_nc:
+            self.downsample = (
+                Seq()
+                .append(convolution(in_channels=input_nc, out_channels=output_nc, kernel_size=1, stride=1, dilation=1,
+                                    bias=False, dimension=dimension))
+                .append(ME.MinkowskiBatchNorm(output_nc))
+            )
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            b = self.block
+            res = ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False) if self.downsample else x
+            h = ME.conv_bn_act(x, b[0], b[1], relu=True)
+            return ME.conv_bn_act(h, b[3], b[4], relu=True, residual=res)
+        out = self.block(x)
+        if self.downsample:
+            out = out + self.downsample(x)
+        else:
+            out = out + x
+        return out
+
+
+_res_blocks = sys.modules[__name__]
+
+
+class ResNetDown(ME.MinkowskiNetwork):
+    CONVOLUTION = ME.MinkowskiConvolution
+
+    def __init__(self, down_conv_nn=[], kernel_size=2, dilation=1, dimension=3, stride=2, N=1, block="ResBlock", **kwargs):
+        block = getattr(_res_blocks, block)
+        ME.MinkowskiNetwork.__init__(self, dimension)
+        conv1_output = down_conv_nn[0] if stride > 1 else down_conv_nn[1]
+        self.conv_in = (
+            Seq()
+            .append(self.CONVOLUTION(in_channels=down_conv_nn[0], out_channels=conv1_output, kernel_size=kernel_size,
+                                     stride=stride, dilation=dilation, bias=False, dimension=dimension))
+            .append(ME.MinkowskiBatchNorm(conv1_output))
+            .append(ME.MinkowskiReLU())
+        )
+        if N > 0:
+            self.blocks = Seq()
+            for _ in range(N):
+                self.blocks.append(block(conv1_output, down_conv_nn[1], self.CONVOLUTION, dimension=dimension))
+                conv1_output = down_conv_nn[1]
+        else:
+            self.blocks = None
+
+    def _conv_in(self, x, skip=None):
+        if not self.training and not torch.is_grad_enabled():
+            return ME.conv_bn_act(x, self.conv_in[0], self.conv_in[1], relu=True, skip=skip)
+        if skip is not None:
+            x = ME.cat(x, skip)
+        return self.conv_in(x)
+
+    def forward(self, x):
+        out = self._conv_in(x)
+        if self.blocks:
+            out = self.blocks(out)
+        return out
+
+
+class ResNetUp(ResNetDown):
+    CONVOLUTION = ME.MinkowskiConvolutionTranspose
+
+    def __init__(self, up_conv_nn=[], kernel_size=2, dilation=1, dimension=3, stride=2, N=1, **kwargs):
+        super().__init__(down_conv_nn=up_conv_nn, kernel_size=kernel_size, dilation=dilation, dimension=dimension,
+                         stride=stride, N=N, **kwargs)
+
+    def forward(self, x, skip):
+        out = self._conv_in(x, skip)  # ME.cat(x, skip): upsampled channels first, then the skip's
+        if self.blocks:
+            out = self.blocks(out)
+        return out

@@ -12,6 +12,36 @@ from . import _lib
 _REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the dominant kernel (pp_spconv_fwd) with HIP events recorded on the stream the
+    kernel is launched on (bench.py uses it for the roofline object; off by default)."""
+
+    def __init__(self):
+        self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual)
+
+    def summarize(self):
+        torch.cuda.synchronize()
+        pairs = {}
+        tot_ms = tot_bytes = tot_flops = 0.0
+        for (e0, e1, n_in, n_out, cin, cout, K, nbr, has_res) in self.records:
+            if nbr is None:
+                P = n_out
+            else:
+                key = nbr.data_ptr()
+                if key not in pairs:
+                    pairs[key] = int((nbr >= 0).sum().item())
+                P = pairs[key]
+            # SURVEY.md 8(d): features read once + written once, weights once, one (in,out) int32 pair per map entry
+            b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
+            tot_bytes += b
+            tot_flops += 2.0 * P * cin * cout
+            tot_ms += e0.elapsed_time(e1)
+        return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops}
+
+
+PROFILER = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -128,8 +158,16 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     scale = _need(scale, torch.float32, "scale")
     shift = _need(shift, torch.float32, "shift")
     residual = _need(residual, torch.float32, "residual")
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
                                  _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd")
+    if prof is not None:
+        e1.record()
+        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, nbr, residual is not None))
     return out
 
 

@@ -1,0 +1,235 @@
+"""PointGroup3heads -- the reference's 3-head panoptic model (semantic + offset + embedding heads on a sparse
+U-Net, region growing / mean shift proposals, ScorerUnet), on the MI355X kernels.
+
+Mirrors torch_points3d/models/panoptic/PointGroup3heads.py: constructor arguments and sub-module names
+(=> state_dict keys of SURVEY.md App. A), set_input :95-99, forward :101-157, _cluster/_cluster2/_cluster5/_cluster6
+:163-210,291-391, _compute_score :393-454, _compute_loss :552-634, backward :636-639.
+
+What is different by design (MI355X-first, results unchanged): everything stays device-resident -- proposals travel
+as CSR (ops.ClusterCSR) instead of Python lists until the caller asks for lists; mean shift runs for all cylinders of
+the batch at once on the GPU instead of one sklearn process per cylinder; the scorer batch is assembled with one
+gather instead of a Python loop over proposals; eval-mode layers run as fused launches.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..applications import Data, Minkowski
+from ..modules import MLP, Seq, fused_head
+from ..torch_points_kernels import region_grow_csr
+from ..torch_scatter import scatter
+from ..utils import meanshift_cluster
+from .losses import discriminative_loss, instance_iou_loss, instance_ious, offset_loss
+from .structures import PanopticLabels, PanopticResults
+
+IGNORE_LABEL = -1  # torch_points3d/datasets/segmentation/__init__.py
+MAX_SCORER_BATCH = 60000  # proposals per ScorerUnet launch (batch index must fit the 16-bit key field)
+
+
+class PointGroup3heads(nn.Module):
+    __REQUIRED_DATA__ = ["pos"]
+    __REQUIRED_LABELS__ = list(PanopticLabels._fields)
+
+    def __init__(self, option, model_type, dataset, modules):
+        super().__init__()
+        self.opt = option
+        backbone_options = option.get("backbone", {"architecture": "unet"})
+        self.Backbone = Minkowski(backbone_options.get("architecture", "unet"), input_nc=dataset.feature_dimension,
+                                  num_layers=4, config=backbone_options.get("config", {}))
+        self._scorer_type = option.get("scorer_type", None)
+        self._voxelizer = None
+        nc = self.Backbone.output_nc
+        self.ScorerUnet = Minkowski("unet", input_nc=nc, num_layers=4, config=option.scorer_unet)
+        self.ScorerEncoder = Minkowski("encoder", input_nc=nc, num_layers=4, config=option.scorer_encoder)
+        self.ScorerMLP = MLP([nc, nc, self.ScorerUnet.output_nc])
+        self.ScorerHead = Seq().append(nn.Linear(self.ScorerUnet.output_nc, 1)).append(nn.Sigmoid())
+        self.mask_supervise = option.get("mask_supervise", False)
+        if self.mask_supervise:
+            self.MaskScore = (Seq().append(nn.Linear(self.ScorerUnet.output_nc, self.ScorerUnet.output_nc))
+                              .append(nn.ReLU()).append(nn.Linear(self.ScorerUnet.output_nc, 1)))
+        self.use_score_net = option.get("use_score_net", True)
+        self.cal_iou_based_on_mask = option.get("cal_iou_based_on_mask", False)
+        self.cal_iou_based_on_mask_start_epoch = option.get("cal_iou_based_on_mask_start_epoch", 200)
+
+        self.Offset = Seq().append(MLP([nc, nc], bias=False))
+        self.Offset.append(nn.Linear(nc, 3))
+        self.Embed = Seq().append(MLP([nc, nc], bias=False))
+        self.Embed.append(nn.Linear(nc, option.get("embed_dim", 5)))
+        self.Semantic = (Seq().append(MLP([nc, nc], bias=False)).append(nn.Linear(nc, dataset.num_classes))
+                         .append(nn.LogSoftmax(dim=-1)))
+        self.num_classes = dataset.num_classes
+        self.loss_names = ["loss", "offset_norm_loss", "offset_dir_loss", "ins_loss", "ins_var_loss", "ins_dist_loss",
+                           "ins_reg_loss", "semantic_loss", "score_loss", "mask_loss"]
+        stuff_classes = dataset.stuff_classes
+        if isinstance(stuff_classes, (list, tuple)):
+            stuff_classes = torch.Tensor(stuff_classes).long()
+        self._stuff_classes = torch.cat([torch.tensor([IGNORE_LABEL]), stuff_classes.long()])
+        self.output = None
+
+    # ------------------------------------------------------------------ BaseModel contract (models/base_model.py:136-297)
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def get_opt_mergeTh(self):
+        return self.opt.block_merge_th if self.opt.get("block_merge_th") else 0.01
+
+    def set_input(self, data, device):
+        self.input = data.to(device)  # everything device-resident (the reference leaves `input` on the host)
+        self.raw_pos = self.input.pos
+        if all(hasattr(self.input, l) for l in self.__REQUIRED_LABELS__):
+            self.labels = PanopticLabels(**{l: getattr(self.input, l) for l in self.__REQUIRED_LABELS__})
+        else:
+            self.labels = None
+
+    def get_output(self):
+        return self.output
+
+    def get_labels(self):
+        return self.labels
+
+    def get_current_losses(self):
+        out = OrderedDict()
+        for name in self.loss_names:
+            if hasattr(self, name):
+                try:
+                    out[name] = float(getattr(self, name))
+                except Exception:
+                    out[name] = None
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def backbone_and_heads(self):
+        """Sparse U-Net + the three heads.  Returns (features [N,16], semantic log-probs, offsets, embeddings,
+        predicted labels [N] int64)."""
+        feats = self.Backbone(self.input).x
+        if not self.training and not torch.is_grad_enabled():
+            sem, pred = fused_head(self.Semantic, feats, log_softmax=True, want_argmax=True)
+            off = fused_head(self.Offset, feats)
+            emb = fused_head(self.Embed, feats)
+        else:
+            sem = self.Semantic(feats)
+            off = self.Offset(feats)
+            emb = self.Embed(feats)
+            pred = torch.max(sem, 1)[1]
+        return feats, sem, off, emb, pred
+
+    def group_and_score(self, epoch, feats, sem, off, emb, pred=None):
+        """Instance grouping (+ scoring) on given head outputs; returns a PanopticResults."""
+        if pred is None:
+            pred = torch.max(sem, 1)[1]
+        cluster_scores = mask_scores = csr = cluster_type = None
+        ct = self.opt.cluster_type
+        fns = {1: self._cluster, 2: self._cluster2, 5: self._cluster5, 6: self._cluster6}
+        run = (epoch > self.opt.prepare_epoch) if self.use_score_net else True
+        if run:
+            if ct not in fns:
+                raise NotImplementedError("cluster_type %s (published settings use 1, 2, 5, 6)" % ct)
+            with torch.no_grad():
+                csr, cluster_type = fns[ct](pred, off.detach(), emb.detach())
+            if self.use_score_net and csr.n:
+                cluster_scores, mask_scores = self._compute_score(epoch, csr, feats, sem)
+        return PanopticResults(semantic_logits=sem, offset_logits=off, embed_logits=emb, clusters=None,
+                               cluster_scores=cluster_scores, mask_scores=mask_scores, cluster_type=cluster_type,
+                               clusters_csr=csr)
+
+    def forward(self, epoch=-1, **kwargs):
+        feats, sem, off, emb, pred = self.backbone_and_heads()
+        res = self.group_and_score(epoch, feats, sem, off, emb, pred)
+        if res.clusters_csr is not None:  # materialise the reference's List[LongTensor] view
+            res = res._replace(clusters=res.clusters_csr.to_list())
+        self.output = res
+        return res
+
+    # ------------------------------------------------------------------ proposal generators
+    def _grow(self, pos, pred, nsample):
+        kw = {} if nsample is None else {"nsample": nsample}  # reference leaves the default (16) for raw coordinates
+        csr, _ = region_grow_csr(pos, pred, self.input.batch, ignore_labels=self._stuff_classes,
+                                 radius=self.opt.cluster_radius_search, min_cluster_size=10,
+                                 num_classes=self.num_classes, **kw)
+        return csr
+
+    def _embed_clusters(self, pred, emb):
+        ignore = self._stuff_classes.to(pred.device)
+        label_mask = ~torch.isin(pred, ignore)
+        local_ind = torch.nonzero(label_mask).view(-1)
+        return meanshift_cluster.cluster_single_csr(emb[label_mask], self.input.batch[label_mask], local_ind,
+                                                    self.opt.bandwidth)
+
+    @staticmethod
+    def _types(parts, dev):
+        return torch.cat([torch.full((c.n,), t, dtype=torch.uint8, device=dev) for c, t in parts])
+
+    def _cluster(self, pred, off, emb):
+        votes = self._grow(self.raw_pos + off, pred, 200)
+        return votes, self._types([(votes, 0)], pred.device)
+
+    def _cluster2(self, pred, off, emb):
+        pos = self._grow(self.raw_pos, pred, None)
+        votes = self._grow(self.raw_pos + off, pred, 200)
+        return ops.ClusterCSR.concat([pos, votes]), self._types([(pos, 0), (votes, 1)], pred.device)
+
+    def _cluster5(self, pred, off, emb):
+        votes = self._grow(self.raw_pos + off, pred, 200)
+        embed = self._embed_clusters(pred, emb)
+        return ops.ClusterCSR.concat([votes, embed]), self._types([(votes, 0), (embed, 1)], pred.device)
+
+    def _cluster6(self, pred, off, emb):
+        pos = self._grow(self.raw_pos, pred, None)
+        votes = self._grow(self.raw_pos + off, pred, 200)
+        embed = self._embed_clusters(pred, emb)
+        return (ops.ClusterCSR.concat([pos, votes, embed]),
+                self._types([(pos, 0), (votes, 1), (embed, 2)], pred.device))
+
+    # ------------------------------------------------------------------ scorer
+    def _compute_score(self, epoch, csr, backbone_features, semantic_logits):
+        if not self._scorer_type:
+            with torch.no_grad():
+                sizes = csr.sizes()
+                b = torch.repeat_interleave(torch.arange(csr.n, device=sizes.device), sizes)
+                mean_sem = scatter(semantic_logits[csr.points], b, dim=0, reduce="mean", dim_size=csr.n)
+                return torch.max(torch.exp(mean_sem), 1)[0], None
+        if self._scorer_type not in ("unet",):
+            raise NotImplementedError("scorer_type %s (published settings use 'unet')" % self._scorer_type)
+        sizes = csr.sizes()
+        offsets = csr.offsets.long()
+        scores = []
+        for lo in range(0, csr.n, MAX_SCORER_BATCH):
+            hi = min(lo + MAX_SCORER_BATCH, csr.n)
+            p0, p1 = int(offsets[lo].item()), int(offsets[hi].item())
+            pts = csr.points[p0:p1]
+            b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi])
+            batch_cluster = Data(x=backbone_features[pts], coords=self.input.coords[pts], batch=b, pos=None)
+            out = self.ScorerUnet(batch_cluster)
+            cluster_feats = scatter(out.x, b, dim=0, reduce="max", dim_size=hi - lo)
+            scores.append(self.ScorerHead(cluster_feats).squeeze(-1))
+        return (scores[0] if len(scores) == 1 else torch.cat(scores)), None
+
+    # ------------------------------------------------------------------ losses / backward
+    def _compute_loss(self, epoch):
+        out, inp = self.output, self.input
+        self.semantic_loss = torch.nn.functional.nll_loss(out.semantic_logits, self.labels.y.to(torch.int64),
+                                                          ignore_index=IGNORE_LABEL)
+        self.loss = self.opt.loss_weights.semantic * self.semantic_loss
+        mask = inp.instance_mask
+        for name, loss in offset_loss(out.offset_logits[mask], inp.vote_label[mask], torch.sum(mask)).items():
+            setattr(self, name, loss)
+            self.loss = self.loss + self.opt.loss_weights[name] * loss
+        for name, loss in discriminative_loss(out.embed_logits[mask], inp.instance_labels[mask], inp.batch[mask],
+                                              self.opt.embed_dim).items():
+            setattr(self, name, loss)
+            if name == "ins_loss":
+                self.loss = self.loss + self.opt.loss_weights.embedding_loss * loss
+        if out.cluster_scores is not None and self._scorer_type and epoch > self.opt.prepare_epoch and self.use_score_net:
+            ious = instance_ious(out.clusters, out.cluster_scores, inp.instance_labels, inp.batch, None, False,
+                                 clusters_csr=out.clusters_csr)
+            self.score_loss = instance_iou_loss(ious, out.clusters, out.cluster_scores, inp.instance_labels, inp.batch,
+                                                min_iou_threshold=self.opt.min_iou_threshold,
+                                                max_iou_threshold=self.opt.max_iou_threshold)
+            self.loss = self.loss + self.score_loss * self.opt.loss_weights["score_loss"]
+
+    def backward(self, epoch):
+        self._compute_loss(epoch)
+        self.loss.backward()

