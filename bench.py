@@ -66,6 +66,10 @@ def build_model(device, voxel):
         if isinstance(m, torch.nn.BatchNorm1d):
             m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.05)
             m.running_var.copy_(1.0 + 0.1 * torch.rand(m.running_var.shape, generator=g))
+    # random-init ScorerHead gives sigmoid(~0) ~ 0.5: lift the bias so proposals clear the score > 0.5 filter and the
+    # NMS / painting / exchange stages see realistic work (documented in DESIGN.md "what is measured")
+    with torch.no_grad():
+        model.ScorerHead[0].bias.fill_(1.0)
     return model.to(device).eval(), cfg, DS
 
 

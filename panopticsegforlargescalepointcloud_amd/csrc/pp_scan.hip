@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_triad(float4* __restrict__ a, const flo
 extern "C" int pp_triad(float* a, const float* b, const float* c, float s, int64_t n, pp_stream_t stream) {
   PP_REQUIRE(n % 4 == 0, "pp_triad: n must be a multiple of 4");
   int64_t n4 = n / 4;
-  unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+  unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 64);
   if (blocks == 0) return PP_OK;
   hipLaunchKernelGGL(k_triad, dim3(blocks), dim3(256), 0, pp_s(stream), (float4*)a, (const float4*)b,
                      (const float4*)c, s, n4);

@@ -1,0 +1,32 @@
+"""Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) kernel trace into the `--stats`-style table committed under profiles/.
+usage: python profiles/rocpd_summary.py <results.db> [out.md]"""
+import sqlite3
+import sys
+
+
+def main(db, out=None):
+    con = sqlite3.connect(db)
+    rows = con.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
+        "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) from kernels group by name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    span = con.execute("select min(start), max(end) from kernels").fetchone()
+    lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % db.split("/")[-1], "",
+             "GPU kernel time %.1f ms over a %.1f ms span (%d dispatches)" % (total / 1e6, (span[1] - span[0]) / 1e6,
+                                                                              sum(r[1] for r in rows)), "",
+             "| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | sgpr | lds | scratch |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for r in rows[:40]:
+        name = r[0]
+        if len(name) > 90:
+            name = name[:87] + "..."
+        lines.append("| %s | %d | %.2f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s | %s |" % (
+            name, r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, r[6], r[7], r[8], r[9], r[10]))
+    txt = "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
