@@ -81,6 +81,20 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
                   int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr,
                   pp_stream_t stream);
 
+/* Derived maps (no hash probes).  pp_kernel_map_transpose: out_map[k][in_map[k][o]] = o, i.e. the map of the
+ * transposed strided convolution (coarse -> fine, ME's "swapped" kernel map, api_modules.py:288-311) from the
+ * strided convolution's map; out_map is int32 [K][n_in], filled with -1 first. */
+int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
+                            pp_stream_t stream);
+
+/* Morton (Z-order) permutation of COO rows, batch-major: perm[p] = input row holding the p-th smallest key.
+ * The coordinate manager keeps rows in this order internally (compact 16-row tiles -> per-tile offset skipping
+ * in pp_spconv_fwd, L2-resident gathers); the caller-visible row order of stride-1 tensors is unchanged
+ * (applications/minkowski.py:193).  info[1] = rows outside the key range. */
+size_t pp_morton_order_workspace(int64_t n);
+int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
+                    int32_t* info /*int32[2]*/, pp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4  sparse convolution forward  replaces: ME ConvolutionForward (gather-GEMM-scatter per offset),
  *                                 api_modules.py:30-51 ; K6 folded BN + ReLU epilogue api_modules.py:40-41 ;

@@ -37,14 +37,26 @@ class _Level:
 class CoordinateManager:
     """Coordinate levels (tensor stride -> COO rows + hash) and kernel maps, cached for one input.
 
+    Rows are kept in batch-major Morton (Z-) order internally (`perm`: internal row p = caller row perm[p]), so 16
+    consecutive rows form a compact surface patch -- the convolution skips kernel offsets that are empty for a whole
+    tile and gathered neighbours stay L2-resident.  Caller-visible order at tensor stride 1 is unchanged.
+
     map(ts_from, ts_to, ksize, sign)[k, o] = row at level ts_from of  coords[ts_to][o] + sign*offset_k*step,
     step = min(ts_from, ts_to).  sign=+1 is a convolution, sign=-1 a transposed convolution; the map needed
-    for the input gradient of map(A->B, sign) is map(B->A, -sign)."""
+    for the input gradient of map(A->B, sign) is map(B->A, -sign).  Only map(ts,ts,+1) and map(ts,2ts,+1) are built
+    with hash probes; mirrored and transposed maps are derived (flip along k / pp_kernel_map_transpose)."""
 
-    def __init__(self, coords):
+    def __init__(self, coords, reorder=True):
         if coords.dtype != torch.int32:
             coords = coords.to(torch.int32)
         coords = coords.contiguous()
+        self.orig_coords = coords
+        self.perm = self.inv_perm = None
+        if reorder and coords.shape[0] > 1:
+            self.perm = ops.morton_order(coords)
+            self.inv_perm = torch.empty_like(self.perm)
+            self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
+            coords = coords[self.perm].contiguous()
         table, ndup = ops.hash_build(coords)
         if ndup:
             raise ValueError("%d duplicate coordinates: the input must hold one row per (batch, x, y, z) "
@@ -54,6 +66,12 @@ class CoordinateManager:
 
     def level(self, ts):
         return self.levels[ts]
+
+    def to_internal(self, feats):
+        return feats if self.perm is None else feats[self.perm]
+
+    def to_caller(self, feats):
+        return feats if self.inv_perm is None else feats[self.inv_perm]
 
     def ensure_stride(self, ts_in, stride):
         ts_out = ts_in * stride
@@ -73,7 +91,13 @@ class CoordinateManager:
         if m is None:
             if ts_to not in self.levels:
                 raise ValueError("transposed convolution onto tensor stride %d: that coordinate map was never created" % ts_to)
-            m = ops.kernel_map(self.levels[ts_to].coords, self.levels[ts_from].table, ksize, min(ts_from, ts_to), sign)
+            rev = self.maps.get((ts_to, ts_from, ksize, -sign))
+            if rev is not None and ts_from == ts_to:
+                m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
+            elif rev is not None:
+                m = ops.kernel_map_transpose(rev, self.levels[ts_to].n)
+            else:
+                m = ops.kernel_map(self.levels[ts_to].coords, self.levels[ts_from].table, ksize, min(ts_from, ts_to), sign)
             self.maps[key] = m
         return m
 
@@ -82,6 +106,10 @@ class CoordinateManager:
 # sparse tensor
 # ------------------------------------------------------------------------------------------------
 class SparseTensor:
+    """features + coordinate manager + tensor stride.  `feats` is the internal (Morton-ordered) feature matrix every
+    kernel works on; `.F` / `.C` give the caller-visible view (row i of F belongs to row i of the coordinates passed
+    in, applications/minkowski.py:193)."""
+
     def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1, **kwargs):
         if coordinate_manager is None:
             if coordinates is None:
@@ -89,28 +117,31 @@ class SparseTensor:
             dev = torch.device(device) if device is not None else features.device
             if dev.type != "cuda":
                 raise ops._lib.PanopticHipError("SparseTensor must live on a HIP device (no CPU fallback)")
-            coordinates = coordinates.to(dev)
-            features = features.to(dev)
-            coordinate_manager = CoordinateManager(coordinates)
-        self._F = features
+            coordinate_manager = CoordinateManager(coordinates.to(dev))
+            features = coordinate_manager.to_internal(features.to(dev))
+        self.feats = features
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = int(tensor_stride)
 
     @property
     def F(self):
-        return self._F
+        if self.tensor_stride == 1:
+            return self.coordinate_manager.to_caller(self.feats)
+        return self.feats
 
     @property
     def C(self):
+        if self.tensor_stride == 1:
+            return self.coordinate_manager.orig_coords
         return self.coordinate_manager.level(self.tensor_stride).coords
 
     @property
     def device(self):
-        return self._F.device
+        return self.feats.device
 
     @property
     def shape(self):
-        return self._F.shape
+        return self.feats.shape
 
     def _like(self, feats):
         return SparseTensor(feats, coordinate_manager=self.coordinate_manager, tensor_stride=self.tensor_stride)
@@ -119,11 +150,11 @@ class SparseTensor:
         if isinstance(other, SparseTensor):
             if other.coordinate_manager is not self.coordinate_manager or other.tensor_stride != self.tensor_stride:
                 raise ValueError("SparseTensor + SparseTensor needs the same coordinate map")
-            return self._like(self._F + other._F)
-        return self._like(self._F + other)
+            return self._like(self.feats + other.feats)
+        return self._like(self.feats + other)
 
     def __repr__(self):
-        return "SparseTensor(F=%s, tensor_stride=%d)" % (tuple(self._F.shape), self.tensor_stride)
+        return "SparseTensor(F=%s, tensor_stride=%d)" % (tuple(self.feats.shape), self.tensor_stride)
 
 
 def cat(*tensors):
@@ -132,7 +163,7 @@ def cat(*tensors):
     for t in tensors[1:]:
         if t.coordinate_manager is not a.coordinate_manager or t.tensor_stride != a.tensor_stride:
             raise ValueError("ME.cat: tensors must share the coordinate map")
-    return a._like(torch.cat([t.F for t in tensors], dim=1))
+    return a._like(torch.cat([t.feats for t in tensors], dim=1))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -295,7 +326,7 @@ class _ConvBase(nn.Module):
     def forward(self, x):
         ts_out, nbr, inv_fn = self.out_stride_and_map(x)
         n_out = x.coordinate_manager.level(ts_out).n
-        feats = _SparseConvFn.apply(x.F, self.kernel, nbr, inv_fn, n_out, self.kernel_volume)
+        feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume)
         if self.bias is not None:
             feats = feats + self.bias
         return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=ts_out)
@@ -357,7 +388,7 @@ class MinkowskiBatchNorm(nn.Module):
         return _AffineFn.apply(feats, scale, shift, 1 if relu else 0)
 
     def forward(self, x):
-        return x._like(self.features_forward(x.F))
+        return x._like(self.features_forward(x.feats))
 
     def __repr__(self):
         return "MinkowskiBatchNorm(%s)" % self.bn.extra_repr()
@@ -368,12 +399,12 @@ class MinkowskiReLU(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        return x._like(_AffineFn.apply(x.F, None, None, 1))
+        return x._like(_AffineFn.apply(x.feats, None, None, 1))
 
 
 class MinkowskiSigmoid(nn.Module):
     def forward(self, x):
-        return x._like(torch.sigmoid(x.F))
+        return x._like(torch.sigmoid(x.feats))
 
 
 class MinkowskiLinear(nn.Module):
@@ -382,26 +413,25 @@ class MinkowskiLinear(nn.Module):
         self.linear = nn.Linear(in_features, out_features, bias=bias)
 
     def forward(self, x):
-        return x._like(self.linear(x.F))
+        return x._like(self.linear(x.feats))
 
 
 class MinkowskiGlobalPooling(nn.Module):
     """Average of the features of each batch element (one row per batch element, tensor stride kept)."""
 
     def forward(self, x):
-        b = x.C[:, 0].long()
+        b = x.coordinate_manager.level(x.tensor_stride).coords[:, 0].long()
         nb = int(b.max().item()) + 1 if b.numel() else 0
-        pooled = ops.segment_reduce(x.F.contiguous(), b, nb, "mean")
+        pooled = ops.segment_reduce(x.feats.contiguous(), b, nb, "mean")
         out = SparseTensor.__new__(SparseTensor)
-        out._F, out.coordinate_manager, out.tensor_stride = pooled, x.coordinate_manager, x.tensor_stride
-        out._batch_rows = True
+        out.feats, out.coordinate_manager, out.tensor_stride = pooled, x.coordinate_manager, -1
         return out
 
 
 class MinkowskiBroadcastMultiplication(nn.Module):
     def forward(self, x, pooled):
-        b = x.C[:, 0].long()
-        return x._like(x.F * pooled.F[b])
+        b = x.coordinate_manager.level(x.tensor_stride).coords[:, 0].long()
+        return x._like(x.feats * pooled.feats[b])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -420,13 +450,13 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
     if skip is not None:
         if skip.coordinate_manager is not cm or skip.tensor_stride != x.tensor_stride:
             raise ValueError("fused cat: tensors must share the coordinate map")
-        in1 = skip.F
+        in1 = skip.feats
     res = None
     if residual is not None:
         if residual.tensor_stride != ts_out:
             raise ValueError("residual on a different tensor stride")
-        res = residual.F
-    feats = ops.spconv_fwd(x.F, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1, scale=scale,
+        res = residual.feats
+    feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1, scale=scale,
                            shift=shift, relu=relu, residual=res)
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")

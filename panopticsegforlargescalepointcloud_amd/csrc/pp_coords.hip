@@ -195,3 +195,78 @@ extern "C" int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uin
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// kernel-map transpose: out[k][in_map[k][o]] = o.  Turns the strided (fine -> coarse) map into the transposed
+// convolution's (coarse -> fine) map with P scattered writes instead of 27 hash probes per fine row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kernel_map_transpose(const int32_t* __restrict__ in_map, int64_t n_out, int K,
+                                                              int64_t n_in, int32_t* __restrict__ out_map) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)K * n_out) return;
+  int32_t i = in_map[e];
+  if (i >= 0) {
+    int64_t k = e / n_out, o = e - k * n_out;
+    out_map[k * n_in + i] = (int32_t)o;
+  }
+}
+extern "C" int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
+                                       pp_stream_t stream) {
+  PP_REQUIRE(in_map && out_map && K >= 1, "pp_kernel_map_transpose: bad arguments");
+  hipStream_t s = pp_s(stream);
+  if (n_in > 0) PP_HIP(hipMemsetAsync(out_map, 0xFF, sizeof(int32_t) * (size_t)K * (size_t)n_in, s));
+  if (n_out == 0 || n_in == 0) return PP_OK;
+  hipLaunchKernelGGL(k_kernel_map_transpose, dim3(pp_blocks((int64_t)K * n_out, 256)), dim3(256), 0, s, in_map, n_out, K,
+                     n_in, out_map);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Morton (Z-order) row permutation: perm[p] = row with the p-th smallest (batch, interleave(x,y,z)) key.
+// Internal row order of the coordinate manager: 16 consecutive rows form a compact surface patch (tile-level
+// offset skipping in the convolution) and gathered neighbours stay L2-resident.
+// ---------------------------------------------------------------------------------------------
+__device__ inline uint64_t pp_spread3(uint64_t x) {
+  x &= 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__global__ __launch_bounds__(256) void k_morton_keys(const int4* __restrict__ coords, int64_t n, uint64_t* key,
+                                                     int32_t* idx, int32_t* info) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  if (!pp_key_ok(c.x, c.y, c.z, c.w)) {
+    atomicAdd(&info[1], 1);
+    key[i] = ~0ull;
+  } else {
+    key[i] = ((uint64_t)(uint16_t)c.x << 48) | pp_spread3((uint64_t)(c.y + 32768)) |
+             (pp_spread3((uint64_t)(c.z + 32768)) << 1) | (pp_spread3((uint64_t)(c.w + 32768)) << 2);
+  }
+  idx[i] = (int32_t)i;
+}
+extern "C" size_t pp_morton_order_workspace(int64_t n) {
+  size_t m = (size_t)std::max<int64_t>(n, 1);
+  return 2 * pp_align(m * 8) + pp_align(m * 4) + pp_sort_pairs_workspace(n) + 1024;
+}
+extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
+                               int32_t* info, pp_stream_t stream) {
+  PP_REQUIRE(perm && info, "pp_morton_order: null output");
+  if (workspace_bytes < pp_morton_order_workspace(n)) return PP_ERR_WORKSPACE;
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int32_t), s));
+  if (n == 0) return PP_OK;
+  PPArena ar(workspace, workspace_bytes);
+  size_t m = (size_t)n;
+  uint64_t* key = ar.take<uint64_t>(m);
+  uint64_t* key2 = ar.take<uint64_t>(m);
+  int32_t* idx = ar.take<int32_t>(m);
+  hipLaunchKernelGGL(k_morton_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, key, idx, info);
+  PP_LAUNCH_CHECK();
+  return pp_sort_pairs_u64(key, key2, idx, perm, n, 64, ar.cur(), ar.left(), s);
+}

@@ -93,12 +93,20 @@ struct SpconvArgs {
   int c0, c1, K, cout, NT, relu;
 };
 
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
+// blocks so the neighbour rows gathered by adjacent blocks hit that XCD's private L2 (guide T1; speed only).
+__device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 template <int NTW, bool MODE16>
 __global__ __launch_bounds__(256) void k_spconv_fwd(SpconvArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const unsigned bid = pp_xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row_base = ((int64_t)bid * 4 + wave) * 32;
   if (row_base >= a.n_out) return;  // wave-uniform
   const int jt0 = blockIdx.y * NTW;
   const int64_t r0 = row_base + i, r1 = row_base + 16 + i;
@@ -112,67 +120,101 @@ __global__ __launch_bounds__(256) void k_spconv_fwd(SpconvArgs a) {
   }
 
   const int cin = a.c0 + a.c1;
+  // neighbour indices are prefetched one offset ahead (breaks the index -> gather -> MFMA dependency chain)
+  int a0 = -1, a1 = -1;
+  if (a.nbr) {
+    if (v0) a0 = a.nbr[r0];
+    if (v1) a1 = a.nbr[r1];
+  } else {
+    if (v0) a0 = (int)r0;
+    if (v1) a1 = (int)r1;
+  }
   for (int k = 0; k < a.K; ++k) {
-    int a0 = -1, a1 = -1;
-    if (a.nbr) {
-      if (v0) a0 = a.nbr[(int64_t)k * a.n_out + r0];
-      if (v1) a1 = a.nbr[(int64_t)k * a.n_out + r1];
-    } else {
-      if (v0) a0 = (int)r0;
-      if (v1) a1 = (int)r1;
+    int a0n = -1, a1n = -1;
+    if (k + 1 < a.K) {
+      if (v0) a0n = a.nbr[(int64_t)(k + 1) * a.n_out + r0];
+      if (v1) a1n = a.nbr[(int64_t)(k + 1) * a.n_out + r1];
     }
-    if (__ballot((a0 >= 0) || (a1 >= 0)) == 0ull) continue;  // no row of this wave has that neighbour
-    if (MODE16) {
-      const int S0 = a.c0 >> 4, S = cin >> 4;
-      const float* wk = a.wp + (int64_t)k * S * a.NT * 256;
-      for (int s = 0; s < S; ++s) {
-        const float* src;
-        int cs, ss;
-        if (s < S0) {
-          src = a.in0; cs = a.c0; ss = s;
-        } else {
-          src = a.in1; cs = a.c1; ss = s - S0;
+    // per-16-row-tile skip: with Morton-ordered rows a tile is a compact surface patch, so whole offsets are empty
+    const bool act0 = __ballot(a0 >= 0) != 0ull;
+    const bool act1 = __ballot(a1 >= 0) != 0ull;
+    if (act0 || act1) {
+      if (MODE16) {
+        const int S0 = a.c0 >> 4, S = cin >> 4;
+        const float* wk = a.wp + (int64_t)k * S * a.NT * 256;
+        for (int s = 0; s < S; ++s) {
+          const float* src;
+          int cs, ss;
+          if (s < S0) {
+            src = a.in0; cs = a.c0; ss = s;
+          } else {
+            src = a.in1; cs = a.c1; ss = s - S0;
+          }
+          f32x4 A0 = (f32x4){0.f, 0.f, 0.f, 0.f}, A1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (a0 >= 0) A0 = *(const f32x4*)(src + (int64_t)a0 * cs + ss * 16 + q * 4);
+          if (a1 >= 0) A1 = *(const f32x4*)(src + (int64_t)a1 * cs + ss * 16 + q * 4);
+          const float* ws = wk + ((int64_t)s * a.NT + jt0) * 256 + lane * 4;
+          if (act0 && act1) {
+#pragma unroll
+            for (int jt = 0; jt < NTW; ++jt) {
+              if (jt0 + jt < a.NT) {
+                f32x4 B = *(const f32x4*)(ws + jt * 256);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[t], B[t], acc[0][jt], 0, 0, 0);
+                  acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], B[t], acc[1][jt], 0, 0, 0);
+                }
+              }
+            }
+          } else if (act0) {
+#pragma unroll
+            for (int jt = 0; jt < NTW; ++jt) {
+              if (jt0 + jt < a.NT) {
+                f32x4 B = *(const f32x4*)(ws + jt * 256);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[t], B[t], acc[0][jt], 0, 0, 0);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int jt = 0; jt < NTW; ++jt) {
+              if (jt0 + jt < a.NT) {
+                f32x4 B = *(const f32x4*)(ws + jt * 256);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], B[t], acc[1][jt], 0, 0, 0);
+              }
+            }
+          }
         }
-        f32x4 A0 = (f32x4){0.f, 0.f, 0.f, 0.f}, A1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a0 >= 0) A0 = *(const f32x4*)(src + (int64_t)a0 * cs + ss * 16 + q * 4);
-        if (a1 >= 0) A1 = *(const f32x4*)(src + (int64_t)a1 * cs + ss * 16 + q * 4);
-        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 256 + lane * 4;
+      } else {
+        const int S4 = (cin + 3) >> 2;
+        const float* wk = a.wp + (int64_t)k * S4 * a.NT * 64;
+        for (int s = 0; s < S4; ++s) {
+          const int ch = 4 * s + q;
+          float A0 = 0.f, A1 = 0.f;
+          if (ch < cin) {
+            const float* src = ch < a.c0 ? a.in0 : a.in1;
+            const int cs = ch < a.c0 ? a.c0 : a.c1;
+            const int cc = ch < a.c0 ? ch : ch - a.c0;
+            if (a0 >= 0) A0 = src[(int64_t)a0 * cs + cc];
+            if (a1 >= 0) A1 = src[(int64_t)a1 * cs + cc];
+          }
+          const float* ws = wk + ((int64_t)s * a.NT + jt0) * 64 + lane;
 #pragma unroll
-        for (int jt = 0; jt < NTW; ++jt) {
-          if (jt0 + jt < a.NT) {
-            f32x4 B = *(const f32x4*)(ws + jt * 256);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[t], B[t], acc[0][jt], 0, 0, 0);
-              acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], B[t], acc[1][jt], 0, 0, 0);
+          for (int jt = 0; jt < NTW; ++jt) {
+            if (jt0 + jt < a.NT) {
+              float B = ws[jt * 64];
+              acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B, acc[0][jt], 0, 0, 0);
+              acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B, acc[1][jt], 0, 0, 0);
             }
           }
         }
       }
-    } else {
-      const int S4 = (cin + 3) >> 2;
-      const float* wk = a.wp + (int64_t)k * S4 * a.NT * 64;
-      for (int s = 0; s < S4; ++s) {
-        const int ch = 4 * s + q;
-        float A0 = 0.f, A1 = 0.f;
-        if (ch < cin) {
-          const float* src = ch < a.c0 ? a.in0 : a.in1;
-          const int cs = ch < a.c0 ? a.c0 : a.c1;
-          const int cc = ch < a.c0 ? ch : ch - a.c0;
-          if (a0 >= 0) A0 = src[(int64_t)a0 * cs + cc];
-          if (a1 >= 0) A1 = src[(int64_t)a1 * cs + cc];
-        }
-        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 64 + lane;
-#pragma unroll
-        for (int jt = 0; jt < NTW; ++jt) {
-          if (jt0 + jt < a.NT) {
-            float B = ws[jt * 64];
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B, acc[1][jt], 0, 0, 0);
-          }
-        }
-      }
     }
+    a0 = a0n;
+    a1 = a1n;
   }
 
   // epilogue: lane (col = i, row group = q) holds rows 4q+r of each 16-row tile

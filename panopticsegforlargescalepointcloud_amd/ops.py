@@ -132,6 +132,29 @@ def kernel_map(out_coords, table, ksize, step, sign):
     return nbr
 
 
+def kernel_map_transpose(nbr, n_in):
+    """map of the transposed strided conv from the strided conv's map: out[k][nbr[k][o]] = o."""
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    out = torch.empty((K, n_in), dtype=torch.int32, device=nbr.device)
+    _lib.check(lib.pp_kernel_map_transpose(_ptr(nbr), n_out, K, int(n_in), _ptr(out), _stream()), "pp_kernel_map_transpose")
+    return out
+
+
+def morton_order(coords):
+    """perm (int64 [n]): rows of `coords` in batch-major Z-order."""
+    lib = _lib.load()
+    coords = _need(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    dev = coords.device
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    wsb = lib.pp_morton_order_workspace(n)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_morton_order(_ptr(coords), n, _ptr(perm), _ptr(ws), wsb, _ptr(info), _stream()), "pp_morton_order")
+    return perm[:n].long()
+
+
 # ------------------------------------------------------------------------------------------ convolution
 def pack_weight(weight, transpose=False):
     """ME-layout kernel [K,Cin,Cout] (or [Cin,Cout]) -> MFMA fragment order.  transpose=True packs W_k^T."""

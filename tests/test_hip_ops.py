@@ -301,3 +301,29 @@ def test_instance_iou_and_intersections_match_goldens(ops, oracle):
     inter = ops.proposal_intersections(csr, int(z["n"]))
     want = oracle.proposal_intersections([c.numpy() for c in clusters], int(z["n"]))
     assert np.array_equal(inter.cpu().numpy(), want)
+
+
+def test_morton_order_and_derived_maps(ops, oracle):
+    rng = np.random.default_rng(12)
+    fine = surface(rng, n=3000, n_batch=3, extent=60)
+    d = dev(fine)
+    perm = ops.morton_order(d).cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(len(fine)))
+    # batch-major, Z-order inside a batch
+    def key(c):
+        k = 0
+        for b in range(16):
+            for a, v in enumerate((c[1] + 32768, c[2] + 32768, c[3] + 32768)):
+                k |= ((int(v) >> b) & 1) << (3 * b + a)
+        return (int(c[0]) << 48) | k
+    keys = [key(c) for c in fine[perm]]
+    assert keys == sorted(keys)
+    # derived maps == probed maps
+    table, _ = ops.hash_build(d)
+    coarse, ctable, _ = ops.stride_coords(d, 2)
+    down = ops.kernel_map(coarse, table, 3, 1, 1)
+    up_probe = ops.kernel_map(d, ctable, 3, 1, -1)
+    up_derived = ops.kernel_map_transpose(down, len(fine))
+    assert torch.equal(up_probe, up_derived)
+    same = ops.kernel_map(d, table, 3, 1, 1)
+    assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))

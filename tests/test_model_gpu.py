@@ -124,7 +124,8 @@ def test_training_step_runs_and_matches_torch_autograd(setup):
             out = out.index_add(0, torch.nonzero(ok).view(-1), inp[r[ok]] @ w[k])
         return out
 
-    h = gconv(x2, w1, down, n2)
+    xin = x2 if cm.perm is None else x2[cm.perm]  # kernel maps index the manager's internal (Morton) row order
+    h = gconv(xin, w1, down, n2)
     h = torch.nn.functional.batch_norm(h, None, None, bn.bn.weight.detach(), bn.bn.bias.detach(), True, 0.1, 1e-5)
     h = torch.relu(h)
     y2 = gconv(h, w2, upm, len(coords))
