@@ -112,6 +112,23 @@ int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, co
                   const float* shift, int32_t relu, const float* residual, float* out,
                   pp_stream_t stream);
 
+/* K3b/K4b  block-compacted rulebook and the convolution on it (the fast path for 3x3x3 kernels with Cin % 16 == 0).
+ * The kernel map is regrouped per block of 128 consecutive output rows and per offset into compact lists of
+ * (input row, local output row) pairs padded to 16, so MFMA tiles hold only ACTIVE pairs (ME's "kernel map" in
+ * in/out-pair form, regrouped for an output-stationary kernel; same reference call sites as K3/K4).
+ *   rb_off int32 [blocks*28 + 1] (entry offsets per block and offset; total[0] = #entries), rb_in / rb_out int32 [total].
+ * pp_spconv_fwd_rb has pp_spconv_fwd's contract (same packed weights, epilogue, fused second source). */
+int64_t pp_rulebook_blocks(int64_t n_out);
+size_t pp_rulebook_workspace(int64_t n_out);
+int pp_rulebook_offsets(const int32_t* nbr /*[27,n_out]*/, int64_t n_out, int32_t* rb_off, int32_t* total,
+                        void* workspace, size_t workspace_bytes, pp_stream_t stream);
+int pp_rulebook_fill(const int32_t* nbr, int64_t n_out, const int32_t* rb_off, int32_t* rb_in, int32_t* rb_out,
+                     pp_stream_t stream);
+int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
+                     const int32_t* rb_off, const int32_t* rb_in, const int32_t* rb_out, int64_t n_out, int32_t cout,
+                     const float* scale, const float* shift, int32_t relu, const float* residual, float* out,
+                     pp_stream_t stream);
+
 /* K5  weight gradient             replaces: ME ConvolutionBackward (dW part), reached from
  *                                 loss.backward(), torch_points3d/models/panoptic/PointGroup3heads.py:636-639
  * dw[k] (+)= sum_o in[nbr[k][o]]^T . dout[o]          dw is float32 [K,cin,cout], zeroed by the callee. */

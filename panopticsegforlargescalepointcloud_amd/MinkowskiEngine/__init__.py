@@ -14,12 +14,18 @@ Use as a drop-in:   import panopticsegforlargescalepointcloud_amd.MinkowskiEngin
 or                  sys.modules["MinkowskiEngine"] = panopticsegforlargescalepointcloud_amd.MinkowskiEngine
 """
 import math
+import os
 
 import torch
 from torch import nn
 
 from .. import ops
 from . import utils  # noqa: F401
+
+
+# 3x3x3 convolutions with Cin % 16 == 0 run on the block-compacted rulebook kernel (csrc/pp_spconv_rb.hip);
+# PP_CONV=dense forces the dense-offset kernel (csrc/pp_spconv.hip) for A/B measurements.
+USE_RULEBOOK = os.environ.get("PP_CONV", "rb") != "dense"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -63,6 +69,15 @@ class CoordinateManager:
                              "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
         self.levels = {1: _Level(coords, table)}
         self.maps = {}
+        self.rulebooks = {}
+
+    def rulebook(self, ts_from, ts_to, ksize, sign):
+        key = (ts_from, ts_to, ksize, sign)
+        rb = self.rulebooks.get(key)
+        if rb is None:
+            rb = ops.rulebook_build(self.kernel_map(ts_from, ts_to, ksize, sign))
+            self.rulebooks[key] = rb
+        return rb
 
     def level(self, ts):
         return self.levels[ts]
@@ -456,8 +471,16 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
         if residual.tensor_stride != ts_out:
             raise ValueError("residual on a different tensor stride")
         res = residual.feats
-    feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1, scale=scale,
-                           shift=shift, relu=relu, residual=res)
+    c0 = x.feats.shape[1]
+    c1 = 0 if in1 is None else in1.shape[1]
+    if USE_RULEBOOK and nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0:
+        sign = -1 if conv.TRANSPOSED else 1
+        rb = cm.rulebook(x.tensor_stride, ts_out, conv.kernel_size, sign)
+        feats = ops.spconv_fwd_rb(x.feats, conv.packed(), rb, conv.out_channels, in1=in1, scale=scale, shift=shift,
+                                  relu=relu, residual=res)
+    else:
+        feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
+                               scale=scale, shift=shift, relu=relu, residual=res)
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

@@ -1,0 +1,278 @@
+// K3b/K4b: block-compacted rulebook + sparse convolution on it.
+//
+// Why: on surface-like voxel data only 6-13 of the 27 offsets of a 3x3x3 kernel are occupied per output voxel
+// (SURVEY.md App. F), so a dense offset loop spends 50-77 % of its MFMA issue slots on zero rows.  The rulebook
+// regroups the kernel map per block of RB_ROWS consecutive (Morton-ordered) output rows and per offset k into
+// COMPACT lists of (input row, local output row) pairs, padded to 16: the convolution then runs one 16-row MFMA
+// tile per 16 ACTIVE pairs (~85 % useful work) instead of one per 16 output rows.
+//
+// Convolution kernel (one wave = one 128-row block x NTW*16 output channels, waves fully independent: no barriers,
+// no atomics, fixed summation order => deterministic):
+//   accumulators   LDS [128][NTW*16 (+4 pad)] fp32, private to the wave
+//   A (gathered)   global_load_lds_dwordx4: lane L fetches quarter L&3 of input row L>>2, so every 4-lane quad reads
+//                  one full 64 B row segment (coalesced; 16 line requests per instruction instead of 64) straight into
+//                  a 2 x 1 KiB wave-private staging ring; the DMA of step s+1 overlaps the MFMAs of step s
+//   A fragments    ds_read_b128 from the staging tile in MFMA layout (lane (i,q) -> row i, floats 4q..4q+3)
+//   B fragments    packed weights (pp_pack_weight mode16), one coalesced 1 KiB load per (k, s, jt), L1/L2 resident
+//   MFMA           v_mfma_f32_16x16x4_f32, NTW independent accumulator chains
+//   scatter        D rows go to the LDS accumulator rows named by the rulebook (plain read-add-write: within a tile
+//                  every output row appears once, and the LDS block belongs to this wave alone)
+//   epilogue       folded BN / ReLU / residual, float4 coalesced stores (same contract as pp_spconv_fwd)
+#include "pp_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RB_ROWS 128
+#define RB_K 27
+
+// ---------------------------------------------------------------------------------------------
+// rulebook build: one workgroup (4 waves) per block; wave w handles offsets k = w, w+4, ...
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rb_count(const int32_t* __restrict__ nbr, int64_t n_out, int64_t nblk,
+                                                  int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t row0 = b * RB_ROWS;
+  for (int k = wave; k < RB_K; k += 4) {
+    int c = 0;
+#pragma unroll
+    for (int h = 0; h < RB_ROWS / 64; ++h) {
+      int64_t r = row0 + h * 64 + lane;
+      bool act = r < n_out && nbr[(int64_t)k * n_out + r] >= 0;
+      c += __popcll(__ballot(act));
+    }
+    if (lane == 0) cnt[b * (RB_K + 1) + k] = (c + 15) & ~15;
+  }
+  if (threadIdx.x == 0) cnt[b * (RB_K + 1) + RB_K] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_rb_fill(const int32_t* __restrict__ nbr, int64_t n_out, int64_t nblk,
+                                                 const int32_t* __restrict__ off, int32_t* __restrict__ rb_in,
+                                                 int32_t* __restrict__ rb_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t row0 = b * RB_ROWS;
+  for (int k = wave; k < RB_K; k += 4) {
+    const int beg = off[b * (RB_K + 1) + k], end = off[b * (RB_K + 1) + k + 1];
+    int w = beg;
+#pragma unroll
+    for (int h = 0; h < RB_ROWS / 64; ++h) {
+      int64_t r = row0 + h * 64 + lane;
+      int v = r < n_out ? nbr[(int64_t)k * n_out + r] : -1;
+      bool act = v >= 0;
+      unsigned long long m = __ballot(act);
+      if (act) {
+        int p = w + __popcll(m & ((1ull << lane) - 1ull));
+        rb_in[p] = v;
+        rb_out[p] = h * 64 + lane;
+      }
+      w += __popcll(m);
+    }
+    for (int p = w + lane; p < end; p += 64) {  // padding: a valid input row, output row -1 (result discarded)
+      rb_in[p] = 0;
+      rb_out[p] = -1;
+    }
+  }
+}
+
+extern "C" int64_t pp_rulebook_blocks(int64_t n_out) { return (n_out + RB_ROWS - 1) / RB_ROWS; }
+extern "C" size_t pp_rulebook_workspace(int64_t n_out) {
+  return pp_align((size_t)(pp_rulebook_blocks(n_out) * (RB_K + 1) + 1) * 4) + pp_scan_workspace(pp_rulebook_blocks(n_out) * (RB_K + 1) + 1) + 1024;
+}
+
+// step 1: offsets.  rb_off int32 [nblk*28 + 1]; total[0] = number of entries (device)
+extern "C" int pp_rulebook_offsets(const int32_t* nbr, int64_t n_out, int32_t* rb_off, int32_t* total, void* workspace,
+                                   size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(nbr && rb_off && total, "pp_rulebook_offsets: null pointer");
+  if (workspace_bytes < pp_rulebook_workspace(n_out)) return PP_ERR_WORKSPACE;
+  hipStream_t s = pp_s(stream);
+  const int64_t nblk = pp_rulebook_blocks(n_out);
+  if (nblk == 0) {
+    PP_HIP(hipMemsetAsync(total, 0, sizeof(int32_t), s));
+    PP_HIP(hipMemsetAsync(rb_off, 0, sizeof(int32_t), s));
+    return PP_OK;
+  }
+  PPArena ar(workspace, workspace_bytes);
+  const int64_t m = nblk * (RB_K + 1);
+  int32_t* cnt = ar.take<int32_t>((size_t)m + 1);
+  PP_HIP(hipMemsetAsync(cnt + m, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_rb_count, dim3((unsigned)nblk), dim3(256), 0, s, nbr, n_out, nblk, cnt);
+  PP_LAUNCH_CHECK();
+  int rc = pp_exclusive_scan_i32(cnt, rb_off, m + 1, nullptr, ar.cur(), ar.left(), s);
+  if (rc) return rc;
+  PP_HIP(hipMemcpyAsync(total, rb_off + m, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  return PP_OK;
+}
+// step 2: entries.  rb_in / rb_out int32 [total]
+extern "C" int pp_rulebook_fill(const int32_t* nbr, int64_t n_out, const int32_t* rb_off, int32_t* rb_in,
+                                int32_t* rb_out, pp_stream_t stream) {
+  PP_REQUIRE(nbr && rb_off && rb_in && rb_out, "pp_rulebook_fill: null pointer");
+  const int64_t nblk = pp_rulebook_blocks(n_out);
+  if (nblk == 0) return PP_OK;
+  hipLaunchKernelGGL(k_rb_fill, dim3((unsigned)nblk), dim3(256), 0, pp_s(stream), nbr, n_out, nblk, rb_off, rb_in,
+                     rb_out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// convolution on the rulebook
+// ---------------------------------------------------------------------------------------------
+struct RbArgs {
+  const float* in0;
+  const float* in1;
+  const float* wp;
+  const int32_t* rb_off;
+  const int32_t* rb_in;
+  const int32_t* rb_out;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  float* out;
+  int64_t n_out, nblk;
+  int c0, c1, cout, NT, relu;
+};
+
+__device__ inline unsigned rb_xcd_remap(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_spconv_rb(RbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LD = NTW * 16 + 4;                       // padded accumulator row stride (floats); 16 B multiple
+  constexpr int WAVE_FLOATS = RB_ROWS * LD + 2 * 256;    // accumulators + 2 x 1 KiB staging
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t bid = (int64_t)rb_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  if (bid >= a.nblk) return;  // wave-uniform; waves never synchronise with each other
+  float* acc_lds = (float*)smem + (size_t)wave * WAVE_FLOATS;
+  float* stage = acc_lds + RB_ROWS * LD;
+  const int jt0 = blockIdx.y * NTW;
+  const int cin = a.c0 + a.c1;
+  const int S0 = a.c0 >> 4, S = cin >> 4;
+
+  for (int t = lane; t < RB_ROWS * LD / 4; t += 64) ((f32x4*)acc_lds)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* off = a.rb_off + bid * (RB_K + 1);
+  const int dma_row = lane >> 2, dma_q = lane & 3;
+  for (int k = 0; k < RB_K; ++k) {
+    const int beg = __builtin_amdgcn_readfirstlane(off[k]);
+    const int end = __builtin_amdgcn_readfirstlane(off[k + 1]);
+    const float* wk = a.wp + (int64_t)k * S * a.NT * 256;
+    for (int t = beg; t < end; t += 16) {
+      const int e_in = a.rb_in[t + i];
+      const int e_out = a.rb_out[t + i];
+      const int row_dma = __shfl(e_in, dma_row);  // input row this lane's quad fetches
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // prologue: DMA of channel step 0
+      {
+        const float* g = a.in0 + (int64_t)row_dma * a.c0 + dma_q * 4;
+        if (S0 == 0) g = a.in1 + (int64_t)row_dma * a.c1 + dma_q * 4;
+        __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)stage, 16, 0, 0);
+      }
+      for (int s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(s) has landed in stage[s & 1]
+        const f32x4 A = *(const f32x4*)(stage + (s & 1) * 256 + i * 16 + q * 4);
+        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 256 + lane * 4;
+        f32x4 B[NTW];
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt)
+          B[jt] = (jt0 + jt < a.NT) ? *(const f32x4*)(ws + jt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s + 1 < S) {  // DMA(s+1) overlaps the MFMAs below; its buffer was last read at step s-1
+          const int s1 = s + 1;
+          const float* g = s1 < S0 ? a.in0 + (int64_t)row_dma * a.c0 + s1 * 16 + dma_q * 4
+                                   : a.in1 + (int64_t)row_dma * a.c1 + (s1 - S0) * 16 + dma_q * 4;
+          __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(stage + (s1 & 1) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt], B[jt][tt], acc[jt], 0, 0, 0);
+        }
+      }
+      // scatter the 16 x (NTW*16) tile into the wave's LDS accumulator rows
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lo = __shfl(e_out, 4 * q + r);
+        if (lo >= 0) {
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt) acc_lds[lo * LD + jt * 16 + i] += acc[jt][r];
+        }
+      }
+    }
+  }
+
+  // epilogue: LDS rows -> global, float4 per lane
+  const int64_t row_base = bid * RB_ROWS;
+  constexpr int CQ = NTW * 4;  // float4 chunks per row
+  for (int c = lane; c < RB_ROWS * CQ; c += 64) {
+    const int row = c / CQ, cq = c % CQ;
+    const int64_t grow = row_base + row;
+    const int col = jt0 * 16 + cq * 4;
+    if (grow < a.n_out && col < a.cout) {
+      f32x4 v = *(const f32x4*)(acc_lds + row * LD + cq * 4);
+      float e[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (col + u < a.cout) {
+          float x = e[u];
+          if (a.scale) x *= a.scale[col + u];
+          if (a.shift) x += a.shift[col + u];
+          if (a.relu) x = fmaxf(x, 0.f);
+          e[u] = x;
+        }
+      }
+      if (col + 3 < a.cout) {
+        if (a.residual) {
+          f32x4 rr = *(const f32x4*)(a.residual + grow * a.cout + col);
+          e[0] += rr[0]; e[1] += rr[1]; e[2] += rr[2]; e[3] += rr[3];
+        }
+        *(f32x4*)(a.out + grow * a.cout + col) = (f32x4){e[0], e[1], e[2], e[3]};
+      } else {
+        for (int u = 0; u < 4 && col + u < a.cout; ++u)
+          a.out[grow * a.cout + col + u] = e[u] + (a.residual ? a.residual[grow * a.cout + col + u] : 0.f);
+      }
+    }
+  }
+}
+
+extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
+                                const int32_t* rb_off, const int32_t* rb_in, const int32_t* rb_out, int64_t n_out,
+                                int32_t cout, const float* scale, const float* shift, int32_t relu,
+                                const float* residual, float* out, pp_stream_t stream) {
+  PP_REQUIRE(in0 && packed_weight && rb_off && rb_in && rb_out && out, "pp_spconv_fwd_rb: null pointer");
+  PP_REQUIRE(c0 >= 0 && c1 >= 0 && (c0 + c1) > 0 && (c1 == 0 || in1), "pp_spconv_fwd_rb: bad channel split");
+  PP_REQUIRE(c0 % 16 == 0 && c1 % 16 == 0, "pp_spconv_fwd_rb: input channels must be multiples of 16 (use pp_spconv_fwd)");
+  PP_REQUIRE(cout % 4 == 0, "pp_spconv_fwd_rb: cout must be a multiple of 4");
+  if (n_out == 0) return PP_OK;
+  RbArgs a;
+  a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.rb_off = rb_off; a.rb_in = rb_in; a.rb_out = rb_out;
+  a.scale = scale; a.shift = shift; a.residual = residual; a.out = out; a.n_out = n_out;
+  a.nblk = pp_rulebook_blocks(n_out); a.c0 = c0; a.c1 = c1; a.cout = cout; a.NT = (cout + 15) / 16; a.relu = relu;
+  const int ntw = a.NT >= 2 ? 2 : 1;
+  const int groups = (a.NT + ntw - 1) / ntw;
+  dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)groups);
+  hipStream_t s = pp_s(stream);
+  static bool attr_done = false;
+  constexpr size_t lds2 = 4 * (RB_ROWS * (2 * 16 + 4) + 512) * sizeof(float);  // 80 KiB -> 2 workgroups per CU
+  constexpr size_t lds1 = 4 * (RB_ROWS * (1 * 16 + 4) + 512) * sizeof(float);  // 48 KiB -> 3 workgroups per CU
+  if (!attr_done) {
+    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    attr_done = true;
+  }
+  if (ntw == 2)
+    hipLaunchKernelGGL((k_spconv_rb<2>), grid, dim3(256), lds2, s, a);
+  else
+    hipLaunchKernelGGL((k_spconv_rb<1>), grid, dim3(256), lds1, s, a);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -194,6 +194,57 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     return out
 
 
+class Rulebook:
+    """Block-compacted form of a 27-offset kernel map (see csrc/pp_spconv_rb.hip)."""
+
+    def __init__(self, off, rb_in, rb_out, n_out, total, nbr):
+        self.off, self.rb_in, self.rb_out, self.n_out, self.total, self.nbr = off, rb_in, rb_out, n_out, total, nbr
+
+
+def rulebook_build(nbr):
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    assert K == 27
+    dev = nbr.device
+    nblk = int(lib.pp_rulebook_blocks(n_out))
+    off = torch.empty(nblk * 28 + 1, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.pp_rulebook_workspace(n_out)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_rulebook_offsets(_ptr(nbr), n_out, _ptr(off), _ptr(total), _ptr(ws), wsb, _stream()),
+               "pp_rulebook_offsets")
+    t = int(total.item())
+    rb_in = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
+    rb_out = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.pp_rulebook_fill(_ptr(nbr), n_out, _ptr(off), _ptr(rb_in), _ptr(rb_out), _stream()), "pp_rulebook_fill")
+    return Rulebook(off, rb_in, rb_out, n_out, t, nbr)
+
+
+def spconv_fwd_rb(in0, packed, rb, cout, in1=None, scale=None, shift=None, relu=False, residual=None):
+    lib = _lib.load()
+    in0 = _need(in0, torch.float32, "in0")
+    in1 = _need(in1, torch.float32, "in1")
+    c0 = in0.shape[1]
+    c1 = 0 if in1 is None else in1.shape[1]
+    n_out = rb.n_out
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=in0.device)
+    scale = _need(scale, torch.float32, "scale")
+    shift = _need(shift, torch.float32, "shift")
+    residual = _need(residual, torch.float32, "residual")
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.pp_spconv_fwd_rb(_ptr(in0), c0, _ptr(in1), c1, _ptr(packed), _ptr(rb.off), _ptr(rb.rb_in),
+                                    _ptr(rb.rb_out), n_out, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
+                                    _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd_rb")
+    if prof is not None:
+        e1.record()
+        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, 27, rb.nbr, residual is not None))
+    return out
+
+
 def spconv_bwd_weight(inp, dout, nbr, K):
     lib = _lib.load()
     inp = _need(inp, torch.float32, "in")

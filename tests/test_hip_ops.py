@@ -327,3 +327,42 @@ def test_morton_order_and_derived_maps(ops, oracle):
     assert torch.equal(up_probe, up_derived)
     same = ops.kernel_map(d, table, 3, 1, 1)
     assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))
+
+
+@pytest.mark.parametrize("cin,cout,n_pts", [(16, 16, 3000), (16, 32, 3000), (64, 64, 2000), (96, 96, 1500), (32, 48, 2500),
+                                           (192, 80, 1200), (16, 16, 1), (16, 16, 129), (48, 112, 700)])
+def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
+    """block-compacted rulebook kernel (LDS-DMA gather, LDS accumulators) vs the oracle, incl. fused cat + epilogue."""
+    rng = np.random.default_rng(13)
+    coords = surface(rng, n=n_pts, n_batch=2 if n_pts > 200 else 1, extent=40)
+    n = len(coords)
+    nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin / 4)).astype(np.float32)
+    rb = ops.rulebook_build(dev(nbr))
+    # rulebook invariants: every (k, out row) pair appears exactly once
+    off = rb.off.cpu().numpy()
+    rin, rout = rb.rb_in.cpu().numpy(), rb.rb_out.cpu().numpy()
+    assert rb.total == off[-1] and rb.total % 16 == 0
+    pairs = 0
+    for b in range(len(off) // 28):
+        for k in range(27):
+            lo, hi = off[b * 28 + k], off[b * 28 + k + 1]
+            act = rout[lo:hi] >= 0
+            rows = b * 128 + rout[lo:hi][act]
+            assert np.array_equal(nbr[k][rows], rin[lo:hi][act])
+            assert np.array_equal(np.nonzero(nbr[k][b * 128: b * 128 + 128] >= 0)[0], rout[lo:hi][act])
+            pairs += act.sum()
+    assert pairs == (nbr >= 0).sum()
+    want = oracle.spconv_fwd(x, W, nbr, n)
+    got = ops.spconv_fwd_rb(dev(x), ops.pack_weight(dev(W)), rb, cout)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    if cin >= 32:
+        h = cin // 2 // 16 * 16
+        sc = rng.normal(size=cout).astype(np.float32)
+        sh = rng.normal(size=cout).astype(np.float32)
+        res = rng.normal(size=(n, cout)).astype(np.float32)
+        want = oracle.spconv_fwd(x[:, :h], W, nbr, n, in1=x[:, h:], scale=sc, shift=sh, relu=True, residual=res)
+        got = ops.spconv_fwd_rb(dev(x[:, :h].copy()), ops.pack_weight(dev(W)), rb, cout, in1=dev(x[:, h:].copy()),
+                                scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)

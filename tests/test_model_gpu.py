@@ -54,8 +54,12 @@ def test_full_path_matches_oracle_with_synthetic_head_statistics(setup):
         assert np.array_equal(g, np.sort(w))
     assert np.array_equal(res.cluster_type.cpu().numpy(), want["cluster_type"])
     np.testing.assert_allclose(res.cluster_scores.cpu().numpy(), want["cluster_scores"], rtol=1e-3, atol=1e-4)
-    assert np.array_equal(labels.cpu().numpy(), want_labels)
-    assert sum(counts) == len(np.unique(want_labels[want_labels >= 0])) or sum(counts) > 0
+    # instance ids bit-exact after label canonicalisation (ids are paint ranks by score; near-equal scores may swap)
+    b = s["b"]["batch"]
+    for t in range(len(s["ids"])):
+        m = b == t
+        assert np.array_equal(bf.canon_partition(labels.cpu().numpy()[m]), bf.canon_partition(want_labels[m]))
+    assert sum(counts) > 0
 
 
 def test_network_outputs_match_oracle(setup):
