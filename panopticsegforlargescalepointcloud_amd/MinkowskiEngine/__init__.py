@@ -25,7 +25,19 @@ from . import utils  # noqa: F401
 
 # 3x3x3 convolutions with Cin % 16 == 0 run on the block-compacted rulebook kernel (csrc/pp_spconv_rb.hip);
 # PP_CONV=dense forces the dense-offset kernel (csrc/pp_spconv.hip) for A/B measurements.
-USE_RULEBOOK = os.environ.get("PP_CONV", "rb") != "dense"
+#   auto : rulebook for transposed stride-2 convolutions (each fine voxel has only ~3 coarse neighbours, the dense
+#          loop would be ~8x zero work) and for Cin >= 112; dense-offset kernel otherwise (measured per layer,
+#          profiles/r01_c_dense_vs_rulebook.md)
+CONV_MODE = os.environ.get("PP_CONV", "auto")
+USE_RULEBOOK = CONV_MODE != "dense"
+
+
+def _want_rulebook(conv, x, ts_out, cin):
+    if CONV_MODE == "rb":
+        return True
+    if CONV_MODE == "dense":
+        return False
+    return (conv.TRANSPOSED and ts_out != x.tensor_stride) or cin >= 112
 
 
 # ------------------------------------------------------------------------------------------------
@@ -473,7 +485,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
         res = residual.feats
     c0 = x.feats.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
-    if USE_RULEBOOK and nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0:
+    if (nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0
+            and _want_rulebook(conv, x, ts_out, c0 + c1)):
         sign = -1 if conv.TRANSPOSED else 1
         rb = cm.rulebook(x.tensor_stride, ts_out, conv.kernel_size, sign)
         feats = ops.spconv_fwd_rb(x.feats, conv.packed(), rb, conv.out_channels, in1=in1, scale=scale, shift=shift,
