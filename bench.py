@@ -109,9 +109,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=env_int("PP_BENCH_POINTS", 10_000_000))
     ap.add_argument("--grid", type=int, default=env_int("PP_BENCH_GRID", 8))
-    ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 8))
+    ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 64))
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +185,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    stage_ms = None
+    if args.stage_timing:
+        runner.stage_timing = True
+        runner.stage_ms = {}
+        step()
+        runner.stage_timing = False
+        stage_ms = {k: round(v, 1) for k, v in runner.stage_ms.items()}
+
     # HBM triad to confirm the roofline denominator on this box
     n_tri = 1 << 28
     a = torch.empty(n_tri, device=device)
@@ -226,7 +235,7 @@ def main():
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
-                       "setup_s": round(t_gen, 1)},
+                       "setup_s": round(t_gen, 1), "stage_ms": stage_ms},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

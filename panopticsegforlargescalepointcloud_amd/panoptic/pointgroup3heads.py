@@ -116,8 +116,10 @@ class PointGroup3heads(nn.Module):
             pred = torch.max(sem, 1)[1]
         return feats, sem, off, emb, pred
 
-    def group_and_score(self, epoch, feats, sem, off, emb, pred=None):
-        """Instance grouping (+ scoring) on given head outputs; returns a PanopticResults."""
+    def group_and_score(self, epoch, feats, sem, off, emb, pred=None, timer=None, t0=0.0):
+        """Instance grouping (+ scoring) on given head outputs; returns a PanopticResults.
+        timer(name, t0) -> t0: optional stage stopwatch used by bench.py (synchronises; off by default)."""
+        self._timer, self._t0 = timer, t0
         if pred is None:
             pred = torch.max(sem, 1)[1]
         cluster_scores = mask_scores = csr = cluster_type = None
@@ -131,6 +133,7 @@ class PointGroup3heads(nn.Module):
                 csr, cluster_type = fns[ct](pred, off.detach(), emb.detach())
             if self.use_score_net and csr.n:
                 cluster_scores, mask_scores = self._compute_score(epoch, csr, feats, sem)
+                self._lap("scorer")
         return PanopticResults(semantic_logits=sem, offset_logits=off, embed_logits=emb, clusters=None,
                                cluster_scores=cluster_scores, mask_scores=mask_scores, cluster_type=cluster_type,
                                clusters_csr=csr)
@@ -171,9 +174,15 @@ class PointGroup3heads(nn.Module):
         votes = self._grow(self.raw_pos + off, pred, 200)
         return ops.ClusterCSR.concat([pos, votes]), self._types([(pos, 0), (votes, 1)], pred.device)
 
+    def _lap(self, name):
+        if getattr(self, "_timer", None) is not None:
+            self._t0 = self._timer(name, self._t0)
+
     def _cluster5(self, pred, off, emb):
         votes = self._grow(self.raw_pos + off, pred, 200)
+        self._lap("region_grow")
         embed = self._embed_clusters(pred, emb)
+        self._lap("meanshift")
         return ops.ClusterCSR.concat([votes, embed]), self._types([(votes, 0), (embed, 1)], pred.device)
 
     def _cluster6(self, pred, off, emb):

@@ -187,8 +187,20 @@ def exchange_tile_results(local, group=None):
 class TileRunner:
     """Runs batches of cylinder tiles through the model on one device (eval mode, no_grad)."""
 
-    def __init__(self, model, device, epoch=10 ** 6):
+    def __init__(self, model, device, epoch=10 ** 6, stage_timing=False):
         self.model, self.device, self.epoch = model, device, epoch
+        self.stage_timing = stage_timing
+        self.stage_ms = {}
+
+    def _tick(self, name, t0):
+        """wall time of a stage incl. its device work (only when stage_timing is on: it synchronises)."""
+        if self.stage_timing:
+            import time
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.stage_ms[name] = self.stage_ms.get(name, 0.0) + 1e3 * (now - t0)
+            return now
+        return t0
 
     @torch.no_grad()
     def run(self, batch_np, n_tiles, override=None):
@@ -198,10 +210,19 @@ class TileRunner:
         dev = self.device
         to = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)  # noqa: E731
         data = Data(pos=to(batch_np["pos"]), coords=to(batch_np["coords"]), batch=to(batch_np["batch"]), x=to(batch_np["x"]))
+        import time
+        t0 = time.perf_counter() if self.stage_timing else 0.0
+        if self.stage_timing:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         self.model.set_input(data, dev)
         feats, sem, off, emb, pred = self.model.backbone_and_heads()
+        t0 = self._tick("backbone+heads", t0)
         if override is not None:
             pred, off, emb = override
-        res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred)
+        res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred, timer=self._tick if self.stage_timing else None,
+                                         t0=t0)
+        t0 = self._tick("(group+score total marker)", time.perf_counter()) if False else (time.perf_counter() if self.stage_timing else 0.0)
         labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)
+        self._tick("nms+paint", t0)
         return labels, res, counts
