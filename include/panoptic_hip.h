@@ -113,7 +113,7 @@ int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, co
                   pp_stream_t stream);
 
 /* K3b/K4b  block-compacted rulebook and the convolution on it (the fast path for 3x3x3 kernels with Cin % 16 == 0).
- * The kernel map is regrouped per block of 128 consecutive output rows and per offset into compact lists of
+ * The kernel map is regrouped per block of 64 consecutive output rows and per offset into compact lists of
  * (input row, local output row) pairs padded to 16, so MFMA tiles hold only ACTIVE pairs (ME's "kernel map" in
  * in/out-pair form, regrouped for an output-stationary kernel; same reference call sites as K3/K4).
  *   rb_off int32 [blocks*28 + 1] (entry offsets per block and offset; total[0] = #entries), rb_in / rb_out int32 [total].

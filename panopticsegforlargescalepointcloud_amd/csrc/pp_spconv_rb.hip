@@ -22,7 +22,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define RB_ROWS 128
+#define RB_ROWS 64
 #define RB_K 27
 
 // ---------------------------------------------------------------------------------------------
@@ -141,73 +141,132 @@ __device__ inline unsigned rb_xcd_remap(unsigned b, unsigned n) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int NTW>
+// Work unit = TB tiles x CH channel steps of ONE offset k: all TB*CH A-tile DMAs and the CH*NTW B fragments are
+// issued back to back, ONE s_waitcnt covers them, then TB*CH*NTW*4 MFMAs run.  (TB,CH) = (4,1) for Cin = 16,
+// (2,2) for Cin = 32, (1,4) otherwise (chunks of 4 channel steps).  The entries of the next unit are prefetched
+// before the wait, so the dependent chain entry -> DMA address is off the critical path.
+template <int NTW, int TB, int CH>
 __global__ __launch_bounds__(256) void k_spconv_rb(RbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int LD = NTW * 16 + 4;                       // padded accumulator row stride (floats); 16 B multiple
-  constexpr int WAVE_FLOATS = RB_ROWS * LD + 2 * 256;    // accumulators + 2 x 1 KiB staging
+  constexpr int LD = NTW * 16 + 4;                                 // padded accumulator row stride (floats)
+  constexpr int ACC_FLOATS = (RB_ROWS + 1) * LD;                   // +1: dummy row that swallows padding pairs
+  constexpr int STAGE_FLOATS = TB * CH * 256;                      // TB*CH x 1 KiB A tiles
+  constexpr int WAVE_FLOATS = ACC_FLOATS + STAGE_FLOATS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int64_t bid = (int64_t)rb_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
   if (bid >= a.nblk) return;  // wave-uniform; waves never synchronise with each other
   float* acc_lds = (float*)smem + (size_t)wave * WAVE_FLOATS;
-  float* stage = acc_lds + RB_ROWS * LD;
+  float* stage = acc_lds + ACC_FLOATS;
   const int jt0 = blockIdx.y * NTW;
   const int cin = a.c0 + a.c1;
   const int S0 = a.c0 >> 4, S = cin >> 4;
 
-  for (int t = lane; t < RB_ROWS * LD / 4; t += 64) ((f32x4*)acc_lds)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = lane; t < ACC_FLOATS / 4; t += 64) ((f32x4*)acc_lds)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int32_t* off = a.rb_off + bid * (RB_K + 1);
   const int dma_row = lane >> 2, dma_q = lane & 3;
-  for (int k = 0; k < RB_K; ++k) {
-    const int beg = __builtin_amdgcn_readfirstlane(off[k]);
-    const int end = __builtin_amdgcn_readfirstlane(off[k + 1]);
+  const int blk_beg = __builtin_amdgcn_readfirstlane(off[0]);
+  const int blk_end = __builtin_amdgcn_readfirstlane(off[RB_K]);
+  // entries of the first unit
+  int e_in[TB], e_out[TB];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    const int p = blk_beg + tb * 16 + i;
+    e_in[tb] = p < blk_end ? a.rb_in[p] : 0;
+    e_out[tb] = p < blk_end ? a.rb_out[p] : -1;
+  }
+  int k = 0;
+  int kend = __builtin_amdgcn_readfirstlane(off[1]);
+  for (int t = blk_beg; t < blk_end;) {
+    while (t >= kend) {  // advance to the offset owning tile t (wave-uniform)
+      ++k;
+      kend = __builtin_amdgcn_readfirstlane(off[k + 1]);
+    }
+    // tiles of this unit: up to TB, all inside offset k
+    int ntile = (kend - t) >> 4;
+    if (ntile > TB) ntile = TB;
     const float* wk = a.wp + (int64_t)k * S * a.NT * 256;
-    for (int t = beg; t < end; t += 16) {
-      const int e_in = a.rb_in[t + i];
-      const int e_out = a.rb_out[t + i];
-      const int row_dma = __shfl(e_in, dma_row);  // input row this lane's quad fetches
-      f32x4 acc[NTW];
+    int row_dma[TB], lo_cur[TB];
 #pragma unroll
-      for (int jt = 0; jt < NTW; ++jt) acc[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // prologue: DMA of channel step 0
-      {
-        const float* g = a.in0 + (int64_t)row_dma * a.c0 + dma_q * 4;
-        if (S0 == 0) g = a.in1 + (int64_t)row_dma * a.c1 + dma_q * 4;
-        __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)stage, 16, 0, 0);
-      }
-      for (int s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(s) has landed in stage[s & 1]
-        const f32x4 A = *(const f32x4*)(stage + (s & 1) * 256 + i * 16 + q * 4);
-        const float* ws = wk + ((int64_t)s * a.NT + jt0) * 256 + lane * 4;
-        f32x4 B[NTW];
+    for (int tb = 0; tb < TB; ++tb) {
+      row_dma[tb] = __shfl(e_in[tb], dma_row);
+      lo_cur[tb] = e_out[tb];
+    }
+    // prefetch the next unit's entries (consumed after this unit's MFMAs)
+    const int tn = t + ntile * 16;
 #pragma unroll
-        for (int jt = 0; jt < NTW; ++jt)
-          B[jt] = (jt0 + jt < a.NT) ? *(const f32x4*)(ws + jt * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s + 1 < S) {  // DMA(s+1) overlaps the MFMAs below; its buffer was last read at step s-1
-          const int s1 = s + 1;
-          const float* g = s1 < S0 ? a.in0 + (int64_t)row_dma * a.c0 + s1 * 16 + dma_q * 4
-                                   : a.in1 + (int64_t)row_dma * a.c1 + (s1 - S0) * 16 + dma_q * 4;
-          __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(stage + (s1 & 1) * 256), 16, 0, 0);
+    for (int tb = 0; tb < TB; ++tb) {
+      const int p = tn + tb * 16 + i;
+      e_in[tb] = p < blk_end ? a.rb_in[p] : 0;
+      e_out[tb] = p < blk_end ? a.rb_out[p] : -1;
+    }
+    f32x4 acc[TB][NTW];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) acc[tb][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int s0 = 0; s0 < S; s0 += CH) {
+      const int ch = (S - s0) < CH ? (S - s0) : CH;
+      // issue: A tiles by LDS-DMA, B fragments to registers
+#pragma unroll
+      for (int sl = 0; sl < CH; ++sl) {
+        if (sl < ch) {
+          const int sg = s0 + sl;
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) {
+            if (tb < ntile) {
+              const float* g = sg < S0 ? a.in0 + (int64_t)row_dma[tb] * a.c0 + sg * 16 + dma_q * 4
+                                       : a.in1 + (int64_t)row_dma[tb] * a.c1 + (sg - S0) * 16 + dma_q * 4;
+              __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(stage + (tb * CH + sl) * 256), 16, 0, 0);
+            }
+          }
         }
+      }
+      f32x4 B[CH][NTW];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+      for (int sl = 0; sl < CH; ++sl) {
 #pragma unroll
-          for (int jt = 0; jt < NTW; ++jt)
-            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt], B[jt][tt], acc[jt], 0, 0, 0);
+        for (int jt = 0; jt < NTW; ++jt) {
+          B[sl][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (sl < ch && jt0 + jt < a.NT)
+            B[sl][jt] = *(const f32x4*)(wk + ((int64_t)(s0 + sl) * a.NT + jt0 + jt) * 256 + lane * 4);
         }
       }
-      // scatter the 16 x (NTW*16) tile into the wave's LDS accumulator rows
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs (and B, and the prefetched entries) have landed
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int lo = __shfl(e_out, 4 * q + r);
-        if (lo >= 0) {
+      for (int sl = 0; sl < CH; ++sl) {
+        if (sl < ch) {
 #pragma unroll
-          for (int jt = 0; jt < NTW; ++jt) acc_lds[lo * LD + jt * 16 + i] += acc[jt][r];
+          for (int tb = 0; tb < TB; ++tb) {
+            if (tb < ntile) {
+              const f32x4 A = *(const f32x4*)(stage + (tb * CH + sl) * 256 + i * 16 + q * 4);
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int jt = 0; jt < NTW; ++jt)
+                  acc[tb][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt], B[sl][jt][tt], acc[tb][jt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      asm volatile("" ::: "memory");  // the staging tiles are re-filled by the next chunk's DMAs
+    }
+    // scatter the TB x (16 x NTW*16) tiles into the wave's LDS accumulator rows (padding pairs -> dummy row)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+      if (tb < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int lo = __shfl(lo_cur[tb], 4 * q + r);
+          lo = lo < 0 ? RB_ROWS : lo;
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt) acc_lds[lo * LD + jt * 16 + i] += acc[tb][jt][r];
         }
       }
     }
+    t = tn;
   }
 
   // epilogue: LDS rows -> global, float4 per lane
@@ -244,6 +303,19 @@ __global__ __launch_bounds__(256) void k_spconv_rb(RbArgs a) {
   }
 }
 
+template <int NTW, int TB, int CH>
+static int rb_launch(const RbArgs& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = 4 * ((RB_ROWS + 1) * (NTW * 16 + 4) + TB * CH * 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb<NTW, TB, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_spconv_rb<NTW, TB, CH>), grid, dim3(256), lds, s, a);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
                                 const int32_t* rb_off, const int32_t* rb_in, const int32_t* rb_out, int64_t n_out,
                                 int32_t cout, const float* scale, const float* shift, int32_t relu,
@@ -261,18 +333,14 @@ extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, 
   const int groups = (a.NT + ntw - 1) / ntw;
   dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)groups);
   hipStream_t s = pp_s(stream);
-  static bool attr_done = false;
-  constexpr size_t lds2 = 4 * (RB_ROWS * (2 * 16 + 4) + 512) * sizeof(float);  // 80 KiB -> 2 workgroups per CU
-  constexpr size_t lds1 = 4 * (RB_ROWS * (1 * 16 + 4) + 512) * sizeof(float);  // 48 KiB -> 3 workgroups per CU
-  if (!attr_done) {
-    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    attr_done = true;
+  const int S = (c0 + c1) / 16;
+  if (ntw == 2) {
+    if (S == 1) return rb_launch<2, 4, 1>(a, grid, s);
+    if (S == 2) return rb_launch<2, 2, 2>(a, grid, s);
+    return rb_launch<2, 1, 4>(a, grid, s);
   }
-  if (ntw == 2)
-    hipLaunchKernelGGL((k_spconv_rb<2>), grid, dim3(256), lds2, s, a);
-  else
-    hipLaunchKernelGGL((k_spconv_rb<1>), grid, dim3(256), lds1, s, a);
-  PP_LAUNCH_CHECK();
-  return PP_OK;
+  if (S == 1) return rb_launch<1, 4, 1>(a, grid, s);
+  if (S == 2) return rb_launch<1, 2, 2>(a, grid, s);
+  return rb_launch<1, 1, 4>(a, grid, s);
 }
+

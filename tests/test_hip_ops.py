@@ -330,7 +330,7 @@ def test_morton_order_and_derived_maps(ops, oracle):
 
 
 @pytest.mark.parametrize("cin,cout,n_pts", [(16, 16, 3000), (16, 32, 3000), (64, 64, 2000), (96, 96, 1500), (32, 48, 2500),
-                                           (192, 80, 1200), (16, 16, 1), (16, 16, 129), (48, 112, 700)])
+                                           (192, 80, 1200), (16, 16, 1), (16, 16, 129), (48, 112, 700), (80, 80, 900), (112, 96, 500)])
 def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
     """block-compacted rulebook kernel (LDS-DMA gather, LDS accumulators) vs the oracle, incl. fused cat + epilogue."""
     rng = np.random.default_rng(13)
@@ -345,13 +345,14 @@ def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
     rin, rout = rb.rb_in.cpu().numpy(), rb.rb_out.cpu().numpy()
     assert rb.total == off[-1] and rb.total % 16 == 0
     pairs = 0
+    RBR = 64  # RB_ROWS in csrc/pp_spconv_rb.hip
     for b in range(len(off) // 28):
         for k in range(27):
             lo, hi = off[b * 28 + k], off[b * 28 + k + 1]
             act = rout[lo:hi] >= 0
-            rows = b * 128 + rout[lo:hi][act]
+            rows = b * RBR + rout[lo:hi][act]
             assert np.array_equal(nbr[k][rows], rin[lo:hi][act])
-            assert np.array_equal(np.nonzero(nbr[k][b * 128: b * 128 + 128] >= 0)[0], rout[lo:hi][act])
+            assert np.array_equal(np.nonzero(nbr[k][b * RBR: b * RBR + RBR] >= 0)[0], rout[lo:hi][act])
             pairs += act.sum()
     assert pairs == (nbr >= 0).sum()
     want = oracle.spconv_fwd(x, W, nbr, n)
