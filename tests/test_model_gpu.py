@@ -54,7 +54,13 @@ def test_full_path_matches_oracle_with_synthetic_head_statistics(setup):
         assert np.array_equal(g, np.sort(w))
     assert np.array_equal(res.cluster_type.cpu().numpy(), want["cluster_type"])
     np.testing.assert_allclose(res.cluster_scores.cpu().numpy(), want["cluster_scores"], rtol=1e-3, atol=1e-4)
-    # instance ids bit-exact after label canonicalisation (ids are paint ranks by score; near-equal scores may swap)
+    # NMS + painting: bit-exact after label canonicalisation GIVEN THE SAME SCORES (a random-init scorer squeezes all
+    # scores into a ~1e-3 band, so float-rounding differences between the two score vectors may legitimately swap the
+    # paint order of two overlapping proposals; the scores themselves are compared above)
+    from oracle import pipeline as opipe
+    want2 = dict(want)
+    want2["cluster_scores"] = res.cluster_scores.cpu().numpy()
+    want_labels = opipe.instance_labels(want2, len(s["b"]["pos"]), s["b"]["batch"])
     b = s["b"]["batch"]
     for t in range(len(s["ids"])):
         m = b == t
