@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
 // label propagation (16 lanes per point)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict__ list, const int32_t* __restrict__ deg,
-                                                      int32_t* L, int64_t M, int nsample, int32_t* changed) {
+                                                      int32_t* L, int32_t* pushed, int64_t M, int nsample,
+                                                      int32_t* changed) {
   const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int sl = threadIdx.x & 15;
   if (g >= M) return;
@@ -214,6 +215,13 @@ __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict_
     atomicMin(&L[g], lk);
     ch = true;
   }
+  // frontier: a point re-walks its neighbour list only when it has a smaller label to push than last time
+  // (labels only decrease, so a label already pushed can never be needed again by the same neighbours)
+  if (pushed[g] <= lk) {
+    if (ch) changed[0] = 1;
+    return;
+  }
+  if (sl == 0) pushed[g] = lk;
   const int d = deg[g];
   for (int t = sl; t < d; t += 16) {
     int j = list[g * nsample + t];
@@ -417,12 +425,14 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   hipLaunchKernelGGL(k_ball_query, dim3(pp_blocks(M, 4)), dim3(256), 0, s, spos, sbc, ckeys, cell_start, cell_end, cap,
                      M, radius, nsample, list, deg);
   hipLaunchKernelGGL(k_iota, dim3(mb), dim3(256), 0, s, L, M);
+  int32_t* pushed = size;  // reused as the cluster-size array once the fixpoint is reached
+  hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks(M)), dim3(256), 0, s, pushed, 0x7FFFFFFF, M);
   PP_LAUNCH_CHECK();
   // fixpoint
   for (int round = 0; round < 4096; ++round) {
     PP_HIP(hipMemsetAsync(misc + 2, 0, sizeof(int32_t), s));
     for (int it = 0; it < 4; ++it)
-      hipLaunchKernelGGL(k_rg_propagate, dim3(pp_blocks(M * 16, 256)), dim3(256), 0, s, list, deg, L, M, nsample,
+      hipLaunchKernelGGL(k_rg_propagate, dim3(pp_blocks(M * 16, 256)), dim3(256), 0, s, list, deg, L, pushed, M, nsample,
                          misc + 2);
     PP_LAUNCH_CHECK();
     PP_HIP(hipMemcpyAsync(h, misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -57,10 +57,19 @@ __device__ inline int pp_floor_div(int a, int b) {
   return q;
 }
 
+// Home slot of a coordinate key: the 4x4x4 voxel block (batch, x>>2, y>>2, z>>2) is hashed, the low two bits of
+// x/y/z pick one of 64 consecutive slots.  The 27 probes of a kernel-map row then touch a handful of 512 B key
+// groups that the Morton-ordered neighbouring rows have just pulled into L2, instead of 27 random cache lines.
+__host__ __device__ inline uint64_t pp_home_slot(uint64_t key, uint64_t mask) {
+  const uint64_t block = key & 0xFFFFFFFCFFFCFFFCull;
+  const uint64_t low = ((key >> 32) & 3ull) << 4 | ((key >> 16) & 3ull) << 2 | (key & 3ull);
+  return ((pp_mix64(block) << 6) | low) & mask;
+}
+
 // open-addressing lookup: returns slot holding `key`, or -1
 __device__ inline int64_t pp_hash_find_slot(const uint64_t* __restrict__ keys, int64_t cap, uint64_t key) {
   uint64_t mask = (uint64_t)cap - 1;
-  uint64_t s = pp_mix64(key) & mask;
+  uint64_t s = pp_home_slot(key, mask);
   for (;;) {
     uint64_t k = keys[s];
     if (k == key) return (int64_t)s;
@@ -71,7 +80,7 @@ __device__ inline int64_t pp_hash_find_slot(const uint64_t* __restrict__ keys, i
 // insert-or-find: returns slot
 __device__ inline int64_t pp_hash_insert_slot(uint64_t* keys, int64_t cap, uint64_t key) {
   uint64_t mask = (uint64_t)cap - 1;
-  uint64_t s = pp_mix64(key) & mask;
+  uint64_t s = pp_home_slot(key, mask);
   for (;;) {
     unsigned long long prev = atomicCAS((unsigned long long*)&keys[s], (unsigned long long)PP_EMPTY_KEY,
                                        (unsigned long long)key);

@@ -17,10 +17,39 @@ from .applications import Data
 
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
+def overlapping_pairs(csr, max_sources=4):
+    """Proposal pairs that share points, with their intersection sizes, from the point -> proposal incidence
+    (the sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  Returns int64 tensors (a, b, inter)
+    with a < b.  A point may belong to at most `max_sources` proposals (one per proposal source: region growing on
+    raw / shifted coordinates, mean shift) -- checked."""
+    dev = csr.points.device
+    P = csr.n
+    sizes = csr.sizes()
+    prop_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+    order = torch.argsort(csr.points, stable=True)
+    sp, sq = csr.points[order], prop_of_entry[order]
+    if sp.numel() > max_sources and bool((sp[max_sources:] == sp[:-max_sources]).any()):
+        raise NotImplementedError("a point belongs to more than %d proposals" % max_sources)
+    keys = []
+    for d in range(1, max_sources):
+        if sp.numel() <= d:
+            break
+        m = sp[d:] == sp[:-d]
+        x, y = sq[:-d][m], sq[d:][m]
+        keys.append(torch.minimum(x, y) * P + torch.maximum(x, y))
+    if not keys:
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        return z, z, z, prop_of_entry
+    uniq, inter = torch.unique(torch.cat(keys), return_counts=True)
+    return uniq // P, uniq % P, inter, prop_of_entry
+
+
 def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
-    """Runs get_instances per batch element and paints the surviving clusters in ascending score order.
+    """get_instances per batch element (NMS, size and score filters; structure_3heads.py:28-71) and
+    get_cur_ins_pre_label (surviving clusters painted in ascending score order; tracker :326-337), for all tiles of the
+    batch at once: overlaps come from one device-side pass over the incidence, the greedy picks run on the host over
+    the few overlapping pairs (the reference runs NMS on the host too), painting is one scatter-max.
     Returns int32 labels [N] (-1 = none; ids restart at 0 in every tile) and the number of instances per tile."""
-    from . import ops
     dev = batch.device
     n = batch.shape[0]
     labels = torch.full((n,), -1, dtype=torch.int32, device=dev)
@@ -28,44 +57,49 @@ def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster
     csr = res.clusters_csr
     if csr is None or csr.n == 0:
         return labels, counts
-    first_pt = csr.points[csr.offsets[:-1].long()]
-    tile_of_prop = batch[first_pt]
-    sizes = csr.sizes()
-    scores_all = res.cluster_scores
-    for t in range(n_tiles):
-        ids = torch.nonzero(tile_of_prop == t).view(-1)
-        if ids.numel() == 0:
-            continue
-        sz = sizes[ids]
-        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sz, 0)])
-        starts = csr.offsets[ids.long()].long()
-        # gather the point lists of the selected proposals
-        rep = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), sz)
-        within = torch.arange(int(offs[-1].item()), device=dev) - offs[rep]
-        pts = csr.points[starts[rep] + within]
-        sub = ops.ClusterCSR(offs.to(torch.int32), pts, ids.numel())
-        if scores_all is None:
-            keep = list(range(sub.n))  # no ScoreNet: every proposal is an instance (structure_3heads.py:34-35)
-            order = keep
-        else:
-            inter = ops.proposal_intersections(sub, n).cpu().numpy().astype(np.float32)
-            szn = np.diag(inter).copy()
-            ious = inter / (szn[:, None] + szn[None, :] - inter)
-            sc = scores_all[ids].detach().cpu().numpy()
-            from .panoptic.structures import non_max_suppression
-            pick = non_max_suppression(ious, sc, nms_threshold)
-            keep = [i for i in pick if szn[i] > min_cluster_points and sc[i] > min_score]
-            order = [keep[j] for j in np.argsort(sc[keep], kind="stable")] if keep else []
-        if not order:
-            continue
-        # paint ascending score: later (better) clusters overwrite earlier ones -> amax over the paint rank
-        order_t = torch.tensor(order, device=dev)
-        rank_of = torch.full((sub.n,), -1, dtype=torch.int32, device=dev)
-        rank_of[order_t] = torch.arange(len(order), dtype=torch.int32, device=dev)
-        r = rank_of[rep]
-        m = r >= 0
-        labels.scatter_reduce_(0, pts[m], r[m], "amax", include_self=True)
-        counts[t] = len(order)
+    P = csr.n
+    sizes_d = csr.sizes()
+    tile_of_prop = batch[csr.points[csr.offsets[:-1].long()]].cpu().numpy()
+    sizes = sizes_d.cpu().numpy()
+    rank_of_prop = np.full(P, -1, np.int32)
+    if res.cluster_scores is None:  # no ScoreNet: every proposal is an instance (structure_3heads.py:34-35)
+        a, b, inter, prop_of_entry = overlapping_pairs(csr)
+        for t in range(n_tiles):
+            ids = np.nonzero(tile_of_prop == t)[0]
+            rank_of_prop[ids] = np.arange(len(ids))
+            counts[t] = len(ids)
+    else:
+        a, b, inter, prop_of_entry = overlapping_pairs(csr)
+        iou = inter.float() / (sizes_d[a] + sizes_d[b] - inter).float()
+        hot = iou > nms_threshold
+        ea, eb = a[hot].cpu().numpy(), b[hot].cpu().numpy()
+        scores = res.cluster_scores.detach().float().cpu().numpy()
+        adj = {}
+        for x, y in zip(ea.tolist(), eb.tolist()):
+            adj.setdefault(x, []).append(y)
+            adj.setdefault(y, []).append(x)
+        for t in range(n_tiles):
+            ids = np.nonzero(tile_of_prop == t)[0]
+            if len(ids) == 0:
+                continue
+            sc = scores[ids]
+            suppressed = set()
+            pick = []
+            for j in sc.argsort()[::-1]:  # same ordering call as non_max_suppression (structure_3heads.py:6-16)
+                i = int(ids[j])
+                if i in suppressed:
+                    continue
+                pick.append(i)
+                suppressed.update(adj.get(i, ()))
+            keep = [i for i in pick if sizes[i] > min_cluster_points and scores[i] > min_score]
+            if keep:
+                order = [keep[j] for j in np.argsort(scores[keep], kind="stable")]
+                rank_of_prop[order] = np.arange(len(order))
+                counts[t] = len(order)
+    r = torch.from_numpy(rank_of_prop).to(dev)[prop_of_entry]
+    m = r >= 0
+    # ascending score = ascending rank: the best cluster covering a point wins -> max over paint ranks
+    labels.scatter_reduce_(0, csr.points[m], r[m], "amax", include_self=True)
     return labels, counts
 
 
