@@ -37,13 +37,14 @@ def env_int(name, default):
 def build_scene(total_points, grid, voxel, seed):
     from panopticsegforlargescalepointcloud_amd import synthetic as syn
     # overlapping cylinders feed each scene voxel ~2x: size the scene so the tiles sum to ~total_points
-    scene = syn.urban_scene(int(total_points / 2.0), voxel=voxel, seed=seed)
-    tiles, radius = syn.cylinder_tiles(scene, grid)
-    fed = sum(len(t) for t in tiles)
-    # one correction pass so the fed total lands within a few % of the target
-    if abs(fed - total_points) / total_points > 0.03:
-        scene = syn.urban_scene(int(total_points / 2.0 * total_points / fed), voxel=voxel, seed=seed)
+    target = total_points / 2.0
+    for _ in range(4):
+        scene = syn.urban_scene(int(target), voxel=voxel, seed=seed)
         tiles, radius = syn.cylinder_tiles(scene, grid)
+        fed = sum(len(t) for t in tiles)
+        if abs(fed - total_points) / total_points <= 0.02:
+            break
+        target *= total_points / fed
     return scene, tiles, radius
 
 

@@ -17,21 +17,22 @@ from .applications import Data
 
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
-def overlapping_pairs(csr, max_sources=4):
+def overlapping_pairs(csr, max_sources=64):
     """Proposal pairs that share points, with their intersection sizes, from the point -> proposal incidence
     (the sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  Returns int64 tensors (a, b, inter)
-    with a < b.  A point may belong to at most `max_sources` proposals (one per proposal source: region growing on
-    raw / shifted coordinates, mean shift) -- checked."""
+    with a < b.  In the model a point belongs to one proposal per source (region growing on raw / shifted
+    coordinates, mean shift), so the multiplicity loop below runs 1-2 times; `max_sources` only bounds it."""
     dev = csr.points.device
     P = csr.n
     sizes = csr.sizes()
     prop_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
     order = torch.argsort(csr.points, stable=True)
     sp, sq = csr.points[order], prop_of_entry[order]
-    if sp.numel() > max_sources and bool((sp[max_sources:] == sp[:-max_sources]).any()):
-        raise NotImplementedError("a point belongs to more than %d proposals" % max_sources)
+    mult = int(torch.unique_consecutive(sp, return_counts=True)[1].max().item()) if sp.numel() else 0
+    if mult > max_sources:
+        raise NotImplementedError("a point belongs to %d proposals (> %d)" % (mult, max_sources))
     keys = []
-    for d in range(1, max_sources):
+    for d in range(1, mult):
         if sp.numel() <= d:
             break
         m = sp[d:] == sp[:-d]

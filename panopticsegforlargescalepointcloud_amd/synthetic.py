@@ -44,7 +44,8 @@ def urban_points(n_points, extent, rng, objects_per_m2=0.12):
     pos = np.concatenate([g, f, o])
     cls = np.concatenate([np.zeros(n_ground, np.int64), np.ones(n_fac, np.int64), o_cls[o_id]])
     inst = np.concatenate([np.zeros(n_ground + n_fac, np.int64), o_id + 1])
-    return pos, cls, inst
+    inside = (pos[:, 0] >= 0) & (pos[:, 0] <= extent) & (pos[:, 1] >= 0) & (pos[:, 1] <= extent)  # facades may overshoot
+    return pos[inside], cls[inside], inst[inside]
 
 
 def voxelise(pos, cls, inst, voxel, rng):

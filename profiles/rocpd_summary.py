@@ -28,5 +28,24 @@ def main(db, out=None):
     print(txt)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--pmc"):
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+
+
+def pmc(db, out=None, like="%"):
+    """per-kernel average of every collected counter (rocprofv3 --pmc run): python rocpd_summary.py --pmc db out.md"""
+    con = sqlite3.connect(db)
+    rows = con.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                       "where kernel_name like ? group by kernel_name, counter_name order by 5 desc", (like,)).fetchall()
+    lines = ["# rocprofv3 --pmc summary (%s)" % db.split("/")[-1], "", "| kernel | counter | dispatches | avg per dispatch | sum |",
+             "|---|---|---|---|---|"]
+    for r in rows[:60]:
+        lines.append("| %s | %s | %d | %.6g | %.6g |" % (r[0][:70], r[1], r[2], r[3], r[4]))
+    txt = "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc":
+    pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

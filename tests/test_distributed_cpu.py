@@ -1,0 +1,85 @@
+"""world_size-2 gloo test of the multi-GPU path on CPU tensors: tile sharding, the single all-gather exchange of
+per-tile label arrays, and the order-dependent scene assembly being identical on every rank and equal to the
+single-process result."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tile_results(n_tiles, n_scene):
+    """deterministic fake per-tile outputs: (origin_ids, labels)"""
+    out = {}
+    for t in range(n_tiles):
+        rng = np.random.default_rng(100 + t)
+        start = t * 700
+        origin = np.sort(rng.choice(np.arange(start, min(start + 1500, n_scene)), size=900 + 37 * t, replace=False))
+        labels = np.full(len(origin), -1, np.int32)
+        k = 4 + t % 3
+        cuts = np.sort(rng.choice(len(origin), size=k + 1, replace=False))
+        for i in range(k):
+            labels[cuts[i]: cuts[i + 1]] = i
+        out[t] = (torch.from_numpy(origin.astype(np.int64)), torch.from_numpy(labels))
+    return out
+
+
+def _assemble(results, n_scene):
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler
+    asm = SceneAssembler(n_scene, 9)
+    for t in sorted(results):  # original block order (the greedy merge is order dependent)
+        asm.add_block(results[t][0].numpy(), results[t][1].numpy())
+    return asm.ins_pre, asm.max_instance, asm.prediction_count
+
+
+def _worker(rank, world, port, n_tiles, n_scene, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results, shard_tiles
+    allr = _tile_results(n_tiles, n_scene)
+    sizes = [len(allr[t][0]) for t in range(n_tiles)]
+    mine = shard_tiles(sizes, world)[rank]
+    local = {t: allr[t] for t in mine}
+    full = exchange_tile_results(local)
+    ok = sorted(full) == list(range(n_tiles)) and all(
+        torch.equal(full[t][0], allr[t][0]) and torch.equal(full[t][1], allr[t][1]) for t in range(n_tiles))
+    ins, mx, cnt = _assemble(full, n_scene)
+    q.put((rank, ok, ins.tobytes(), mx, int(cnt.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_and_assembly_world2():
+    n_tiles, n_scene, world = 9, 8000, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_tiles, n_scene, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_ins, ref_mx, ref_cnt = _assemble(_tile_results(n_tiles, n_scene), n_scene)
+    for rank, ok, ins_bytes, mx, cnt in got:
+        assert ok, "rank %d did not receive every tile intact" % rank
+        assert ins_bytes == ref_ins.tobytes() and mx == ref_mx and cnt == int(ref_cnt.sum())
+
+
+def test_exchange_single_process_is_identity():
+    from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results
+    r = _tile_results(3, 4000)
+    out = exchange_tile_results(r)
+    assert sorted(out) == [0, 1, 2] and all(torch.equal(out[t][1], r[t][1]) for t in r)

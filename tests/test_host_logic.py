@@ -1,0 +1,172 @@
+"""CPU tests of the host-side logic: config loading (the reference YAML schema), model assembly / state_dict layout,
+tile sharding, NMS + painting, block merging, synthetic scenes.  No GPU, no HIP calls."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bruteforce as bf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_YAML = "/root/reference/conf/models/panoptic/area4_ablation_3heads_5.yaml"
+
+
+class DS:
+    feature_dimension = 4
+    num_classes = 9
+    stuff_classes = torch.tensor([0, 1, 5])
+
+
+def _build(path):
+    from panopticsegforlargescalepointcloud_amd.config import load_model_config
+    from panopticsegforlargescalepointcloud_amd.panoptic import PointGroup3heads
+    cfg = load_model_config(path, "PointGroup-PAPER", data={"grid_size": 0.12})
+    torch.manual_seed(0)
+    return PointGroup3heads(cfg, "dummy", DS, None), cfg
+
+
+@pytest.mark.parametrize("path", [os.path.join(ROOT, "conf", "panoptic_3heads.yaml"), REF_YAML])
+def test_model_from_reference_yaml_schema(path):
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this box")
+    m, cfg = _build(path)
+    assert abs(cfg.cluster_radius_search - 1.5 * 0.12) < 1e-9 and cfg.cluster_type == 5 and cfg.prepare_epoch == 30
+    sd = m.state_dict()
+    conv = sum(v.numel() for k, v in sd.items() if k.startswith("Backbone.") and k.endswith(".kernel"))
+    bn = sum(v.numel() for k, v in sd.items() if k.startswith("Backbone.") and k.endswith(("bn.weight", "bn.bias")))
+    scorer = sum(v.numel() for k, v in sd.items() if k.startswith("ScorerUnet.") and k.endswith(".kernel"))
+    assert (conv, bn, scorer) == (10403520, 10176, 931840)
+    # ME layout and names: kernel [27, Cin, Cout]; 1x1 shortcut [Cin, Cout]; BN under .bn
+    assert tuple(sd["Backbone.down_modules.0.conv_in.0.kernel"].shape) == (27, 4, 16)
+    assert tuple(sd["Backbone.down_modules.1.blocks.0.downsample.0.kernel"].shape) == (16, 32)
+    assert tuple(sd["Backbone.up_modules.1.conv_in.0.kernel"].shape) == (27, 192, 192)
+    assert "Backbone.up_modules.6.blocks.1.block.4.bn.running_var" in sd
+    assert tuple(sd["Semantic.0.0.0.weight"].shape) == (16, 16) and "Semantic.0.0.1.batch_norm.weight" in sd
+    assert tuple(sd["Offset.1.weight"].shape) == (3, 16) and tuple(sd["Embed.1.weight"].shape) == (5, 16)
+    assert tuple(sd["ScorerHead.0.weight"].shape) == (1, 16)
+    assert m._stuff_classes.tolist() == [-1, 0, 1, 5]
+    # kaiming fan_out init of conv kernels (applications/minkowski.py:104-111): std = sqrt(2 / (27 * Cout))
+    k = sd["Backbone.down_modules.3.blocks.1.block.0.kernel"]
+    assert abs(float(k.std()) - (2.0 / (27 * 64)) ** 0.5) < 2e-3
+
+
+def test_config_resolver_keeps_non_expressions():
+    from panopticsegforlargescalepointcloud_amd.config import resolve
+    cfg = {"a": "2*in_feat", "b": "max", "c": "ResNetDown", "d": ["FEAT", "in_feat"], "e": "1.5 * 0.05"}
+    resolve(cfg, {"in_feat": 16, "FEAT": 4})
+    assert cfg == {"a": 32, "b": "max", "c": "ResNetDown", "d": [4, 16], "e": 0.07500000000000001}
+
+
+def test_shard_tiles_balanced_and_complete():
+    from panopticsegforlargescalepointcloud_amd.scene import shard_tiles
+    sizes = np.random.default_rng(0).integers(100_000, 200_000, size=64)
+    for w in (1, 2, 4, 8):
+        sh = shard_tiles(sizes, w)
+        assert sorted(sum(sh, [])) == list(range(64))
+        loads = [sizes[s].sum() for s in sh]
+        assert max(loads) / min(loads) < 1.08
+        assert all(s == sorted(s) for s in sh)
+
+
+def test_synthetic_scene_and_tiles():
+    import bench
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    scene, tiles, r = bench.build_scene(120_000, 2, 0.05, 2022)
+    assert abs(sum(len(t) for t in tiles) - 120_000) / 120_000 < 0.05
+    assert len(np.unique(scene.coords, axis=0)) == len(scene.coords)  # one point per voxel
+    covered = np.zeros(len(scene.pos), bool)
+    for t in tiles:
+        covered[t] = True
+    assert covered.mean() > 0.97  # cylinders overlap and cover the scene (corners excepted)
+    b = syn.tile_batch(scene, tiles, [0, 3])
+    cc = np.concatenate([b["batch"][:, None], b["coords"]], 1)
+    assert len(np.unique(cc, axis=0)) == len(cc) and b["x"].shape[1] == 4
+    cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(0))
+    thing = scene.inst[b["origin_id"]] > 0
+    assert np.all(np.isin(cls[thing], syn.THING_CLASSES)) and np.all(off[~thing] == 0)
+    # shifted points pile up around the instance centre
+    sh = scene.pos[b["origin_id"]][thing] + off[thing] - scene.inst_center[scene.inst[b["origin_id"]][thing]]
+    assert np.abs(sh).mean() < 0.06
+
+
+def _fake_results(rng, n_tiles=3, per_tile=2000):
+    """proposals over `n_tiles` batch elements incl. duplicates and partial overlaps + scores"""
+    from panopticsegforlargescalepointcloud_amd import ops
+    clusters, batch = [], np.repeat(np.arange(n_tiles), per_tile)
+    for t in range(n_tiles):
+        base = t * per_tile
+        for _ in range(12):
+            c0 = int(rng.integers(0, per_tile - 300))
+            size = int(rng.integers(5, 250))
+            clusters.append(np.sort(base + c0 + rng.permutation(300)[:size]))
+        clusters.append(clusters[-1].copy())  # exact duplicate (region growing and mean shift often agree)
+    perm = rng.permutation(len(clusters))
+    clusters = [clusters[i] for i in perm]
+    scores = rng.uniform(0.3, 1.0, len(clusters)).astype(np.float32)
+    csr = ops.ClusterCSR.from_list([torch.from_numpy(c) for c in clusters], "cpu")
+    return clusters, scores, csr, batch
+
+
+def test_nms_and_painting_match_oracle_pipeline():
+    from oracle import pipeline as opipe
+    from panopticsegforlargescalepointcloud_amd.panoptic.structures import PanopticResults
+    from panopticsegforlargescalepointcloud_amd.scene import instance_labels_per_tile, overlapping_pairs
+    rng = np.random.default_rng(3)
+    clusters, scores, csr, batch = _fake_results(rng)
+    n = len(batch)
+    a, b, inter, _ = overlapping_pairs(csr)
+    dense = np.zeros((len(clusters), n), np.int64)
+    for i, c in enumerate(clusters):
+        dense[i, c] = 1
+    full = dense @ dense.T
+    assert np.array_equal(inter.numpy(), full[a.numpy(), b.numpy()])
+    assert len(a) == (np.triu(full, 1) > 0).sum()
+    res = PanopticResults(semantic_logits=torch.zeros(n, 9), offset_logits=None, embed_logits=None, clusters=None,
+                          cluster_scores=torch.from_numpy(scores), mask_scores=None, cluster_type=None, clusters_csr=csr)
+    labels, counts = instance_labels_per_tile(res, torch.from_numpy(batch), 3)
+    want = opipe.instance_labels({"clusters": clusters, "cluster_scores": scores}, n, batch)
+    assert np.array_equal(labels.numpy(), want)
+    assert sum(counts) == sum(len(np.unique(want[batch == t][want[batch == t] >= 0])) for t in range(3))
+
+
+def test_get_instances_matches_reference_golden():
+    """PanopticResults.get_instances vs the reference's own implementation (tests/golden/nms_cases.npz);
+    the CPU-only parts: NMS order and the size / score filters via the sparse overlap pairs."""
+    from panopticsegforlargescalepointcloud_amd import ops
+    from panopticsegforlargescalepointcloud_amd.panoptic.structures import non_max_suppression
+    from panopticsegforlargescalepointcloud_amd.scene import overlapping_pairs
+    z = np.load(os.path.join(ROOT, "tests", "golden", "nms_cases.npz"))
+    offs = z["cluster_offsets"]
+    clusters = [z["cluster_points"][offs[i]: offs[i + 1]] for i in range(len(offs) - 1)]
+    csr = ops.ClusterCSR.from_list([torch.from_numpy(c) for c in clusters], "cpu")
+    a, b, inter, _ = overlapping_pairs(csr, max_sources=31)
+    P = len(clusters)
+    m = np.zeros((P, P), np.float32)
+    m[a.numpy(), b.numpy()] = inter.numpy()
+    m = m + m.T + np.diag([len(c) for c in clusters])
+    sz = np.diag(m).copy()
+    ious = m / (sz[:, None] + sz[None, :] - m)
+    for tag, (thr, mn, ms) in {"default": (0.3, 100, 0.5), "tracker": (0.3, 10, 0.5), "loose": (0.6, 0, 0.0)}.items():
+        pick = non_max_suppression(ious, z["scores"], thr)
+        ids = [i for i in pick if sz[i] > mn and z["scores"][i] > ms]
+        assert ids == z["ids_" + tag].tolist()
+        assert [int(sz[i]) for i in ids] == z["sizes_" + tag].tolist()
+
+
+def test_block_merging_rules():
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler
+    asm = SceneAssembler(20, 3)
+    # block 0: instances {0: pts 0-4, 1: pts 5-7}
+    asm.add_block(np.arange(10), np.array([0, 0, 0, 0, 0, 1, 1, 1, -1, -1]))
+    assert asm.max_instance == 2 and asm.ins_pre[:8].tolist() == [0] * 5 + [1] * 3
+    # block 1 overlaps pts 3-12: its instance 0 = pts 3-9 (IoU with old 0: 2/10 > 0.1 -> merge), instance 1 = pts 10-12 (new)
+    asm.add_block(np.arange(3, 13), np.array([0, 0, 0, 0, 0, 0, 0, 1, 1, 1]))
+    assert asm.ins_pre[5:8].tolist() == [1, 1, 1]  # already labelled points keep their label
+    assert asm.ins_pre[8:10].tolist() in ([0, 0], [1, 1])  # merged into the best-IoU old instance
+    assert asm.ins_pre[10:13].tolist() == [3, 3, 3] and asm.max_instance == 3  # reference allocates max_instance + 1
+    assert asm.prediction_count[3:10].tolist() == [2] * 7
+    # a fully labelled block changes nothing
+    before = asm.ins_pre.copy()
+    asm.add_block(np.arange(0, 8), np.array([0, 0, 1, 1, 2, 2, 3, 3]))
+    assert np.array_equal(before, asm.ins_pre)
