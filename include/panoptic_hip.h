@@ -165,7 +165,8 @@ int pp_head_mlp(const float* x, int64_t n, int32_t cin, const float* w1, int32_t
  * Clusters ordered by (class ascending, seed index ascending); points ascending inside a cluster.
  * counts[0] = #clusters, counts[1] = #points in clusters.  num_classes > max(labels).
  * ---------------------------------------------------------------------------------------------- */
-size_t pp_region_grow_workspace(int64_t n, int32_t nsample);
+size_t pp_region_grow_workspace(int64_t n, int32_t nsample);                    /* safe for any input */
+size_t pp_region_grow_workspace_for(int64_t n, int64_t n_selected, int32_t nsample); /* when #non-ignored points is known */
 int pp_region_grow(const float* pos /*[n,3]*/, const int64_t* labels, const int64_t* batch, int64_t n,
                    const int64_t* ignore_labels, int32_t n_ignore, int32_t num_classes, int32_t nsample,
                    float radius, int32_t min_cluster_size, int32_t* point_cluster /*[n]*/,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "pp_region_grow_workspace": (sz, [i64, i32]),
+    "pp_region_grow_workspace_for": (sz, [i64, i64, i32]),
     "pp_region_grow": (C.c_int, [vp, vp, vp, i64, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "pp_meanshift_workspace": (sz, [i64, i32, i32]),
     "pp_meanshift": (C.c_int, [vp, i64, i32, vp, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]),

@@ -342,18 +342,21 @@ extern "C" int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n
 // ---------------------------------------------------------------------------------------------
 // region grow driver
 // ---------------------------------------------------------------------------------------------
-extern "C" size_t pp_region_grow_workspace(int64_t n, int32_t nsample) {
+// n = all points, m = points that are not ignored (the neighbour lists, the big part, scale with m only)
+extern "C" size_t pp_region_grow_workspace_for(int64_t n, int64_t m_sel, int32_t nsample) {
   size_t m = (size_t)std::max<int64_t>(n, 1);
-  size_t cap = (size_t)pp_hash_capacity((int64_t)m);
+  size_t ms = (size_t)std::max<int64_t>(std::min<int64_t>(m_sel, n), 1);
+  size_t cap = (size_t)pp_hash_capacity((int64_t)ms);
   size_t b = 0;
   b += 16 * pp_align(m * 4);            // flag, rank, sel, bc, slot_of, sorted_slot, local, sorted_local, sbc, deg, L, size, keys32 x2, roots x2
   b += pp_align(m * 8);                 // sel64
   b += pp_align(m * 16);                // spos
   b += pp_align(cap * 8) + 2 * pp_align(cap * 4);  // cell hash
-  b += pp_align(m * (size_t)nsample * 4);          // neighbour lists
+  b += pp_align(ms * (size_t)nsample * 4);         // neighbour lists
   b += pp_sort_pairs_workspace(n) + pp_scan_workspace(n) + pp_group_by_key_workspace(n) + 8192;
   return b;
 }
+extern "C" size_t pp_region_grow_workspace(int64_t n, int32_t nsample) { return pp_region_grow_workspace_for(n, n, nsample); }
 
 extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int64_t* batch, int64_t n,
                               const int64_t* ignore_labels, int32_t n_ignore, int32_t num_classes, int32_t nsample,
@@ -363,7 +366,7 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   PP_REQUIRE(point_cluster && cluster_offsets && cluster_points && counts, "pp_region_grow: null output");
   PP_REQUIRE(nsample >= 1 && radius > 0.f && num_classes >= 1 && num_classes <= 256, "pp_region_grow: bad parameters");
   PP_REQUIRE(n < (1ll << 31), "pp_region_grow: n too large");
-  if (workspace_bytes < pp_region_grow_workspace(n, nsample)) return PP_ERR_WORKSPACE;
+  if (workspace_bytes < pp_region_grow_workspace_for(n, 0, nsample)) return PP_ERR_WORKSPACE;
   hipStream_t s = pp_s(stream);
   PP_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
   PP_HIP(hipMemsetAsync(cluster_offsets, 0, sizeof(int32_t), s));
@@ -406,6 +409,10 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   }
   const int64_t M = h[0];
   if (M == 0) return PP_OK;
+  if (workspace_bytes < pp_region_grow_workspace_for(n, M, nsample)) {
+    pp_set_error("pp_region_grow: workspace too small for %lld selected points (see pp_region_grow_workspace_for)", (long long)M);
+    return PP_ERR_WORKSPACE;
+  }
   const int64_t cap = pp_hash_capacity(M);
   uint64_t* ckeys = ar.take<uint64_t>((size_t)cap);
   int32_t* cell_start = ar.take<int32_t>((size_t)cap);

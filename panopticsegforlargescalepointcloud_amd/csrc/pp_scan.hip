@@ -40,7 +40,7 @@ extern "C" int pp_triad(float* a, const float* b, const float* c, float s, int64
 // ---------------------------------------------------------------------------------------------
 size_t pp_scan_workspace(int64_t n) {
   size_t bytes = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
   return pp_align(bytes) + 256;
 }
 
@@ -64,9 +64,9 @@ int pp_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* t
 size_t pp_sort_pairs_workspace(int64_t n) {
   size_t b64 = 0, b32 = 0;
   int nn = (int)std::max<int64_t>(n, 1);
-  hipcub::DeviceRadixSort::SortPairs(nullptr, b64, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b64, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
                                      (int32_t*)nullptr, nn, 0, 64);
-  hipcub::DeviceRadixSort::SortPairs(nullptr, b32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
                                      (int32_t*)nullptr, nn, 0, 32);
   return pp_align(std::max(b64, b32)) + 256;
 }

@@ -18,6 +18,8 @@
 //   scatter        D rows go to the LDS accumulator rows named by the rulebook (plain read-add-write: within a tile
 //                  every output row appears once, and the LDS block belongs to this wave alone)
 //   epilogue       folded BN / ReLU / residual, float4 coalesced stores (same contract as pp_spconv_fwd)
+#include <stdlib.h>
+
 #include "pp_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -329,7 +331,8 @@ extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, 
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.rb_off = rb_off; a.rb_in = rb_in; a.rb_out = rb_out;
   a.scale = scale; a.shift = shift; a.residual = residual; a.out = out; a.n_out = n_out;
   a.nblk = pp_rulebook_blocks(n_out); a.c0 = c0; a.c1 = c1; a.cout = cout; a.NT = (cout + 15) / 16; a.relu = relu;
-  const int ntw = a.NT >= 2 ? 2 : 1;
+  static const int force_ntw = getenv("PP_RB_NTW") ? atoi(getenv("PP_RB_NTW")) : 0;  // tuning knob (A/B runs)
+  const int ntw = force_ntw == 1 ? 1 : (a.NT >= 2 ? 2 : 1);
   const int groups = (a.NT + ntw - 1) / ntw;
   dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)groups);
   hipStream_t s = pp_s(stream);

@@ -60,8 +60,20 @@ def _need(t, dtype, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+_WS_CACHE = {}
+
+
+def _ws(nbytes, device, tag=None):
+    """Scratch buffer.  Large tagged workspaces are kept (grow-only) per device: re-allocating multi-GB blocks every call
+    makes the caching allocator split / re-hipMalloc them (measured: +270 ms per region_grow call)."""
+    nbytes = max(int(nbytes), 256)
+    if tag is None or nbytes < (64 << 20):
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (tag, str(device))
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _WS_CACHE[key] = buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+    return buf
 
 
 def version():
@@ -352,8 +364,10 @@ def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_clus
     offs = torch.empty(n + 2, dtype=torch.int32, device=dev)
     pts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
-    wsb = lib.pp_region_grow_workspace(n, int(nsample))
-    ws = _ws(wsb, dev)
+    # the neighbour lists dominate the workspace and scale with the number of non-ignored points: count them first
+    n_sel = int((~torch.isin(labels, ign)).sum().item()) if n else 0
+    wsb = lib.pp_region_grow_workspace_for(n, n_sel, int(nsample))
+    ws = _ws(wsb, dev, tag="region_grow")
     _lib.check(lib.pp_region_grow(_ptr(pos), _ptr(labels), _ptr(batch), n, _ptr(ign), ign.numel(), int(num_classes),
                                   int(nsample), float(radius), int(min_cluster_size), _ptr(pc), _ptr(offs), _ptr(pts),
                                   _ptr(counts), _ptr(ws), wsb, _stream()), "pp_region_grow")
@@ -374,7 +388,7 @@ def meanshift(x, sample_offsets, bandwidth, min_points_exclusive=3, max_iter=300
     ncl = torch.zeros(max(ns, 1), dtype=torch.int32, device=dev)
     centers = torch.zeros((max(m, 1), dim), dtype=torch.float32, device=dev) if want_centers else None
     wsb = lib.pp_meanshift_workspace(m, dim, ns)
-    ws = _ws(wsb, dev)
+    ws = _ws(wsb, dev, tag="meanshift")
     _lib.check(lib.pp_meanshift(_ptr(x), m, dim, C.cast(so_arr, C.c_void_p), ns, float(bandwidth),
                                 int(min_points_exclusive), int(max_iter), _ptr(labels), _ptr(ncl), _ptr(centers), _ptr(ws),
                                 wsb, _stream()), "pp_meanshift")
