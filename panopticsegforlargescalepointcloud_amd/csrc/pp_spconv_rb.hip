@@ -318,6 +318,176 @@ static int rb_launch(const RbArgs& a, dim3 grid, hipStream_t s) {
   return PP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: counted-vmcnt DMA ring.  One wave = one 64-row block x ONE 16-channel output tile.  A "unit" is CH channel
+// steps of one 16-pair tile: its CH A-tiles AND its CH B-fragments arrive by global_load_lds (2*CH DMAs, always --
+// short chunks re-issue a valid address so the count is constant).  Units are issued NBUF-1 ahead into an LDS ring and
+// retired with s_waitcnt vmcnt((NBUF-1)*2*CH): no other vector-memory instruction exists in the loop (the rulebook
+// entries come through scalar loads), so hipcc never inserts a draining vmcnt(0) (guide: "mixing load kinds").
+// ---------------------------------------------------------------------------------------------
+template <int CH, int NBUF>
+__global__ __launch_bounds__(256) void k_spconv_rb3(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                    const float* __restrict__ wp, const int32_t* __restrict__ rb_off,
+                                                    const int32_t* __restrict__ rb_in, const int32_t* __restrict__ rb_out,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ residual, float* __restrict__ out,
+                                                    int64_t n_out, int64_t nblk, int c0, int c1, int cout, int NT, int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LD = 20;                              // 16 columns + 4 pad
+  constexpr int ACC_FLOATS = (RB_ROWS + 1) * LD;      // + dummy row for padding pairs
+  constexpr int SLOT_FLOATS = 2 * CH * 256;           // CH A tiles then CH B fragments, 1 KiB each
+  constexpr int WAVE_FLOATS = ACC_FLOATS + NBUF * SLOT_FLOATS;
+  constexpr int D = NBUF - 1;                         // units in flight ahead of the one being computed
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t bid = (int64_t)rb_xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  if (bid >= nblk) return;
+  float* acc_lds = (float*)smem + (size_t)wave * WAVE_FLOATS;
+  float* ring = acc_lds + ACC_FLOATS;
+  const int jt = blockIdx.y;
+  const int cin = c0 + c1;
+  const int S0 = c0 >> 4, S = cin >> 4;
+  const int NCH = (S + CH - 1) / CH;                  // chunks (units) per tile
+
+  for (int t = lane; t < ACC_FLOATS / 4; t += 64) ((f32x4*)acc_lds)[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int32_t* off = rb_off + bid * (RB_K + 1);
+  const int blk_beg = __builtin_amdgcn_readfirstlane(off[0]);
+  const int blk_end = __builtin_amdgcn_readfirstlane(off[RB_K]);
+  const int ntiles = (blk_end - blk_beg) >> 4;
+  const int U = ntiles * NCH;
+  const int dma_row = lane >> 2, dma_q = lane & 3;
+
+  // issue cursor (tile, chunk, offset k) and compute cursor
+  int it = 0, ic = 0, ik = 0, ikend = __builtin_amdgcn_readfirstlane(off[1]);
+  int ct = 0, cc = 0, ck = 0, ckend = ikend;
+  int row_dma = 0;
+
+  auto issue = [&](int slot) {
+    if (ic == 0) {  // new tile: its 16 input rows (scalar loads), pick this lane's row
+      const int pos = blk_beg + it * 16;
+      while (pos >= ikend) {
+        ++ik;
+        ikend = __builtin_amdgcn_readfirstlane(off[ik + 1]);
+      }
+      const int32_t* pin = rb_in + pos;
+      int r = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int v = __builtin_amdgcn_readfirstlane(pin[j]);
+        r = (dma_row == j) ? v : r;
+      }
+      row_dma = r;
+    }
+    float* sl = ring + slot * SLOT_FLOATS;
+    const float* wk = wp + ((int64_t)ik * S * NT + jt) * 256 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      int sg = ic * CH + c;
+      sg = sg < S ? sg : S - 1;  // short last chunk: re-issue a valid step (keeps the DMA count per unit constant)
+      const float* g = sg < S0 ? in0 + (int64_t)row_dma * c0 + sg * 16 + dma_q * 4
+                               : in1 + (int64_t)row_dma * c1 + (sg - S0) * 16 + dma_q * 4;
+      __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(sl + c * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(wk + (int64_t)sg * NT * 256), (lds_void*)(sl + (CH + c) * 256), 16, 0, 0);
+    }
+    if (++ic == NCH) {
+      ic = 0;
+      ++it;
+    }
+  };
+
+  int issued = 0;
+  for (; issued < D && issued < U; ++issued) issue(issued % NBUF);
+
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < U; ++u) {
+    if (issued < U) {
+      issue(issued % NBUF);
+      ++issued;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * 2 * CH) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail: fewer than D units behind us
+    }
+    const float* sl = ring + (u % NBUF) * SLOT_FLOATS;
+    const int nch = (S - cc * CH) < CH ? (S - cc * CH) : CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (c < nch) {
+        const f32x4 A = *(const f32x4*)(sl + c * 256 + i * 16 + q * 4);
+        const f32x4 B = *(const f32x4*)(sl + (CH + c) * 256 + lane * 4);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt], B[tt], acc, 0, 0, 0);
+      }
+    }
+    asm volatile("" ::: "memory");
+    if (++cc == NCH) {  // tile complete: scatter its 16 x 16 result into the LDS accumulator rows
+      const int32_t* pout = rb_out + blk_beg + ct * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int lo = 0;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int v = __builtin_amdgcn_readfirstlane(pout[4 * qq + r]);
+          lo = (q == qq) ? v : lo;
+        }
+        lo = lo < 0 ? RB_ROWS : lo;
+        acc_lds[lo * LD + i] += acc[r];
+      }
+      acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      cc = 0;
+      ++ct;
+    }
+  }
+  (void)ck; (void)ckend;
+
+  // epilogue: 64 rows x 16 columns, float4 per lane
+  const int64_t row_base = bid * RB_ROWS;
+  for (int c = lane; c < RB_ROWS * 4; c += 64) {
+    const int row = c >> 2, cq = c & 3;
+    const int64_t grow = row_base + row;
+    const int col = jt * 16 + cq * 4;
+    if (grow < n_out && col < cout) {
+      f32x4 v = *(const f32x4*)(acc_lds + row * LD + cq * 4);
+      float e[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        if (col + uu < cout) {
+          float x = e[uu];
+          if (scale) x *= scale[col + uu];
+          if (shift) x += shift[col + uu];
+          if (relu) x = fmaxf(x, 0.f);
+          e[uu] = x;
+        }
+      }
+      if (col + 3 < cout) {
+        if (residual) {
+          f32x4 rr = *(const f32x4*)(residual + grow * cout + col);
+          e[0] += rr[0]; e[1] += rr[1]; e[2] += rr[2]; e[3] += rr[3];
+        }
+        *(f32x4*)(out + grow * cout + col) = (f32x4){e[0], e[1], e[2], e[3]};
+      } else {
+        for (int uu = 0; uu < 4 && col + uu < cout; ++uu)
+          out[grow * cout + col + uu] = e[uu] + (residual ? residual[grow * cout + col + uu] : 0.f);
+      }
+    }
+  }
+}
+
+template <int CH, int NBUF>
+static int rb3_launch(const RbArgs& a, hipStream_t s) {
+  constexpr size_t lds = 4 * ((RB_ROWS + 1) * 20 + NBUF * 2 * CH * 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    PP_HIP(hipFuncSetAttribute((const void*)k_spconv_rb3<CH, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)a.NT);
+  hipLaunchKernelGGL((k_spconv_rb3<CH, NBUF>), grid, dim3(256), lds, s, a.in0, a.in1, a.wp, a.rb_off, a.rb_in, a.rb_out,
+                     a.scale, a.shift, a.residual, a.out, a.n_out, a.nblk, a.c0, a.c1, a.cout, a.NT, a.relu);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
                                 const int32_t* rb_off, const int32_t* rb_in, const int32_t* rb_out, int64_t n_out,
                                 int32_t cout, const float* scale, const float* shift, int32_t relu,
@@ -331,7 +501,14 @@ extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, 
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.rb_off = rb_off; a.rb_in = rb_in; a.rb_out = rb_out;
   a.scale = scale; a.shift = shift; a.residual = residual; a.out = out; a.n_out = n_out;
   a.nblk = pp_rulebook_blocks(n_out); a.c0 = c0; a.c1 = c1; a.cout = cout; a.NT = (cout + 15) / 16; a.relu = relu;
-  static const int force_ntw = getenv("PP_RB_NTW") ? atoi(getenv("PP_RB_NTW")) : 0;  // tuning knob (A/B runs)
+  static const int rb_ver = getenv("PP_RB_VER") ? atoi(getenv("PP_RB_VER")) : 3;  // tuning knobs (A/B runs)
+  if (rb_ver == 3) {
+    const int S3 = (c0 + c1) / 16;
+    hipStream_t s3 = pp_s(stream);
+    if (S3 == 1) return rb3_launch<1, 6>(a, s3);
+    return rb3_launch<2, 4>(a, s3);
+  }
+  static const int force_ntw = getenv("PP_RB_NTW") ? atoi(getenv("PP_RB_NTW")) : 0;
   const int ntw = force_ntw == 1 ? 1 : (a.NT >= 2 ? 2 : 1);
   const int groups = (a.NT + ntw - 1) / ntw;
   dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)groups);
