@@ -25,19 +25,22 @@ from . import utils  # noqa: F401
 
 # 3x3x3 convolutions with Cin % 16 == 0 run on the block-compacted rulebook kernel (csrc/pp_spconv_rb.hip);
 # PP_CONV=dense forces the dense-offset kernel (csrc/pp_spconv.hip) for A/B measurements.
-#   auto : rulebook for transposed stride-2 convolutions (each fine voxel has only ~3 coarse neighbours, the dense
-#          loop would be ~8x zero work) and for Cin >= 112; dense-offset kernel otherwise (measured per layer,
-#          profiles/r01_c_dense_vs_rulebook.md)
+#   auto : per layer, from the measured map density P / (27 N_out) (profiles/r01_conv_microbench.md):
+#          rulebook for transposed stride-2 convolutions (2-3 pairs per fine row: the dense loop is ~8x zero work) and
+#          for sparse same-level maps (density < 0.27, i.e. < 7.3 pairs per row) with Cin >= 32; dense-offset otherwise.
 CONV_MODE = os.environ.get("PP_CONV", "auto")
 USE_RULEBOOK = CONV_MODE != "dense"
+RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.27"))
 
 
-def _want_rulebook(conv, x, ts_out, cin):
+def _want_rulebook(conv, x, ts_out, cin, sign):
     if CONV_MODE == "rb":
         return True
     if CONV_MODE == "dense":
         return False
-    return (conv.TRANSPOSED and ts_out != x.tensor_stride) or cin >= 112
+    if conv.TRANSPOSED and ts_out != x.tensor_stride:
+        return True
+    return cin >= 32 and x.coordinate_manager.map_density(x.tensor_stride, ts_out, conv.kernel_size, sign) < RB_DENSITY
 
 
 # ------------------------------------------------------------------------------------------------
@@ -82,6 +85,7 @@ class CoordinateManager:
         self.levels = {1: _Level(coords, table)}
         self.maps = {}
         self.rulebooks = {}
+        self.densities = {}
 
     def rulebook(self, ts_from, ts_to, ksize, sign):
         key = (ts_from, ts_to, ksize, sign)
@@ -90,6 +94,16 @@ class CoordinateManager:
             rb = ops.rulebook_build(self.kernel_map(ts_from, ts_to, ksize, sign))
             self.rulebooks[key] = rb
         return rb
+
+    def map_density(self, ts_from, ts_to, ksize, sign):
+        """fraction of occupied entries of a kernel map (pairs / (K * n_out)); one reduction per map, cached."""
+        key = (ts_from, ts_to, ksize, sign)
+        d = self.densities.get(key)
+        if d is None:
+            m = self.kernel_map(ts_from, ts_to, ksize, sign)
+            d = float((m >= 0).sum().item()) / max(m.numel(), 1)
+            self.densities[key] = d
+        return d
 
     def level(self, ts):
         return self.levels[ts]
@@ -486,7 +500,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
     c0 = x.feats.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
     if (nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0
-            and _want_rulebook(conv, x, ts_out, c0 + c1)):
+            and _want_rulebook(conv, x, ts_out, c0 + c1, -1 if conv.TRANSPOSED else 1)):
         sign = -1 if conv.TRANSPOSED else 1
         rb = cm.rulebook(x.tensor_stride, ts_out, conv.kernel_size, sign)
         feats = ops.spconv_fwd_rb(x.feats, conv.packed(), rb, conv.out_channels, in1=in1, scale=scale, shift=shift,

@@ -501,14 +501,17 @@ extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, 
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.rb_off = rb_off; a.rb_in = rb_in; a.rb_out = rb_out;
   a.scale = scale; a.shift = shift; a.residual = residual; a.out = out; a.n_out = n_out;
   a.nblk = pp_rulebook_blocks(n_out); a.c0 = c0; a.c1 = c1; a.cout = cout; a.NT = (cout + 15) / 16; a.relu = relu;
-  static const int rb_ver = getenv("PP_RB_VER") ? atoi(getenv("PP_RB_VER")) : 3;  // tuning knobs (A/B runs)
+  static const int rb_ver = getenv("PP_RB_VER") ? atoi(getenv("PP_RB_VER")) : 2;  // tuning knobs (A/B runs)
   if (rb_ver == 3) {
     const int S3 = (c0 + c1) / 16;
     hipStream_t s3 = pp_s(stream);
     if (S3 == 1) return rb3_launch<1, 6>(a, s3);
     return rb3_launch<2, 4>(a, s3);
   }
-  static const int force_ntw = getenv("PP_RB_NTW") ? atoi(getenv("PP_RB_NTW")) : 0;
+  // one 16-channel output tile per wave by default: 9 KiB of LDS per wave -> 16 waves per CU; measured 20-70 %
+  // faster than two tiles per wave (8-12 waves per CU) even though A tiles are gathered once per column tile
+  static const int force_ntw = getenv("PP_RB_NTW") ? atoi(getenv("PP_RB_NTW")) : 1;
+  static const int small_stage = getenv("PP_RB_SMALL") ? atoi(getenv("PP_RB_SMALL")) : 0;
   const int ntw = force_ntw == 1 ? 1 : (a.NT >= 2 ? 2 : 1);
   const int groups = (a.NT + ntw - 1) / ntw;
   dim3 grid((unsigned)((a.nblk + 3) / 4), (unsigned)groups);
@@ -519,7 +522,11 @@ extern "C" int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, 
     if (S == 2) return rb_launch<2, 2, 2>(a, grid, s);
     return rb_launch<2, 1, 4>(a, grid, s);
   }
-  if (S == 1) return rb_launch<1, 4, 1>(a, grid, s);
+  if (small_stage) {
+    if (S == 1) return rb_launch<1, 2, 1>(a, grid, s);
+    return rb_launch<1, 1, 2>(a, grid, s);
+  }
+  if (S == 1) return rb_launch<1, 2, 1>(a, grid, s);  // Cin = 16: 2 KiB staging, 20 waves per CU
   if (S == 2) return rb_launch<1, 2, 2>(a, grid, s);
   return rb_launch<1, 1, 4>(a, grid, s);
 }
