@@ -76,9 +76,10 @@ int pp_stride_coords(const int32_t* coords, int64_t n, int32_t ts_out, uint64_t*
  * sign=+1: convolution (stride 1: step = tensor stride; stride 2: step = input tensor stride).
  * sign=-1: transposed convolution (mirrored offsets; with a coarse input map this is ME's swapped map).
  * ksize in {1,3}; ksize==1 ignores step/sign (pure coordinate lookup).
+ * n_pairs (device int64[1], may be NULL) receives the number of (in, out) pairs P of the map.
  * ---------------------------------------------------------------------------------------------- */
 int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys, const int32_t* vals,
-                  int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr,
+                  int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, int64_t* n_pairs,
                   pp_stream_t stream);
 
 /* Derived maps (no hash probes).  pp_kernel_map_transpose: out_map[k][in_map[k][o]] = o, i.e. the map of the

@@ -101,7 +101,7 @@ class CoordinateManager:
         d = self.densities.get(key)
         if d is None:
             m = self.kernel_map(ts_from, ts_to, ksize, sign)
-            d = float((m >= 0).sum().item()) / max(m.numel(), 1)
+            d = float(ops._pairs_of(m).item()) / max(m.numel(), 1)
             self.densities[key] = d
         return d
 
@@ -135,6 +135,8 @@ class CoordinateManager:
             rev = self.maps.get((ts_to, ts_from, ksize, -sign))
             if rev is not None and ts_from == ts_to:
                 m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
+                if hasattr(rev, "pp_pairs"):
+                    m.pp_pairs = rev.pp_pairs
             elif rev is not None:
                 m = ops.kernel_map_transpose(rev, self.levels[ts_to].n)
             else:

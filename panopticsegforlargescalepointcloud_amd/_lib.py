@@ -27,7 +27,7 @@ SIGNATURES = {
     "pp_hash_build": (C.c_int, [vp, i64, vp, vp, i64, vp, vp]),
     "pp_stride_coords_workspace": (sz, [i64]),
     "pp_stride_coords": (C.c_int, [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, sz, vp, vp]),
-    "pp_kernel_map": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp]),
+    "pp_kernel_map": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
     "pp_kernel_map_transpose": (C.c_int, [vp, i64, i32, i64, vp, vp]),
     "pp_morton_order_workspace": (sz, [i64]),
     "pp_morton_order": (C.c_int, [vp, i64, vp, vp, sz, vp, vp]),

@@ -155,9 +155,10 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_kernel_map(const int4* __restrict__ out_coords, int64_t n_out,
                                                     const uint64_t* __restrict__ keys,
                                                     const int32_t* __restrict__ vals, int64_t cap, int step,
-                                                    int32_t* __restrict__ nbr) {
+                                                    int32_t* __restrict__ nbr, unsigned long long* n_pairs) {
   int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
+  int found = 0;
+  if (o < n_out) {
   int4 c = out_coords[o];
   constexpr int K = KS * KS * KS;
 #pragma unroll
@@ -174,24 +175,31 @@ __global__ __launch_bounds__(256) void k_kernel_map(const int4* __restrict__ out
       int64_t s = pp_hash_find_slot(keys, cap, pp_key_pack(c.x, x, y, z));
       if (s >= 0) r = vals[s];
     }
+    found += r >= 0 ? 1 : 0;
     nbr[(int64_t)k * n_out + o] = r;
+  }
+  }
+  if (n_pairs) {  // number of (in, out) pairs of the map: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(n_pairs, (unsigned long long)found);
   }
 }
 
 extern "C" int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys, const int32_t* vals,
                              int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr,
-                             pp_stream_t stream) {
+                             int64_t* n_pairs, pp_stream_t stream) {
   PP_REQUIRE(ksize == 1 || ksize == 3, "pp_kernel_map: ksize must be 1 or 3");
   PP_REQUIRE(sign == 1 || sign == -1, "pp_kernel_map: sign must be +1 or -1");
-  if (n_out == 0) return PP_OK;
   hipStream_t s = pp_s(stream);
+  if (n_pairs) PP_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int64_t), s));
+  if (n_out == 0) return PP_OK;
   unsigned nb = pp_blocks(n_out, 256);
   if (ksize == 3)
     hipLaunchKernelGGL(k_kernel_map<3>, dim3(nb), dim3(256), 0, s, (const int4*)out_coords, n_out, keys, vals, cap,
-                       sign * step, nbr);
+                       sign * step, nbr, (unsigned long long*)n_pairs);
   else
     hipLaunchKernelGGL(k_kernel_map<1>, dim3(nb), dim3(256), 0, s, (const int4*)out_coords, n_out, keys, vals, cap, 0,
-                       nbr);
+                       nbr, (unsigned long long*)n_pairs);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

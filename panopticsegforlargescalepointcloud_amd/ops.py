@@ -21,16 +21,9 @@ class LaunchProfiler:
 
     def summarize(self):
         torch.cuda.synchronize()
-        pairs = {}
         tot_ms = tot_bytes = tot_flops = 0.0
-        for (e0, e1, n_in, n_out, cin, cout, K, nbr, has_res) in self.records:
-            if nbr is None:
-                P = n_out
-            else:
-                key = nbr.data_ptr()
-                if key not in pairs:
-                    pairs[key] = int((nbr >= 0).sum().item())
-                P = pairs[key]
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res) in self.records:
+            P = n_out if pairs is None else int(pairs.item())
             # features read once + written once, weights once, one (in,out) int32 pair per map entry
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
             tot_bytes += b
@@ -40,6 +33,14 @@ class LaunchProfiler:
 
 
 PROFILER = None
+
+
+def _pairs_of(nbr):
+    """device scalar holding the number of pairs of a kernel map (None = identity map); never keeps the map alive"""
+    if nbr is None:
+        return None
+    p = getattr(nbr, "pp_pairs", None)
+    return p if p is not None else (nbr >= 0).sum()
 
 
 def _stream():
@@ -139,8 +140,10 @@ def kernel_map(out_coords, table, ksize, step, sign):
     n_out = out_coords.shape[0]
     K = ksize ** 3
     nbr = torch.empty((K, n_out), dtype=torch.int32, device=out_coords.device)
+    pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
     _lib.check(lib.pp_kernel_map(_ptr(out_coords), n_out, _ptr(table.keys), _ptr(table.vals), table.cap, ksize, int(step),
-                                 int(sign), _ptr(nbr), _stream()), "pp_kernel_map")
+                                 int(sign), _ptr(nbr), _ptr(pairs), _stream()), "pp_kernel_map")
+    nbr.pp_pairs = pairs  # device scalar: number of (in, out) pairs (flops / density bookkeeping, no sync here)
     return nbr
 
 
@@ -150,6 +153,8 @@ def kernel_map_transpose(nbr, n_in):
     K, n_out = nbr.shape
     out = torch.empty((K, n_in), dtype=torch.int32, device=nbr.device)
     _lib.check(lib.pp_kernel_map_transpose(_ptr(nbr), n_out, K, int(n_in), _ptr(out), _stream()), "pp_kernel_map_transpose")
+    if hasattr(nbr, "pp_pairs"):
+        out.pp_pairs = nbr.pp_pairs  # same pairs, roles swapped
     return out
 
 
@@ -202,15 +207,15 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
                                  _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()
-        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, nbr, residual is not None))
+        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None))
     return out
 
 
 class Rulebook:
     """Block-compacted form of a 27-offset kernel map (see csrc/pp_spconv_rb.hip)."""
 
-    def __init__(self, off, rb_in, rb_out, n_out, total, nbr):
-        self.off, self.rb_in, self.rb_out, self.n_out, self.total, self.nbr = off, rb_in, rb_out, n_out, total, nbr
+    def __init__(self, off, rb_in, rb_out, n_out, total, pairs):
+        self.off, self.rb_in, self.rb_out, self.n_out, self.total, self.pairs = off, rb_in, rb_out, n_out, total, pairs
 
 
 def rulebook_build(nbr):
@@ -229,7 +234,7 @@ def rulebook_build(nbr):
     rb_in = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
     rb_out = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
     _lib.check(lib.pp_rulebook_fill(_ptr(nbr), n_out, _ptr(off), _ptr(rb_in), _ptr(rb_out), _stream()), "pp_rulebook_fill")
-    return Rulebook(off, rb_in, rb_out, n_out, t, nbr)
+    return Rulebook(off, rb_in, rb_out, n_out, t, _pairs_of(nbr))
 
 
 def spconv_fwd_rb(in0, packed, rb, cout, in1=None, scale=None, shift=None, relu=False, residual=None):
@@ -253,7 +258,7 @@ def spconv_fwd_rb(in0, packed, rb, cout, in1=None, scale=None, shift=None, relu=
                                     _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd_rb")
     if prof is not None:
         e1.record()
-        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, 27, rb.nbr, residual is not None))
+        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, 27, rb.pairs, residual is not None))
     return out
 
 
