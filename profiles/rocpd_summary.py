@@ -28,7 +28,7 @@ def main(db, out=None):
     print(txt)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--pmc"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("--pmc", "--layers")):
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
 
 
@@ -49,3 +49,24 @@ def pmc(db, out=None, like="%"):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--pmc":
     pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+
+
+def layers(db, out=None, n=106):
+    """the last n convolution dispatches in launch order (one forward of backbone + scorer): --layers db out.md [n]"""
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, grid_x, grid_y, duration from kernels where name like '%spconv%' order by start").fetchall()[-n:]
+    lines = ["# convolution launches of one step, in order (%s)" % db.split("/")[-1], "", "| # | kernel | blocks x col groups | us |", "|---|---|---|---|"]
+    tot = 0
+    for i, (name, gx, gy, dur) in enumerate(rows):
+        tot += dur
+        lines.append("| %d | %s | %d x %d | %.1f |" % (i, name[5:32], gx // 256, gy, dur / 1e3))
+    lines.append("")
+    lines.append("total %.2f ms" % (tot / 1e6))
+    txt = "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--layers":
+    layers(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None, int(sys.argv[4]) if len(sys.argv) > 4 else 106)
