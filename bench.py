@@ -120,12 +120,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (== local_rank on a real multi-GPU node)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+        # "nccl" is RCCL on ROCm; PP_DIST_BACKEND=gloo only exists to exercise the N > 1 control flow on a 1-GPU box
+        dist.init_process_group(os.environ.get("PP_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from panopticsegforlargescalepointcloud_amd import ops, synthetic as syn
     from panopticsegforlargescalepointcloud_amd.scene import TileRunner, exchange_tile_results, shard_tiles

@@ -203,6 +203,9 @@ def exchange_tile_results(local, group=None):
         return dict(local)
     ids = sorted(local)
     dev = local[ids[0]][0].device if ids else torch.device("cpu")
+    if dist.get_backend(group) == "gloo":  # CPU collectives (tests / single-GPU dry runs)
+        local = {t: (local[t][0].cpu(), local[t][1].cpu()) for t in ids}
+        dev = torch.device("cpu")
     meta = torch.tensor([[t, local[t][0].shape[0]] for t in ids], dtype=torch.int64, device=dev).reshape(-1, 2)
     origin = torch.cat([local[t][0] for t in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
     labels = torch.cat([local[t][1].to(torch.int64) for t in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
