@@ -331,6 +331,16 @@ class ClusterCSR:
     def sizes(self):
         return (self.offsets[1: self.n + 1] - self.offsets[: self.n]).to(torch.int64)
 
+    def select(self, ids):
+        """CSR of the proposals `ids` (int64 tensor), in that order."""
+        dev = self.offsets.device
+        sz = self.sizes()[ids]
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sz, 0)])
+        starts = self.offsets[:-1].long()[ids]
+        rep = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), sz)
+        within = torch.arange(int(offs[-1].item()), device=dev) - offs[rep]
+        return ClusterCSR(offs.to(torch.int32), self.points[starts[rep] + within], int(ids.numel()))
+
     def to_list(self):
         if self.n == 0:
             return []
@@ -355,6 +365,41 @@ class ClusterCSR:
             offs.append(p.offsets[1: p.n + 1] + base)
             base += int(p.points.numel())
         return ClusterCSR(torch.cat(offs), torch.cat([p.points for p in parts]), sum(p.n for p in parts))
+
+
+def overlapping_pairs(csr, max_sources=64):
+    """Proposal pairs that share points, with their intersection sizes, from the point -> proposal incidence
+    (the sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  Returns int64 tensors (a, b, inter)
+    with a < b.  In the model a point belongs to one proposal per source (region growing on raw / shifted
+    coordinates, mean shift), so the multiplicity loop below runs 1-2 times; `max_sources` only bounds it."""
+    cached = getattr(csr, "_pairs", None)
+    if cached is not None:
+        return cached
+    dev = csr.points.device
+    P = csr.n
+    sizes = csr.sizes()
+    prop_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
+    order = torch.argsort(csr.points, stable=True)
+    sp, sq = csr.points[order], prop_of_entry[order]
+    mult = int(torch.unique_consecutive(sp, return_counts=True)[1].max().item()) if sp.numel() else 0
+    if mult > max_sources:
+        raise NotImplementedError("a point belongs to %d proposals (> %d)" % (mult, max_sources))
+    keys = []
+    for d in range(1, mult):
+        if sp.numel() <= d:
+            break
+        m = sp[d:] == sp[:-d]
+        x, y = sq[:-d][m], sq[d:][m]
+        keys.append(torch.minimum(x, y) * P + torch.maximum(x, y))
+    if not keys:
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        csr._pairs = (z, z, z, prop_of_entry)
+        return csr._pairs
+    uniq, inter = torch.unique(torch.cat(keys), return_counts=True)
+    csr._pairs = (uniq // P, uniq % P, inter, prop_of_entry)
+    return csr._pairs
+
+
 
 
 def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_cluster_size, num_classes):

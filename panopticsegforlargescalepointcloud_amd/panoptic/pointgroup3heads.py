@@ -50,6 +50,7 @@ class PointGroup3heads(nn.Module):
             self.MaskScore = (Seq().append(nn.Linear(self.ScorerUnet.output_nc, self.ScorerUnet.output_nc))
                               .append(nn.ReLU()).append(nn.Linear(self.ScorerUnet.output_nc, 1)))
         self.use_score_net = option.get("use_score_net", True)
+        self.dedupe_proposals = True  # eval-only optimisation with identical results, see _compute_score
         self.cal_iou_based_on_mask = option.get("cal_iou_based_on_mask", False)
         self.cal_iou_based_on_mask_start_epoch = option.get("cal_iou_based_on_mask_start_epoch", 200)
 
@@ -202,6 +203,24 @@ class PointGroup3heads(nn.Module):
                 return torch.max(torch.exp(mean_sem), 1)[0], None
         if self._scorer_type not in ("unet",):
             raise NotImplementedError("scorer_type %s (published settings use 'unet')" % self._scorer_type)
+        if self.dedupe_proposals and not torch.is_grad_enabled() and csr.n > 1:
+            # Region growing and mean shift often return the SAME point set for a well-separated instance; identical
+            # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set
+            # (results unchanged; the overlap pairs are reused by NMS).
+            a, b, inter, _ = ops.overlapping_pairs(csr)
+            sz = csr.sizes()
+            dup = (inter == sz[a]) & (inter == sz[b])
+            rep = torch.arange(csr.n, device=sz.device)
+            rep.scatter_reduce_(0, b[dup], a[dup], "amin", include_self=True)
+            uniq_ids = torch.nonzero(rep == torch.arange(csr.n, device=sz.device)).view(-1)
+            if uniq_ids.numel() < csr.n:
+                pos_of = torch.empty(csr.n, dtype=torch.int64, device=sz.device)
+                pos_of[uniq_ids] = torch.arange(uniq_ids.numel(), device=sz.device)
+                scores_u, _ = self._score_unique(csr.select(uniq_ids), backbone_features)
+                return scores_u[pos_of[rep]], None
+        return self._score_unique(csr, backbone_features)
+
+    def _score_unique(self, csr, backbone_features):
         sizes = csr.sizes()
         offsets = csr.offsets.long()
         scores = []

@@ -17,32 +17,7 @@ from .applications import Data
 
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
-def overlapping_pairs(csr, max_sources=64):
-    """Proposal pairs that share points, with their intersection sizes, from the point -> proposal incidence
-    (the sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  Returns int64 tensors (a, b, inter)
-    with a < b.  In the model a point belongs to one proposal per source (region growing on raw / shifted
-    coordinates, mean shift), so the multiplicity loop below runs 1-2 times; `max_sources` only bounds it."""
-    dev = csr.points.device
-    P = csr.n
-    sizes = csr.sizes()
-    prop_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
-    order = torch.argsort(csr.points, stable=True)
-    sp, sq = csr.points[order], prop_of_entry[order]
-    mult = int(torch.unique_consecutive(sp, return_counts=True)[1].max().item()) if sp.numel() else 0
-    if mult > max_sources:
-        raise NotImplementedError("a point belongs to %d proposals (> %d)" % (mult, max_sources))
-    keys = []
-    for d in range(1, mult):
-        if sp.numel() <= d:
-            break
-        m = sp[d:] == sp[:-d]
-        x, y = sq[:-d][m], sq[d:][m]
-        keys.append(torch.minimum(x, y) * P + torch.maximum(x, y))
-    if not keys:
-        z = torch.zeros(0, dtype=torch.int64, device=dev)
-        return z, z, z, prop_of_entry
-    uniq, inter = torch.unique(torch.cat(keys), return_counts=True)
-    return uniq // P, uniq % P, inter, prop_of_entry
+from .ops import overlapping_pairs  # noqa: E402,F401  (kept importable from here)
 
 
 def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
