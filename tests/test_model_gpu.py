@@ -150,11 +150,11 @@ def test_training_step_runs_and_matches_torch_autograd(setup):
 def test_full_model_training_step(setup):
     """optimize_parameters2 semantics (models/base_model.py:259-285): forward in train mode (batch-statistics BN through
     the HIP stats kernels), _compute_loss, backward through every sparse conv, Adam step; loss finite and decreasing."""
-    import copy
+    import bench
     from panopticsegforlargescalepointcloud_amd.applications import Data
     s = setup
     dev = torch.device("cuda")
-    model = copy.deepcopy(s["model"]).train()
+    model = bench.build_model(dev, 0.05)[0].train()
     scene, b = s["scene"], s["b"]
     oid = b["origin_id"]
     inst = scene.inst[oid]
