@@ -179,10 +179,10 @@ def test_panoptic_quality_metric():
     # perfect prediction
     r = thing_panoptic_quality(gt_sem, gt_ins - 1, gt_sem, gt_ins, [2, 3])
     assert abs(r["PQ"] - 1.0) < 1e-12
-    # instance 2 split in halves (IoU 0.5 -> one TP at IoU 0.5, one FP), instance 3 missed
-    pred = np.array([0] * 10 + [1] * 5 + [2] * 5 + [-1] * 10 + [-1] * 10)
+    # instance 2 split 6/4 (IoU 0.6 -> TP, IoU 0.4 -> FP), instance 3 missed
+    pred = np.array([0] * 10 + [1] * 6 + [2] * 4 + [-1] * 10 + [-1] * 10)
     r = thing_panoptic_quality(gt_sem, pred, gt_sem, gt_ins, [2, 3])
     c2 = r["per_class"][2]
     assert c2["n_pred"] == 3 and c2["n_gt"] == 2
-    assert abs(c2["precision"] - 2 / 3) < 1e-12 and abs(c2["recall"] - 1.0) < 1e-12 and abs(c2["SQ"] - 0.75) < 1e-12
-    assert r["per_class"][3]["PQ"] == 0.0 and abs(r["PQ"] - (0.75 * 0.8 + 0.0) / 2) < 1e-12
+    assert abs(c2["precision"] - 2 / 3) < 1e-12 and abs(c2["recall"] - 1.0) < 1e-12 and abs(c2["SQ"] - 0.8) < 1e-12
+    assert r["per_class"][3]["PQ"] == 0.0 and abs(r["PQ"] - (0.8 * 0.8 + 0.0) / 2) < 1e-12
