@@ -188,6 +188,19 @@ def meanshift(x, sample_offsets, bandwidth, min_points_exclusive=3, max_iter=300
     return labels[:m].copy(), ncl[:ns].copy(), centers
 
 
+def hdbscan(x, sample_offsets, min_cluster_size=15, min_samples=5, eps=0.006, count_self=True, min_points_exclusive=3):
+    x = _f32(x)
+    m, dim = x.shape
+    so = _i64(sample_offsets)
+    ns = so.shape[0] - 1
+    labels = np.empty(max(m, 1), np.int32)
+    ncl = np.zeros(max(ns, 1), np.int32)
+    _chk(lib().ppo_hdbscan(_p(x), C.c_int64(m), C.c_int32(dim), _p(so), C.c_int32(ns), C.c_int32(min_points_exclusive),
+                           C.c_int32(min_cluster_size), C.c_int32(min_samples), C.c_int32(1 if count_self else 0),
+                           C.c_double(eps), _p(labels), _p(ncl)), "hdbscan")
+    return labels[:m].copy(), ncl[:ns].copy()
+
+
 def group_by_key(key, n_groups, ids=None):
     key = _i32(key)
     n = key.shape[0]

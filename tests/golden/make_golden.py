@@ -176,7 +176,73 @@ def make_nms():
     print("nms:", {k: v.tolist() for k, v in out.items() if k.startswith("ids")})
 
 
+def _hdbscan_canonical_ties(x, min_cluster_size, min_samples, eps):
+    """sklearn's own single-linkage / condensed-tree / stability / EOM / epsilon / labelling code (its Cython
+    make_single_linkage + tree_to_labels) fed with THE minimum spanning tree of the mutual-reachability graph under the
+    strict edge order (weight, min(a,b), max(a,b)) instead of whatever Prim + an unstable argsort leave: removes the
+    implementation-defined handling of equal-weight edges, so the result is a function of the data alone."""
+    from sklearn.cluster._hdbscan._linkage import MST_edge_dtype, make_single_linkage
+    from sklearn.cluster._hdbscan._tree import tree_to_labels
+    xd = x.astype(np.float64)
+    n = len(xd)
+    d2 = np.zeros((n, n))
+    for c in range(xd.shape[1]):
+        t = xd[:, None, c] - xd[None, :, c]
+        d2 += t * t
+    core2 = np.sort(d2, axis=1)[:, min_samples - 1]            # the point itself counts (sklearn convention)
+    a, b = np.triu_indices(n, 1)
+    w2 = np.maximum(np.maximum(core2[a], core2[b]), d2[a, b])
+    order = np.lexsort((b, a, w2))
+    parent = list(range(n))
+
+    def find(v):
+        while parent[v] != v:
+            parent[v] = parent[parent[v]]
+            v = parent[v]
+        return v
+    mst = np.empty(n - 1, dtype=MST_edge_dtype)
+    k = 0
+    for e in order:
+        ra, rb = find(int(a[e])), find(int(b[e]))
+        if ra != rb:
+            parent[ra] = rb
+            mst[k] = (int(a[e]), int(b[e]), np.sqrt(w2[e]))
+            k += 1
+            if k == n - 1:
+                break
+    labels, _ = tree_to_labels(make_single_linkage(mst), min_cluster_size, "eom", False, eps)
+    return labels
+
+
+def make_hdbscan():
+    """hdbscan 0.8.27 (reference: torch_points3d/utils/hdbscan_cluster.py:8-13) is not installed here; sklearn's port of
+    the same algorithm (sklearn.cluster.HDBSCAN, core distance counts the point itself) produces the vectors."""
+    from sklearn.cluster import HDBSCAN
+    rng = np.random.default_rng(15)
+    cases, names = {}, []
+    for t in range(14):
+        n_inst = int(rng.integers(1, 8))
+        dim = int(rng.choice([3, 5]))
+        centers = rng.normal(0, 3, size=(n_inst, dim))
+        sizes = rng.integers(5, 160, size=n_inst)
+        x = np.concatenate([c + rng.normal(0, rng.uniform(0.05, 0.6), size=(s, dim)) for c, s in zip(centers, sizes)] +
+                           [rng.uniform(-6, 6, size=(int(rng.integers(0, 30)), dim))]).astype(np.float32)
+        eps = float([0.006, 0.006, 0.0, 0.3][t % 4])
+        lab = HDBSCAN(min_cluster_size=15, min_samples=5, cluster_selection_epsilon=eps, copy=True).fit_predict(
+            x.astype(np.float64))
+        name = "c%02d" % t
+        names.append(name)
+        cases["x_" + name], cases["eps_" + name], cases["labels_" + name] = x, np.float64(eps), lab.astype(np.int64)
+        cases["canon_" + name] = _hdbscan_canonical_ties(x, 15, 5, eps).astype(np.int64)
+    cases["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "hdbscan_cases.npz"), **cases)
+    print("hdbscan:", {k: int(cases["labels_" + k].max()) + 1 for k in names})
+
+
 if __name__ == "__main__":
+    make_hdbscan()
+    if "--hdbscan-only" in sys.argv:
+        sys.exit(0)
     make_meanshift()
     make_losses()
     make_nms()

@@ -267,6 +267,49 @@ def test_meanshift_skips_small_samples(oracle):
     assert np.all(labels[:3] == -1) and ncl[0] == 0 and ncl[1] >= 1 and np.all(labels[3:] >= 0)
 
 
+# ---------------------------------------------------------------- HDBSCAN vs sklearn's port (hdbscan package absent)
+def _aligned_mismatch(a, b):
+    from scipy.optimize import linear_sum_assignment
+    k = int(max(a.max(), b.max())) + 2
+    m = np.zeros((k, k), np.int64)
+    np.add.at(m, (a + 1, b + 1), 1)
+    r, c = linear_sum_assignment(-m)
+    return len(a) - int(m[r, c].sum())
+
+
+def test_hdbscan_matches_sklearn_goldens(oracle):
+    """canon_*: sklearn's own Cython single-linkage / condensed-tree / EOM / epsilon / labelling code run on the MST under
+    the strict edge order (weight, min, max) -> must match label for label.
+    labels_*: sklearn's public fit_predict, whose handling of equal-weight edges (Prim visiting order + an unstable
+    argsort) is implementation-defined; a point bridging two clusters at exactly its core distance can attach to either
+    side, and a cluster of exactly min_cluster_size points can appear or vanish with it (case c10)."""
+    z = np.load(os.path.join(GOLD, "hdbscan_cases.npz"))
+    names = z["names"].tolist()
+    same_public = 0
+    for name in names:
+        x = z["x_" + name]
+        labels, ncl = oracle.hdbscan(x, [0, len(x)], 15, 5, float(z["eps_" + name]), count_self=True)
+        assert np.array_equal(labels, z["canon_" + name]), name
+        assert ncl[0] == z["canon_" + name].max() + 1
+        same_public += _aligned_mismatch(labels.astype(np.int64), z["labels_" + name]) == 0
+    assert same_public >= 0.8 * len(names), same_public
+
+
+def test_hdbscan_small_and_split_samples(oracle):
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.normal(0, 0.1, (40, 5)), rng.normal(4, 0.1, (40, 5))]).astype(np.float32)
+    b = rng.normal(0, 1, (3, 5)).astype(np.float32)        # <= 3 points: skipped by the wrapper rule
+    c = rng.normal(0, 1, (12, 5)).astype(np.float32)       # < 2 * min_cluster_size: all noise
+    x = np.concatenate([a, b, c])
+    labels, ncl = oracle.hdbscan(x, [0, 80, 83, 95])
+    assert ncl.tolist() == [2, 0, 0]
+    assert len(set(labels[:40])) == 1 and len(set(labels[40:80])) == 1 and labels[0] != labels[40]
+    assert np.all(labels[80:] == -1)
+    # the other core-distance convention (point itself not counted) still separates the two blobs
+    l2, n2 = oracle.hdbscan(a, [0, 80], count_self=False)
+    assert n2[0] == 2
+
+
 # ---------------------------------------------------------------- scatter / iou / intersections
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
 def test_segment_reduce_matches_torch(oracle, reduce):
