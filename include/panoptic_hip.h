@@ -189,6 +189,26 @@ int pp_meanshift(const float* x /*[m,dim]*/, int64_t m, int32_t dim, const int64
                  int32_t* labels /*[m]*/, int32_t* n_clusters /*[n_samples]*/, float* centers,
                  void* workspace, size_t workspace_bytes, pp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K13 HDBSCAN*                    replaces: hdbscan.HDBSCAN(min_cluster_size=15, min_samples=5,
+ *                                 cluster_selection_epsilon=0.006).fit_predict(X)
+ *                                 via torch_points3d/utils/hdbscan_cluster.py:8-13,117-167
+ * Same sample layout as pp_meanshift (host sample_offsets; samples with <= min_points_exclusive
+ * points get label -1 and 0 clusters; reference: 3 for cluster_single, 5 for cluster_loop).
+ * Euclidean metric, excess-of-mass selection, allow_single_cluster=False.
+ * count_self: 1 = the core distance counts the point itself among its min_samples neighbours
+ * (hdbscan's Prim paths, sklearn's port); 0 = it does not (hdbscan's Boruvka path).
+ * Equal-weight tree edges are ordered by (weight, min index, max index) -- see DESIGN.md.
+ * labels[i] = cluster id inside the sample (ascending condensed-tree id) or -1 (noise).
+ * Cost is O(n^2) distance evaluations per Boruvka round per sample (float64, exact).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_hdbscan_workspace(int64_t m, int32_t n_samples);
+int pp_hdbscan(const float* x /*[m,dim]*/, int64_t m, int32_t dim, const int64_t* sample_offsets /*host*/,
+               int32_t n_samples, int32_t min_points_exclusive, int32_t min_cluster_size,
+               int32_t min_samples, int32_t count_self, double cluster_selection_epsilon,
+               int32_t* labels /*[m]*/, int32_t* n_clusters /*[n_samples]*/, void* workspace,
+               size_t workspace_bytes, pp_stream_t stream);
+
 /* Group points by a small integer key into CSR form (stable: ascending point order inside a group).
  * key[i] in [0,n_groups) or -1 (dropped).  ids[i] (int64) is what gets written (NULL -> i).
  * offsets [n_groups+1], out [n] capacity, total[0] = #kept.  Used to turn labels into the

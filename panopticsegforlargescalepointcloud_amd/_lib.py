@@ -49,6 +49,8 @@ SIGNATURES = {
     "pp_region_grow": (C.c_int, [vp, vp, vp, i64, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "pp_meanshift_workspace": (sz, [i64, i32, i32]),
     "pp_meanshift": (C.c_int, [vp, i64, i32, vp, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_hdbscan_workspace": (sz, [i64, i32]),
+    "pp_hdbscan": (C.c_int, [vp, i64, i32, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, sz, vp]),
     "pp_group_by_key_workspace": (sz, [i64]),
     "pp_group_by_key": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
     "pp_segment_reduce_workspace": (sz, [i64]),

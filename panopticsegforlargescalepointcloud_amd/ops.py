@@ -445,6 +445,27 @@ def meanshift(x, sample_offsets, bandwidth, min_points_exclusive=3, max_iter=300
     return labels[:m], ncl[:ns], centers
 
 
+def hdbscan(x, sample_offsets, min_cluster_size=15, min_samples=5, cluster_selection_epsilon=0.006, count_self=False,
+            min_points_exclusive=3):
+    """x [m,dim] float32 (points of a sample contiguous); returns (labels int32 [m], clusters per sample int32 [ns])."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    m, dim = x.shape
+    dev = x.device
+    so = [int(v) for v in (sample_offsets.tolist() if torch.is_tensor(sample_offsets) else sample_offsets)]
+    ns = len(so) - 1
+    so_arr = (C.c_int64 * (ns + 1))(*so)
+    labels = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+    ncl = torch.zeros(max(ns, 1), dtype=torch.int32, device=dev)
+    wsb = lib.pp_hdbscan_workspace(m, ns)
+    ws = _ws(wsb, dev, tag="hdbscan")
+    _lib.check(lib.pp_hdbscan(_ptr(x), m, dim, C.cast(so_arr, C.c_void_p), ns, int(min_points_exclusive),
+                              int(min_cluster_size), int(min_samples), 1 if count_self else 0,
+                              float(cluster_selection_epsilon), _ptr(labels), _ptr(ncl), _ptr(ws), wsb, _stream()),
+               "pp_hdbscan")
+    return labels[:m], ncl[:ns]
+
+
 def group_by_key(key, n_groups, ids=None):
     lib = _lib.load()
     key = _need(key, torch.int32, "key")

@@ -266,6 +266,70 @@ def test_meanshift_batched_matches_oracle(ops, oracle):
     np.testing.assert_allclose(centers.cpu().numpy(), wc, atol=2e-3)
 
 
+def test_hdbscan_matches_goldens(ops):
+    z = np.load(os.path.join(GOLD, "hdbscan_cases.npz"))
+    for name in z["names"].tolist():
+        x = z["x_" + name]
+        labels, ncl = ops.hdbscan(dev(x), [0, len(x)], 15, 5, float(z["eps_" + name]), count_self=True)
+        assert np.array_equal(labels.cpu().numpy(), z["canon_" + name]), name   # sklearn's tree code, canonical tie order
+        assert int(ncl[0]) == z["canon_" + name].max() + 1
+
+
+@pytest.mark.parametrize("count_self", [True, False])
+def test_hdbscan_batched_matches_oracle(ops, oracle, count_self):
+    rng = np.random.default_rng(21)
+    xs, offs = [], [0]
+    for n, k, dim_sigma in [(1500, 9, 0.2), (3, 1, 0.1), (2600, 20, 0.1), (0, 1, 0.1), (40, 1, 0.3), (700, 3, 0.5), (5, 1, 0.1)]:
+        cen = rng.normal(0, 3.0, size=(k, 5))
+        x = cen[rng.integers(0, k, size=n)] + rng.normal(0, dim_sigma, size=(n, 5))
+        if n > 100:
+            x[: n // 20] = rng.uniform(-8, 8, size=(n // 20, 5))     # background noise
+        xs.append(x.astype(np.float32))
+        offs.append(offs[-1] + n)
+    x = np.concatenate(xs)
+    for eps in [0.006, 0.4]:
+        wl, wn = oracle.hdbscan(x, offs, 15, 5, eps, count_self)
+        labels, ncl = ops.hdbscan(dev(x), offs, 15, 5, eps, count_self=count_self)
+        assert np.array_equal(ncl.cpu().numpy(), wn)
+        assert np.array_equal(labels.cpu().numpy(), wl)
+    assert wn[0] >= 5 and wn[2] >= 10 and wn[1] == 0 and wn[4] == 0  # one blob: no split -> noise (allow_single_cluster=False)
+
+
+def test_hdbscan_lattice_ties_and_duplicates(ops, oracle):
+    """Voxel-lattice coordinates (many exactly equal distances) and duplicated points: ties everywhere."""
+    rng = np.random.default_rng(22)
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(-1, 3)
+    a = g[rng.random(len(g)) < 0.7] * 0.05
+    b = a[: len(a) // 2] + np.array([3.0, 0, 0])
+    dup = np.repeat(np.array([[9.0, 9, 9]]), 20, 0)
+    x = np.concatenate([a, b, dup]).astype(np.float32)
+    x = x[rng.permutation(len(x))]
+    wl, wn = oracle.hdbscan(x, [0, len(x)], 15, 5, 0.006, True)
+    labels, ncl = ops.hdbscan(dev(x), [0, len(x)], 15, 5, 0.006, count_self=True)
+    assert np.array_equal(labels.cpu().numpy(), wl) and int(ncl[0]) == wn[0] and wn[0] >= 2
+
+
+def test_hdbscan_wrapper_matches_reference_conventions(ops, oracle):
+    from panopticsegforlargescalepointcloud_amd.utils import hdbscan_cluster as hc
+    rng = np.random.default_rng(23)
+    n = 1200
+    batch = np.sort(rng.integers(0, 3, size=n))
+    cen = rng.normal(0, 3, size=(8, 5))
+    emb = (cen[rng.integers(0, 8, size=n)] + rng.normal(0, 0.1, size=(n, 5))).astype(np.float32)
+    local = rng.permutation(5000)[:n]
+    clusters, types = hc.cluster_single(dev(emb), None, dev(batch), dev(local), 1)
+    offs = [0] + np.cumsum(np.bincount(batch, minlength=3)).tolist()
+    wl, wn = oracle.hdbscan(emb, offs, 15, 5, 0.006, hc.COUNT_SELF)
+    want = []
+    for s in range(3):
+        for l in range(wn[s]):
+            want.append(local[offs[s]: offs[s + 1]][wl[offs[s]: offs[s + 1]] == l])
+    assert len(clusters) == len(want) and types == [1] * len(want)
+    assert all(np.array_equal(c.cpu().numpy(), w) for c, w in zip(clusters, want))
+    cl2, t2 = hc.cluster_loop(dev(emb), None, dev(batch), dev(local), 3, 5, 2)
+    assert len(cl2) == len(t2) and set(t2) <= {0, 1} and all(c.numel() >= 15 for c in cl2)
+
+
 def test_group_by_key_and_segment_reduce(ops, oracle):
     rng = np.random.default_rng(11)
     key = rng.integers(-1, 50, size=10000).astype(np.int32)
