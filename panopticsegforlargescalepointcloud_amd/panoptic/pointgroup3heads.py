@@ -29,6 +29,7 @@ MAX_SCORER_BATCH = 60000  # proposals per ScorerUnet launch (batch index must fi
 
 
 class PointGroup3heads(nn.Module):
+    HEADS = ("Semantic", "Offset", "Embed")  # the 2-head classes of settings I-III narrow this (panoptic/variants.py)
     __REQUIRED_DATA__ = ["pos"]
     __REQUIRED_LABELS__ = list(PanopticLabels._fields)
 
@@ -54,10 +55,12 @@ class PointGroup3heads(nn.Module):
         self.cal_iou_based_on_mask = option.get("cal_iou_based_on_mask", False)
         self.cal_iou_based_on_mask_start_epoch = option.get("cal_iou_based_on_mask_start_epoch", 200)
 
-        self.Offset = Seq().append(MLP([nc, nc], bias=False))
-        self.Offset.append(nn.Linear(nc, 3))
-        self.Embed = Seq().append(MLP([nc, nc], bias=False))
-        self.Embed.append(nn.Linear(nc, option.get("embed_dim", 5)))
+        if "Offset" in self.HEADS:
+            self.Offset = Seq().append(MLP([nc, nc], bias=False))
+            self.Offset.append(nn.Linear(nc, 3))
+        if "Embed" in self.HEADS:
+            self.Embed = Seq().append(MLP([nc, nc], bias=False))
+            self.Embed.append(nn.Linear(nc, option.get("embed_dim", 5)))
         self.Semantic = (Seq().append(MLP([nc, nc], bias=False)).append(nn.Linear(nc, dataset.num_classes))
                          .append(nn.LogSoftmax(dim=-1)))
         self.num_classes = dataset.num_classes
@@ -106,14 +109,15 @@ class PointGroup3heads(nn.Module):
         """Sparse U-Net + the three heads.  Returns (features [N,16], semantic log-probs, offsets, embeddings,
         predicted labels [N] int64)."""
         feats = self.Backbone(self.input).x
+        has_off, has_emb = "Offset" in self.HEADS, "Embed" in self.HEADS
         if not self.training and not torch.is_grad_enabled():
             sem, pred = fused_head(self.Semantic, feats, log_softmax=True, want_argmax=True)
-            off = fused_head(self.Offset, feats)
-            emb = fused_head(self.Embed, feats)
+            off = fused_head(self.Offset, feats) if has_off else None
+            emb = fused_head(self.Embed, feats) if has_emb else None
         else:
             sem = self.Semantic(feats)
-            off = self.Offset(feats)
-            emb = self.Embed(feats)
+            off = self.Offset(feats) if has_off else None
+            emb = self.Embed(feats) if has_emb else None
             pred = torch.max(sem, 1)[1]
         return feats, sem, off, emb, pred
 
@@ -125,13 +129,14 @@ class PointGroup3heads(nn.Module):
             pred = torch.max(sem, 1)[1]
         cluster_scores = mask_scores = csr = cluster_type = None
         ct = self.opt.cluster_type
-        fns = {1: self._cluster, 2: self._cluster2, 5: self._cluster5, 6: self._cluster6}
+        fns = self._cluster_fns()
         run = (epoch > self.opt.prepare_epoch) if self.use_score_net else True
         if run:
             if ct not in fns:
-                raise NotImplementedError("cluster_type %s (published settings use 1, 2, 5, 6)" % ct)
+                raise NotImplementedError("%s: cluster_type %s (available: %s)" % (type(self).__name__, ct, sorted(fns)))
             with torch.no_grad():
-                csr, cluster_type = fns[ct](pred, off.detach(), emb.detach())
+                csr, cluster_type = fns[ct](pred, None if off is None else off.detach(),
+                                            None if emb is None else emb.detach())
             if self.use_score_net and csr.n:
                 cluster_scores, mask_scores = self._compute_score(epoch, csr, feats, sem)
                 self._lap("scorer")
@@ -148,6 +153,9 @@ class PointGroup3heads(nn.Module):
         return res
 
     # ------------------------------------------------------------------ proposal generators
+    def _cluster_fns(self):
+        return {1: self._cluster, 2: self._cluster2, 5: self._cluster5, 6: self._cluster6}
+
     def _grow(self, pos, pred, nsample):
         kw = {} if nsample is None else {"nsample": nsample}  # reference leaves the default (16) for raw coordinates
         csr, _ = region_grow_csr(pos, pred, self.input.batch, ignore_labels=self._stuff_classes,
@@ -242,14 +250,16 @@ class PointGroup3heads(nn.Module):
                                                           ignore_index=IGNORE_LABEL)
         self.loss = self.opt.loss_weights.semantic * self.semantic_loss
         mask = inp.instance_mask
-        for name, loss in offset_loss(out.offset_logits[mask], inp.vote_label[mask], torch.sum(mask)).items():
-            setattr(self, name, loss)
-            self.loss = self.loss + self.opt.loss_weights[name] * loss
-        for name, loss in discriminative_loss(out.embed_logits[mask], inp.instance_labels[mask], inp.batch[mask],
-                                              self.opt.embed_dim).items():
-            setattr(self, name, loss)
-            if name == "ins_loss":
-                self.loss = self.loss + self.opt.loss_weights.embedding_loss * loss
+        if out.offset_logits is not None:
+            for name, loss in offset_loss(out.offset_logits[mask], inp.vote_label[mask], torch.sum(mask)).items():
+                setattr(self, name, loss)
+                self.loss = self.loss + self.opt.loss_weights[name] * loss
+        if out.embed_logits is not None:
+            for name, loss in discriminative_loss(out.embed_logits[mask], inp.instance_labels[mask], inp.batch[mask],
+                                                  self.opt.embed_dim).items():
+                setattr(self, name, loss)
+                if name == "ins_loss":
+                    self.loss = self.loss + self.opt.loss_weights.embedding_loss * loss
         if out.cluster_scores is not None and self._scorer_type and epoch > self.opt.prepare_epoch and self.use_score_net:
             ious = instance_ious(out.clusters, out.cluster_scores, inp.instance_labels, inp.batch, None, False,
                                  clusters_csr=out.clusters_csr)

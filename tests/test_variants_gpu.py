@@ -1,0 +1,96 @@
+"""GPU: the reference's two-head model classes (README settings I-III + the HDBSCAN proposal generator) on the product
+path; proposals are checked against the oracle's grouping functions applied to the same head outputs."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cls_name, **over):
+    import bench
+    from panopticsegforlargescalepointcloud_amd import panoptic, synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.applications import Data
+    dev = torch.device("cuda")
+    _, cfg, DS = bench.build_model(dev, 0.05)
+    cfg = copy.deepcopy(cfg)
+    for k, v in over.items():
+        cfg[k] = v
+    torch.manual_seed(3)
+    model = getattr(panoptic, cls_name)(cfg, "dummy", DS, None).to(dev).eval()
+    scene, tiles, _ = bench.build_scene(60_000, 2, 0.05, 2022)
+    b = syn.tile_batch(scene, tiles, [0, 1])
+    data = Data(pos=torch.from_numpy(b["pos"]), coords=torch.from_numpy(b["coords"]), x=torch.from_numpy(b["x"]),
+                batch=torch.from_numpy(b["batch"]))
+    return model, cfg, scene, b, data, dev
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), np.sort(w))
+
+
+def test_pointgroup_settings_ii_iii(oracle):
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    for ct in (1, 2):
+        model, cfg, scene, b, data, dev = _setup("PointGroup", cluster_type=ct)
+        assert not any(k.startswith("Embed.") for k in model.state_dict())
+        model.set_input(data, dev)
+        with torch.no_grad():
+            feats, sem, off, emb, pred = model.backbone_and_heads()
+            assert emb is None
+            # random-init heads predict nothing useful: substitute generator statistics for the grouping stage
+            cls, off_np, _ = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(4))
+            pred = torch.from_numpy(cls).to(dev)
+            res = model.group_and_score(100, feats, sem, torch.from_numpy(off_np).to(dev), None, pred)
+        stuff = np.concatenate([[-1], syn.NPM3D_STUFF])
+        shifted, _ = oracle.region_grow(b["pos"] + off_np, cls, b["batch"], stuff, 200, cfg.cluster_radius_search, 10)
+        if ct == 1:
+            want, types = shifted, [0] * len(shifted)
+        else:
+            raw, _ = oracle.region_grow(b["pos"], cls, b["batch"], stuff, 16, cfg.cluster_radius_search, 10)
+            want, types = raw + shifted, [0] * len(raw) + [1] * len(shifted)
+        _same(res.clusters_csr.to_list(), want)
+        assert res.cluster_type.cpu().tolist() == types
+        assert res.embed_logits is None and res.cluster_scores.shape[0] == len(want)
+
+
+def test_pointgroupembed_setting_i_and_hdbscan(oracle):
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.utils import hdbscan_cluster as hc
+    for ct in (7, 1):
+        model, cfg, scene, b, data, dev = _setup("PointGroupEmbed", cluster_type=ct, use_score_net=False)
+        assert not any(k.startswith("Offset.") for k in model.state_dict())
+        model.set_input(data, dev)
+        with torch.no_grad():
+            feats, sem, off, emb, pred = model.backbone_and_heads()
+            assert off is None
+            cls, _, emb_np = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(4))
+            res = model.group_and_score(-1, feats, sem, None, torch.from_numpy(emb_np).to(dev), torch.from_numpy(cls).to(dev))
+        thing = ~np.isin(cls, np.concatenate([[-1], syn.NPM3D_STUFF]))
+        local = np.nonzero(thing)[0]
+        bt = b["batch"][thing]
+        offs = [0] + np.cumsum(np.bincount(bt, minlength=2)).tolist()
+
+        def lists(labels, ncl):
+            out = []
+            for s in range(len(offs) - 1):
+                seg = labels[offs[s]: offs[s + 1]]
+                out += [local[offs[s]: offs[s + 1]][seg == l] for l in range(ncl[s]) if np.any(seg == l)]
+            return out
+        if ct == 7:
+            want = lists(*oracle.meanshift(emb_np[thing], offs, cfg.bandwidth)[:2])
+            types = [0] * len(want)
+        else:
+            xyz = lists(*oracle.hdbscan(b["pos"][thing], offs, 15, 5, 0.006, hc.COUNT_SELF))
+            em = lists(*oracle.hdbscan(emb_np[thing], offs, 15, 5, 0.006, hc.COUNT_SELF))
+            want, types = xyz + em, [0] * len(xyz) + [1] * len(em)
+            assert len(xyz) > 0 and len(em) > 0
+        _same(res.clusters_csr.to_list(), want)
+        assert res.cluster_type.cpu().tolist() == types
+        assert res.cluster_scores is None            # no ScoreNet: get_instances hands back every proposal
+        ids, clusters = res._replace(clusters=res.clusters_csr.to_list()).get_instances()
+        assert ids is None and len(clusters) == len(want)
