@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 64))
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-table", default=None, help="write the per-shape convolution table (markdown) here")
     ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
     args = ap.parse_args()
 
@@ -182,6 +183,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = ops.PROFILER.summarize()
+    if args.layer_table and rank == 0:
+        with open(args.layer_table, "w") as f:
+            f.write("# pp_spconv_fwd launches of the timed steps grouped by shape (HIP events on the launch stream)\n\n")
+            f.write(ops.PROFILER.table(args.steps))
     ops.PROFILER = None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)

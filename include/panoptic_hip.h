@@ -104,12 +104,14 @@ int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, void* works
  * epilogue(v) = relu?( v * scale + shift ) + residual      (scale/shift/residual may be NULL)
  * nbr == NULL with K == 1: identity map (1x1 convolution, n_out rows in == rows out).
  * transpose_w: 0 -> packed[k] = W_k (Cin x Cout);  1 -> packed[k] = W_k^T (used for input gradients).
+ * n_in bounds the gathers: the fast kernel reads rows through a buffer descriptor of n_in * c0 * 4 bytes (missing
+ * neighbours come back as hardware-checked zeros); inputs of 4 GiB or more per source take the slower kernel.
  * ---------------------------------------------------------------------------------------------- */
 size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout);
 int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin, int32_t cout,
                    int32_t transpose_w, float* packed, pp_stream_t stream);
-int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
-                  const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
+int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in /*rows of in0 (and in1)*/,
+                  const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
                   const float* shift, int32_t relu, const float* residual, float* out,
                   pp_stream_t stream);
 

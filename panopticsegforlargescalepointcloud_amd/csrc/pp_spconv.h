@@ -1,0 +1,31 @@
+// Shared between the dense-offset convolution kernels (pp_spconv.hip, pp_spconv2.hip).
+#pragma once
+#include "pp_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SpconvArgs {
+  const float* in0;
+  const float* in1;
+  const float* wp;
+  const int32_t* nbr;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  float* out;
+  int64_t n_out;
+  int c0, c1, K, cout, NT, relu;
+};
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
+// blocks so the neighbour rows gathered by adjacent blocks hit that XCD's private L2 (guide T1; speed only).
+__device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// pipelined variant (pp_spconv2.hip); mode16 only, K <= 28
+// VALU-free main loop (buffer loads); needs the input row count for the descriptor
+bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in);
+int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
+int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s);

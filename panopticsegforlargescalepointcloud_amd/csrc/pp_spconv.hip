@@ -12,9 +12,9 @@
 // MFMA operand maps (guide 3, 16x16x4 f32): A lane l -> A[i=l&15][kk=l>>4]; B lane l -> B[kk=l>>4][j=l&15];
 // D reg r of lane l -> D[row=4*(l>>4)+r][col=l&15].  With a float4 per lane, MFMA #t of a 16-channel
 // step consumes channels {t, 4+t, 8+t, 12+t}: lane (i,q) feeds A[i][4q+t], lane (j,q) feeds W[4q+t][j].
-#include "pp_common.h"
+#include <stdlib.h>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "pp_spconv.h"
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -80,26 +80,6 @@ extern "C" int pp_pack_weight(const float* weight, int32_t K, int32_t cin, int32
 // ---------------------------------------------------------------------------------------------
 // forward kernel.  block = 4 waves = 128 output rows; grid.y = output-channel tile groups.
 // ---------------------------------------------------------------------------------------------
-struct SpconvArgs {
-  const float* in0;
-  const float* in1;
-  const float* wp;
-  const int32_t* nbr;
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  float* out;
-  int64_t n_out;
-  int c0, c1, K, cout, NT, relu;
-};
-
-// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
-// blocks so the neighbour rows gathered by adjacent blocks hit that XCD's private L2 (guide T1; speed only).
-__device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
-  const unsigned q = n >> 3, r = n & 7u, x = b & 7u, j = b >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
-
 template <int NTW, bool MODE16>
 __global__ __launch_bounds__(256) void k_spconv_fwd(SpconvArgs a) {
   const int lane = threadIdx.x & 63;
@@ -254,7 +234,8 @@ static void launch_fwd(int ntw, dim3 grid, hipStream_t s, const SpconvArgs& a) {
   }
 }
 
-extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
+extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                             const float* packed_weight,
                              const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
                              const float* shift, int32_t relu, const float* residual, float* out,
                              pp_stream_t stream) {
@@ -269,11 +250,23 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
   a.residual = residual; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
   a.NT = pp_nt(cout); a.relu = relu;
-  int groups = (a.NT + 6) / 7;
+  const int max_ntw = mode16 ? 4 : 7;
+  int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
   groups = (a.NT + ntw - 1) / ntw;
   dim3 grid(pp_blocks(n_out, 128), (unsigned)groups);
-  if (mode16)
+  static int dense_ver = -1;  // PP_DENSE_VER=1 selects the un-pipelined kernel (A/B measurements)
+  if (dense_ver < 0) {
+    const char* e = getenv("PP_DENSE_VER");
+    dense_ver = e ? atoi(e) : 3;
+  }
+  if (mode16 && dense_ver >= 3 && K <= 28 && ntw <= 4 && pp_spconv_fwd3_ok(a, n_in)) {
+    int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, pp_s(stream));
+    if (rc != PP_OK) return rc;
+  } else if (mode16 && dense_ver >= 2 && K <= 28 && ntw <= 4) {
+    int rc = pp_spconv_fwd2_launch(a, ntw, (unsigned)groups, pp_s(stream));
+    if (rc != PP_OK) return rc;
+  } else if (mode16)
     launch_fwd<true>(ntw, grid, pp_s(stream), a);
   else
     launch_fwd<false>(ntw, grid, pp_s(stream), a);

@@ -31,6 +31,27 @@ class LaunchProfiler:
             tot_ms += e0.elapsed_time(e1)
         return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops}
 
+    def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12):
+        """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
+        torch.cuda.synchronize()
+        groups = {}
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res) in self.records:
+            P = n_out if pairs is None else int(pairs.item())
+            b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
+            g = groups.setdefault((n_in, n_out, cin, cout, K, P), [0, 0.0, 0.0, 0.0])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1)
+            g[2] += b
+            g[3] += 2.0 * P * cin * cout
+        lines = ["| rows in | rows out | Cin | Cout | K | pairs/row | launches/step | ms/step | us/launch | alg GB/s | alg TFLOP/s | "
+                 "frac HBM | frac MFMA |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+        for (n_in, n_out, cin, cout, K, P), (cnt, ms, b, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+            sec = ms / 1e3
+            lines.append("| %d | %d | %d | %d | %d | %.2f | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f |" % (
+                n_in, n_out, cin, cout, K, P / max(n_out, 1), cnt / steps, ms / steps, ms / cnt * 1e3, b / sec / 1e9,
+                fl / sec / 1e12, b / sec / hbm_peak, fl / sec / mfma_peak))
+        return "\n".join(lines) + "\n"
+
 
 PROFILER = None
 
@@ -193,6 +214,8 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     in1 = _need(in1, torch.float32, "in1")
     c0 = in0.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
+    if in1 is not None and in1.shape[0] != in0.shape[0]:
+        raise ValueError("in0 and in1 must have the same number of rows")
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=in0.device)
     scale = _need(scale, torch.float32, "scale")
@@ -203,7 +226,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
+    _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
                                  _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()

@@ -1,0 +1,107 @@
+// Ground truth for the roofline denominator: issue rate of v_mfma_f32_16x16x4_f32 (and 32x32x2) with no memory traffic.
+// build: hipcc -O3 --offload-arch=gfx950 mfma_peak.hip -o mfma_peak ; run: ./mfma_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CHAINS>
+__global__ __launch_bounds__(256, 2) void k16(float* out, int iters, float a, float b) {
+  f32x4 acc[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float av = a + threadIdx.x, bv = b + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int CHAINS>
+__global__ __launch_bounds__(256, 2) void k32(float* out, int iters, float a, float b) {
+  f32x16 acc[CHAINS];
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+  float av = a + threadIdx.x, bv = b + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][5];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// 16 MFMAs (4 chains) + NV independent VALU ops (v_fma_f32 on a private chain) per iteration: do they overlap?
+template <int NV>
+__global__ __launch_bounds__(256, 2) void kmix(float* out, int iters, float a, float b) {
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float av = a + threadIdx.x, bv = b + threadIdx.x;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = a * e;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x[v & 7] = __builtin_fmaf(x[v & 7], 1.0001f, bv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += x[e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename F>
+static void run(const char* name, F launch, double flops_per_launch) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  launch();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("%-40s %8.3f ms/launch  %7.1f TFLOP/s\n", name, ms / 5, flops_per_launch / (ms / 5 * 1e-3) / 1e12);
+}
+
+int main() {
+  float* out;
+  hipMalloc(&out, 256 * 4096 * 4);
+  const int iters = 20000;
+  for (int blocks_per_cu = 1; blocks_per_cu <= 4; blocks_per_cu *= 2) {
+    const int blocks = 256 * blocks_per_cu;
+    const double waves = blocks * 4.0;
+    printf("blocks per CU %d (waves per SIMD %d)\n", blocks_per_cu, blocks_per_cu);
+    run("16x16x4 f32, 1 chain", [&] { k16<1><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 1 * 2048);
+    run("16x16x4 f32, 2 chains", [&] { k16<2><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 2 * 2048);
+    run("16x16x4 f32, 4 chains", [&] { k16<4><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 4 * 2048);
+    run("16x16x4 f32, 8 chains", [&] { k16<8><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 8 * 2048);
+    run("16 mfma + 32 valu / iter", [&] { kmix<32><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
+    run("16 mfma + 64 valu / iter", [&] { kmix<64><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
+    run("16 mfma + 128 valu / iter", [&] { kmix<128><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
+    run("32x32x2 f32, 2 chains", [&] { k32<2><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 2 * 4096);
+    run("32x32x2 f32, 4 chains", [&] { k32<4><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 4 * 4096);
+  }
+  return 0;
+}
