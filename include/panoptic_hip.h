@@ -88,13 +88,18 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
 int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
                             pp_stream_t stream);
 
-/* Morton (Z-order) permutation of COO rows, batch-major: perm[p] = input row holding the p-th smallest key.
- * The coordinate manager keeps rows in this order internally (compact 16-row tiles -> per-tile offset skipping
- * in pp_spconv_fwd, L2-resident gathers); the caller-visible row order of stride-1 tensors is unchanged
- * (applications/minkowski.py:193).  info[1] = rows outside the key range. */
+/* Internal row order of a coordinate level, batch-major: perm[p] = input row holding the p-th smallest key.
+ * unit = tensor stride of the level (coordinates are multiples of it).
+ * block_bits = 0: plain Morton (Z-) order of coords / unit.
+ * block_bits = B >= 2: blocks of 2^B voxels per axis in Z-order; inside a block rows are grouped by the parity of
+ *   (x, y, z) / unit, then Z-ordered.  Rows of one parity class use the same offsets of a stride-2 (transposed)
+ *   convolution, so 16-row tiles of a class skip the other offsets entirely (useful MFMA work on the up-convolutions
+ *   0.14 -> ~0.5), while neighbours stay a few hundred rows apart (L2-resident gathers).
+ * The caller-visible row order of stride-1 tensors is unchanged (applications/minkowski.py:193).
+ * info[1] = rows outside the key range. */
 size_t pp_morton_order_workspace(int64_t n);
-int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
-                    int32_t* info /*int32[2]*/, pp_stream_t stream);
+int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t block_bits, int32_t* perm, void* workspace,
+                    size_t workspace_bytes, int32_t* info /*int32[2]*/, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  sparse convolution forward  replaces: ME ConvolutionForward (gather-GEMM-scatter per offset),

@@ -23,20 +23,25 @@ from .. import ops
 from . import utils  # noqa: F401
 
 
-# 3x3x3 convolutions with Cin % 16 == 0 run on the block-compacted rulebook kernel (csrc/pp_spconv_rb.hip);
-# PP_CONV=dense forces the dense-offset kernel (csrc/pp_spconv.hip) for A/B measurements.
-#   auto : per layer, from the measured map density P / (27 N_out) (profiles/r01_conv_microbench.md):
-#          rulebook for transposed stride-2 convolutions (2-3 pairs per fine row: the dense loop is ~8x zero work) and
-#          for sparse same-level maps (density < 0.27, i.e. < 7.3 pairs per row) with Cin >= 32; dense-offset otherwise.
+# Kernel choice for 3x3x3 convolutions with Cin % 16 == 0 (PP_CONV = auto | dense | rb):
+#   dense : output-stationary dense-offset kernel (csrc/pp_spconv2.hip, v3) with per-16-row-tile offset skipping;
+#   rb    : block-compacted rulebook kernel (csrc/pp_spconv_rb.hip).
+# auto = dense everywhere.  The rulebook kernel won on sparse maps only until the dense kernel lost its vector-ALU
+# overhead and the rows became parity-grouped (transposed stride-2 maps: useful MFMA work 0.14 -> 0.4-0.74); measured
+# end to end in profiles/r01_h_*.  PP_RB_DENSITY > 0 re-enables the rulebook below that map density (A/B runs).
 CONV_MODE = os.environ.get("PP_CONV", "auto")
 USE_RULEBOOK = CONV_MODE != "dense"
-RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.27"))
+RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.0"))
+# internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order)
+ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
 
 
 def _want_rulebook(conv, x, ts_out, cin, sign):
     if CONV_MODE == "rb":
         return True
     if CONV_MODE == "dense":
+        return False
+    if RB_DENSITY <= 0.0:
         return False
     if conv.TRANSPOSED and ts_out != x.tensor_stride:
         return True
@@ -74,7 +79,7 @@ class CoordinateManager:
         self.orig_coords = coords
         self.perm = self.inv_perm = None
         if reorder and coords.shape[0] > 1:
-            self.perm = ops.morton_order(coords)
+            self.perm = ops.morton_order(coords, 1, ORDER_BLOCK_BITS)
             self.inv_perm = torch.empty_like(self.perm)
             self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
             coords = coords[self.perm].contiguous()
@@ -119,6 +124,10 @@ class CoordinateManager:
         if ts_out not in self.levels:
             src = self.levels[ts_in]
             out, table, _ = ops.stride_coords(src.coords, ts_out)
+            if ORDER_BLOCK_BITS >= 2 and out.shape[0] > 1:
+                # first-appearance order of the parents follows the fine level only roughly: re-order the level itself
+                out = out[ops.morton_order(out, ts_out, ORDER_BLOCK_BITS)].contiguous()
+                table, _ = ops.hash_build(out)
             self.levels[ts_out] = _Level(out, table)
         return ts_out
 

@@ -245,7 +245,7 @@ __device__ inline uint64_t pp_spread3(uint64_t x) {
   return x;
 }
 __global__ __launch_bounds__(256) void k_morton_keys(const int4* __restrict__ coords, int64_t n, uint64_t* key,
-                                                     int32_t* idx, int32_t* info) {
+                                                     int32_t* idx, int32_t* info, int unit_shift, int block_bits) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int4 c = coords[i];
@@ -253,8 +253,19 @@ __global__ __launch_bounds__(256) void k_morton_keys(const int4* __restrict__ co
     atomicAdd(&info[1], 1);
     key[i] = ~0ull;
   } else {
-    key[i] = ((uint64_t)(uint16_t)c.x << 48) | pp_spread3((uint64_t)(c.y + 32768)) |
-             (pp_spread3((uint64_t)(c.z + 32768)) << 1) | (pp_spread3((uint64_t)(c.w + 32768)) << 2);
+    const uint64_t x = (uint64_t)(c.y + 32768) >> unit_shift, y = (uint64_t)(c.z + 32768) >> unit_shift,
+                   z = (uint64_t)(c.w + 32768) >> unit_shift;
+    if (block_bits <= 1) {
+      key[i] = ((uint64_t)(uint16_t)c.x << 48) | pp_spread3(x) | (pp_spread3(y) << 1) | (pp_spread3(z) << 2);
+    } else {
+      // parity-grouped blocks: [batch][Z-order of the 2^B block][parity x,y,z][Z-order of the 2x2x2 cells in the block]
+      const int hb = block_bits - 1;
+      const uint64_t lm = (1ull << hb) - 1ull;
+      const uint64_t inner = pp_spread3((x >> 1) & lm) | (pp_spread3((y >> 1) & lm) << 1) | (pp_spread3((z >> 1) & lm) << 2);
+      const uint64_t par = (x & 1ull) | ((y & 1ull) << 1) | ((z & 1ull) << 2);
+      const uint64_t outer = pp_spread3(x >> block_bits) | (pp_spread3(y >> block_bits) << 1) | (pp_spread3(z >> block_bits) << 2);
+      key[i] = ((uint64_t)(uint16_t)c.x << 48) | (outer << (3 * block_bits)) | (par << (3 * hb)) | inner;
+    }
   }
   idx[i] = (int32_t)i;
 }
@@ -262,9 +273,13 @@ extern "C" size_t pp_morton_order_workspace(int64_t n) {
   size_t m = (size_t)std::max<int64_t>(n, 1);
   return 2 * pp_align(m * 8) + pp_align(m * 4) + pp_sort_pairs_workspace(n) + 1024;
 }
-extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, void* workspace, size_t workspace_bytes,
-                               int32_t* info, pp_stream_t stream) {
+extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t block_bits, int32_t* perm,
+                               void* workspace, size_t workspace_bytes, int32_t* info, pp_stream_t stream) {
   PP_REQUIRE(perm && info, "pp_morton_order: null output");
+  PP_REQUIRE(unit >= 1 && (unit & (unit - 1)) == 0 && unit <= 16384, "pp_morton_order: unit must be a power of two");
+  PP_REQUIRE(block_bits >= 0 && block_bits <= 8, "pp_morton_order: block_bits in [0,8]");
+  int unit_shift = 0;
+  while ((1 << unit_shift) < unit) ++unit_shift;
   if (workspace_bytes < pp_morton_order_workspace(n)) return PP_ERR_WORKSPACE;
   hipStream_t s = pp_s(stream);
   PP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int32_t), s));
@@ -274,7 +289,8 @@ extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t* perm, 
   uint64_t* key = ar.take<uint64_t>(m);
   uint64_t* key2 = ar.take<uint64_t>(m);
   int32_t* idx = ar.take<int32_t>(m);
-  hipLaunchKernelGGL(k_morton_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, key, idx, info);
+  hipLaunchKernelGGL(k_morton_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, key, idx, info,
+                     unit_shift, block_bits);
   PP_LAUNCH_CHECK();
   return pp_sort_pairs_u64(key, key2, idx, perm, n, 64, ar.cur(), ar.left(), s);
 }

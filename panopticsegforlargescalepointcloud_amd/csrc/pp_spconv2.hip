@@ -276,7 +276,10 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     const unsigned w_step = (unsigned)a.NT * 1024u;  // bytes of packed weights per (k, s)
     const unsigned w_jt0 = (unsigned)jt0 * 1024u;
 
-    // load side runs one step ahead of the compute side
+    // load side runs one step ahead of the compute side.  Its state (rem, kl, sl) is scalar; descriptor base and weight
+    // offset are recomputed from it every step (carrying them across iterations makes hipcc treat them as divergent and
+    // emit waterfall loops around the buffer loads).  Scalar instructions are not free either: they take MFMA issue
+    // slots (profiles/microbench/mfma_peak.hip), so the bookkeeping is kept short.
     int kl = __builtin_ctz(rem), sl = 0;
     unsigned vo[T];
 #pragma unroll
@@ -289,22 +292,23 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)a_bytes, 0x00020000); \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                           \
         AX[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)vo[tt], 0, 0));      \
-    const unsigned so_ = (unsigned)(kl * S + sl) * w_step + w_jt0;                                             \
+    const unsigned wso_ = (unsigned)(kl * S + sl) * w_step + w_jt0;                                            \
     _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                         \
-        BX[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * 1024u), (int)so_, 0)); \
+        BX[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * 1024u), (int)wso_, 0)); \
   }
-    // advance the load side; returns false when no step is left
+    // advance the load side; VALID = false when no step is left (the state then still names a valid step)
 #define F3_ADVANCE(VALID)                                             \
   {                                                                   \
-    VALID = true;                                                     \
-    if (++sl == S) {                                                  \
+    VALID = 1;                                                        \
+    ++sl;                                                             \
+    if (sl == S) {                                                    \
       sl = 0;                                                         \
       rem &= rem - 1;                                                 \
       if (rem) {                                                      \
         kl = __builtin_ctz(rem);                                      \
         _Pragma("unroll") for (int tt = 0; tt < T; ++tt) vo[tt] = off[kl][tt * 16 + i] | q16; \
       } else                                                          \
-        VALID = false;                                                \
+        VALID = 0;                                                    \
     }                                                                 \
   }
 #define F3_MFMAS(AX, BX, KC)                                                                              \
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
   }
     F3_LOADS(A0, B0);
     int kc = kl;
-    bool more;
+    int more;  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
     F3_ADVANCE(more);
     // The loads are unconditional: after the last step the load side simply re-reads a valid step.  (A branch around
     // them makes hipcc merge the two paths' outstanding-load counts and wait for the NEW loads before the MFMAs.)

@@ -179,8 +179,8 @@ def kernel_map_transpose(nbr, n_in):
     return out
 
 
-def morton_order(coords):
-    """perm (int64 [n]): rows of `coords` in batch-major Z-order."""
+def morton_order(coords, unit=1, block_bits=0):
+    """perm (int64 [n]): rows of `coords` in batch-major Z-order (block_bits=0) or parity-grouped block order."""
     lib = _lib.load()
     coords = _need(coords, torch.int32, "coords")
     n = coords.shape[0]
@@ -189,7 +189,7 @@ def morton_order(coords):
     info = torch.zeros(2, dtype=torch.int32, device=dev)
     wsb = lib.pp_morton_order_workspace(n)
     ws = _ws(wsb, dev)
-    _lib.check(lib.pp_morton_order(_ptr(coords), n, _ptr(perm), _ptr(ws), wsb, _ptr(info), _stream()), "pp_morton_order")
+    _lib.check(lib.pp_morton_order(_ptr(coords), n, int(unit), int(block_bits), _ptr(perm), _ptr(ws), wsb, _ptr(info), _stream()), "pp_morton_order")
     return perm[:n].long()
 
 

@@ -382,6 +382,19 @@ def test_morton_order_and_derived_maps(ops, oracle):
         return (int(c[0]) << 48) | k
     keys = [key(c) for c in fine[perm]]
     assert keys == sorted(keys)
+    # parity-grouped block order (unit = tensor stride 2, blocks of 2^3 units)
+    coarse2 = np.unique(np.concatenate([fine[:, :1], fine[:, 1:] // 2 * 2], 1), axis=0).astype(np.int32)
+    p2 = ops.morton_order(dev(coarse2), 2, 3).cpu().numpy()
+    assert np.array_equal(np.sort(p2), np.arange(len(coarse2)))
+
+    def key2(c, B=3):
+        q = [(int(v) + 32768) >> 1 for v in c[1:]]
+        z = lambda vals, nb: sum(((vals[a] >> b) & 1) << (3 * b + a) for b in range(nb) for a in range(3))  # noqa: E731
+        inner = z([(v >> 1) & ((1 << (B - 1)) - 1) for v in q], B - 1)
+        par = (q[0] & 1) | ((q[1] & 1) << 1) | ((q[2] & 1) << 2)
+        return (int(c[0]) << 48) | (z([v >> B for v in q], 16 - B) << (3 * B)) | (par << (3 * (B - 1))) | inner
+    keys2 = [key2(c) for c in coarse2[p2]]
+    assert keys2 == sorted(keys2) and len(set(keys2)) == len(keys2)
     # derived maps == probed maps
     table, _ = ops.hash_build(d)
     coarse, ctable, _ = ops.stride_coords(d, 2)
