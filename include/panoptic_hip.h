@@ -88,6 +88,30 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
 int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
                             pp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K1b/K3c  block index of a level + kernel maps through it (what the coordinate manager uses; the
+ * row-level hash of pp_hash_build / pp_kernel_map gives the same maps and stays available).
+ * The rows must already be in pp_morton_order(unit, block_bits) order.  Per group of <= 4096 voxels
+ * (key >> 12) the index keeps the first row, a 4096-bit occupancy map in key order and per-word
+ * prefix counts; a voxel's row is start + prefix + popcount.  Two steps because the number of blocks
+ * sizes the arrays: count (row_block int32 [n]; counts int32[4] = {blocks, duplicated rows, unsorted
+ * pairs, rows outside the key range}) then fill (bkeys/bvals [cap], cap = pp_block_index_capacity;
+ * start int32 [n_blocks]; bits uint64 [n_blocks*64]; pre uint16 [n_blocks*64]).
+ * pp_kernel_map_bi: same definition as pp_kernel_map (nbr[k][o] = row of out_coords[o] + sign*offset_k*step
+ * in the indexed level, -1 if absent or off its lattice).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_block_index_workspace(int64_t n);
+int64_t pp_block_index_capacity(int64_t n_blocks);
+int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits, int32_t* row_block,
+                         int32_t* counts /*int32[4]*/, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
+                        const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals, int64_t cap,
+                        int32_t* start, uint64_t* bits, uint16_t* pre, pp_stream_t stream);
+int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals, int64_t cap,
+                     const int32_t* start, const uint64_t* bits, const uint16_t* pre, int32_t unit_src,
+                     int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,
+                     int64_t* n_pairs /*device, may be NULL*/, pp_stream_t stream);
+
 /* Internal row order of a coordinate level, batch-major: perm[p] = input row holding the p-th smallest key.
  * unit = tensor stride of the level (coordinates are multiples of it).
  * block_bits = 0: plain Morton (Z-) order of coords / unit.

@@ -32,7 +32,8 @@ from . import utils  # noqa: F401
 CONV_MODE = os.environ.get("PP_CONV", "auto")
 USE_RULEBOOK = CONV_MODE != "dense"
 RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.0"))
-# internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order)
+# internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order,
+# -1 = caller order with row-level hash tables)
 ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
 
 
@@ -52,11 +53,14 @@ def _want_rulebook(conv, x, ts_out, cin, sign):
 # coordinate manager
 # ------------------------------------------------------------------------------------------------
 class _Level:
-    __slots__ = ("coords", "table", "n")
+    """coords int32 [n,4] in internal row order; `index` (ops.BlockIndex) when the rows are order-key sorted, else a
+    row-level hash `table` (PP_ORDER_BLOCK=-1: caller order, hash probing -- the first design, kept for A/B runs)."""
+    __slots__ = ("coords", "table", "index", "n")
 
-    def __init__(self, coords, table):
+    def __init__(self, coords, table=None, index=None):
         self.coords = coords
         self.table = table
+        self.index = index
         self.n = coords.shape[0]
 
 
@@ -78,16 +82,22 @@ class CoordinateManager:
         coords = coords.contiguous()
         self.orig_coords = coords
         self.perm = self.inv_perm = None
-        if reorder and coords.shape[0] > 1:
-            self.perm = ops.morton_order(coords, 1, ORDER_BLOCK_BITS)
-            self.inv_perm = torch.empty_like(self.perm)
-            self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
-            coords = coords[self.perm].contiguous()
-        table, ndup = ops.hash_build(coords)
+        self.sorted = bool(reorder) and ORDER_BLOCK_BITS >= 0
+        if self.sorted:
+            if coords.shape[0] > 1:
+                self.perm = ops.morton_order(coords, 1, ORDER_BLOCK_BITS)
+                self.inv_perm = torch.empty_like(self.perm)
+                self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
+                coords = coords[self.perm].contiguous()
+            index, ndup = ops.block_index_build(coords, 1, ORDER_BLOCK_BITS)
+            level = _Level(coords, index=index)
+        else:
+            table, ndup = ops.hash_build(coords)
+            level = _Level(coords, table=table)
         if ndup:
             raise ValueError("%d duplicate coordinates: the input must hold one row per (batch, x, y, z) "
                              "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
-        self.levels = {1: _Level(coords, table)}
+        self.levels = {1: level}
         self.maps = {}
         self.rulebooks = {}
         self.densities = {}
@@ -124,11 +134,14 @@ class CoordinateManager:
         if ts_out not in self.levels:
             src = self.levels[ts_in]
             out, table, _ = ops.stride_coords(src.coords, ts_out)
-            if ORDER_BLOCK_BITS >= 2 and out.shape[0] > 1:
-                # first-appearance order of the parents follows the fine level only roughly: re-order the level itself
-                out = out[ops.morton_order(out, ts_out, ORDER_BLOCK_BITS)].contiguous()
-                table, _ = ops.hash_build(out)
-            self.levels[ts_out] = _Level(out, table)
+            if self.sorted:
+                # first-appearance order of the parents follows the fine level only roughly: sort the level itself
+                if out.shape[0] > 1:
+                    out = out[ops.morton_order(out, ts_out, ORDER_BLOCK_BITS)].contiguous()
+                index, _ = ops.block_index_build(out, ts_out, ORDER_BLOCK_BITS)
+                self.levels[ts_out] = _Level(out, index=index)
+            else:
+                self.levels[ts_out] = _Level(out, table=table)
         return ts_out
 
     def kernel_map(self, ts_from, ts_to, ksize, sign):
@@ -149,7 +162,11 @@ class CoordinateManager:
             elif rev is not None:
                 m = ops.kernel_map_transpose(rev, self.levels[ts_to].n)
             else:
-                m = ops.kernel_map(self.levels[ts_to].coords, self.levels[ts_from].table, ksize, min(ts_from, ts_to), sign)
+                src = self.levels[ts_from]
+                if src.index is not None:
+                    m = ops.kernel_map_bi(self.levels[ts_to].coords, src.index, ksize, min(ts_from, ts_to), sign)
+                else:
+                    m = ops.kernel_map(self.levels[ts_to].coords, src.table, ksize, min(ts_from, ts_to), sign)
             self.maps[key] = m
         return m
 

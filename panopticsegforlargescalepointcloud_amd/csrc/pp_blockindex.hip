@@ -1,0 +1,240 @@
+// K1b/K3c: block index of a coordinate level and kernel maps looked up through it.
+//
+// The rows of a level are kept sorted by the order key of pp_morton_order (pp_common.h: pp_order_key).  The key's low
+// 12 bits enumerate the positions inside a group of at most 4096 voxels (a 16^3 block), its upper bits name the group.
+// The index stores, per occupied group ("block"),
+//     start   first row of the block                                   int32
+//     bits    4096-bit occupancy map in key order (64 x uint64)
+//     pre     number of occupied positions before each 64-bit word     uint16 x 64
+// plus a small open-addressing hash  block key -> block number.  The row of a voxel is then
+//     start[b] + pre[b][w] + popcount(bits[b][w] & lower bits)          (w = word of its 12-bit code)
+// i.e. ONE 8-byte word (+ 2 bytes) from a 640-byte record shared by ~300 voxels, instead of a 12-byte probe of a
+// row-level hash table spread over ~10 KiB per block: the 27 lookups of a kernel-map row and of its neighbours in the
+// wave hit the same few records in L1/L2.  The block hash is probed only when a neighbour leaves the previous block.
+// Replaces the per-row hash probing of pp_kernel_map for the coordinate manager (same map definition, same results;
+// reference: MinkowskiEngine's coordinate map / kernel map, call sites api_modules.py:30-51,256-271).
+#include "pp_common.h"
+
+#define BI_WORDS 64
+
+struct BlockIndex {
+  const uint64_t* bkeys;
+  const int32_t* bvals;
+  int64_t cap;
+  const int32_t* start;
+  const uint64_t* bits;
+  const uint16_t* pre;
+};
+
+__device__ inline int bi_find_block(const BlockIndex& I, uint64_t blk) {
+  const uint64_t mask = (uint64_t)I.cap - 1;
+  uint64_t s = pp_mix64(blk) & mask;
+  for (;;) {
+    const uint64_t k = I.bkeys[s];
+    if (k == blk) return I.bvals[s];
+    if (k == PP_EMPTY_KEY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// ---- build -------------------------------------------------------------------------------------------------------------
+// phase 1: block number of every row (rows sorted by key), number of blocks, duplicated rows
+__global__ __launch_bounds__(256) void k_bi_flags(const int4* __restrict__ coords, int64_t n, int unit_shift, int block_bits,
+                                                  int32_t* flag, int32_t* counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  const uint64_t key = pp_order_key(c.x, c.y, c.z, c.w, unit_shift, block_bits);
+  int f = 1;
+  if (i > 0) {
+    const int4 p = coords[i - 1];
+    const uint64_t pk = pp_order_key(p.x, p.y, p.z, p.w, unit_shift, block_bits);
+    f = (pk >> 12) != (key >> 12);
+    if (pk == key) atomicAdd(&counts[1], 1);        // duplicate coordinate
+    if (pk > key) atomicAdd(&counts[2], 1);         // not sorted
+  }
+  if (!pp_key_ok(c.x, c.y, c.z, c.w)) atomicAdd(&counts[3], 1);
+  flag[i] = f;
+}
+__global__ __launch_bounds__(256) void k_bi_rowblock(const int32_t* __restrict__ flag, const int32_t* __restrict__ excl,
+                                                     int64_t n, int32_t* row_block) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) row_block[i] = excl[i] + flag[i] - 1;  // inclusive scan - 1
+}
+// phase 2
+__global__ __launch_bounds__(256) void k_bi_hash_fill(uint64_t* keys, int64_t cap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) keys[i] = PP_EMPTY_KEY;
+}
+__global__ __launch_bounds__(256) void k_bi_scatter(const int4* __restrict__ coords, int64_t n, int unit_shift,
+                                                    int block_bits, const int32_t* __restrict__ row_block,
+                                                    uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
+                                                    unsigned long long* bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  const uint64_t key = pp_order_key(c.x, c.y, c.z, c.w, unit_shift, block_bits);
+  const int b = row_block[i];
+  const int code = (int)(key & 4095ull);
+  atomicOr(&bits[(size_t)b * BI_WORDS + (code >> 6)], 1ull << (code & 63));
+  if (i == 0 || row_block[i - 1] != b) {  // first row of the block: owns start[] and the hash entry
+    start[b] = (int32_t)i;
+    const uint64_t blk = key >> 12;
+    const uint64_t mask = (uint64_t)cap - 1;
+    uint64_t s = pp_mix64(blk) & mask;
+    for (;;) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&bkeys[s], (unsigned long long)PP_EMPTY_KEY,
+                                                (unsigned long long)blk);
+      if (prev == PP_EMPTY_KEY) {
+        bvals[s] = b;
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+}
+// one wave per block: exclusive prefix of the 64 word popcounts
+__global__ __launch_bounds__(256) void k_bi_prefix(const uint64_t* __restrict__ bits, int64_t nb, uint16_t* pre) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;
+  const int c = __popcll(bits[(size_t)b * BI_WORDS + lane]);
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  pre[(size_t)b * BI_WORDS + lane] = (uint16_t)(incl - c);
+}
+
+extern "C" size_t pp_block_index_workspace(int64_t n) {
+  const size_t m = (size_t)std::max<int64_t>(n, 1);
+  return 2 * pp_align(m * 4) + pp_scan_workspace(n) + 1024;
+}
+extern "C" int64_t pp_block_index_capacity(int64_t n_blocks) {
+  int64_t cap = 256;
+  while (cap < 2 * n_blocks) cap <<= 1;
+  return cap;
+}
+extern "C" int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
+                                    int32_t* row_block, int32_t* counts, void* workspace, size_t workspace_bytes,
+                                    pp_stream_t stream) {
+  PP_REQUIRE(row_block && counts, "pp_block_index_count: null output");
+  PP_REQUIRE(unit >= 1 && (unit & (unit - 1)) == 0 && unit <= 16384, "pp_block_index_count: unit must be a power of two");
+  PP_REQUIRE(block_bits >= 0 && block_bits <= 8, "pp_block_index_count: block_bits in [0,8]");
+  if (workspace_bytes < pp_block_index_workspace(n)) return PP_ERR_WORKSPACE;
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s));
+  if (n == 0) return PP_OK;
+  int unit_shift = 0;
+  while ((1 << unit_shift) < unit) ++unit_shift;
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* flag = ar.take<int32_t>((size_t)n);
+  int32_t* excl = ar.take<int32_t>((size_t)n);
+  const unsigned nb = pp_blocks(n, 256);
+  hipLaunchKernelGGL(k_bi_flags, dim3(nb), dim3(256), 0, s, (const int4*)coords_sorted, n, unit_shift, block_bits, flag,
+                     counts);
+  PP_LAUNCH_CHECK();
+  int rc = pp_exclusive_scan_i32(flag, excl, n, counts, ar.cur(), ar.left(), s);  // counts[0] = number of blocks
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bi_rowblock, dim3(nb), dim3(256), 0, s, flag, excl, n, row_block);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+extern "C" int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
+                                   const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals,
+                                   int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, pp_stream_t stream) {
+  PP_REQUIRE(bkeys && bvals && start && bits && pre, "pp_block_index_fill: null output");
+  PP_REQUIRE(cap >= 2 * n_blocks && (cap & (cap - 1)) == 0, "pp_block_index_fill: cap must be a power of two >= 2 n_blocks");
+  hipStream_t s = pp_s(stream);
+  int unit_shift = 0;
+  while ((1 << unit_shift) < unit) ++unit_shift;
+  hipLaunchKernelGGL(k_bi_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, bkeys, cap);
+  PP_LAUNCH_CHECK();
+  if (n_blocks > 0) PP_HIP(hipMemsetAsync(bits, 0, sizeof(uint64_t) * BI_WORDS * (size_t)n_blocks, s));
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(k_bi_scatter, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords_sorted, n, unit_shift,
+                     block_bits, row_block, bkeys, bvals, cap, start, (unsigned long long*)bits);
+  PP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bi_prefix, dim3(pp_blocks(n_blocks, 4)), dim3(256), 0, s, bits, n_blocks, pre);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- kernel map through the index ------------------------------------------------------------------------------------
+// One thread per output row.  The keys of its 27 neighbours are ORs of 9 per-axis terms; the block found for the
+// previous neighbour is kept in registers (a row's neighbours touch <= 8 blocks, usually 1-3).
+__global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ out_coords, int64_t n_out, BlockIndex I,
+                                                       int unit_shift, int block_bits, int dstep,
+                                                       int32_t* __restrict__ nbr, unsigned long long* n_pairs) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int found = 0;
+  if (o < n_out) {
+    const int4 c = out_coords[o];
+    uint64_t ax[3][3];
+    bool ok[3][3];
+    const int cc[3] = {c.y, c.z, c.w};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int v = cc[a] + (d - 1) * dstep;
+        // inside the key range AND on the source level's lattice (a fine voxel probing a coarser level may sit between)
+        ok[a][d] = (unsigned)(v + 32768) < 65536u && ((unsigned)(v + 32768) & ((1u << unit_shift) - 1u)) == 0u;
+        ax[a][d] = pp_order_axis((uint32_t)(v + 32768) >> unit_shift, a, block_bits);
+      }
+    const uint64_t kb = (uint64_t)(uint16_t)c.x << 48;
+    const bool bok = (unsigned)c.x < 65536u;
+    uint64_t last_blk = ~0ull;
+    int last_b = -1, last_start = 0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
+      int32_t r = -1;
+      if (bok && ok[0][dx] && ok[1][dy] && ok[2][dz]) {
+        const uint64_t key = kb | ax[0][dx] | ax[1][dy] | ax[2][dz];
+        const uint64_t blk = key >> 12;
+        if (blk != last_blk) {
+          last_blk = blk;
+          last_b = bi_find_block(I, blk);
+          last_start = last_b >= 0 ? I.start[last_b] : 0;
+        }
+        if (last_b >= 0) {
+          const int code = (int)(key & 4095ull);
+          const size_t w = (size_t)last_b * BI_WORDS + (code >> 6);
+          const uint64_t word = I.bits[w];
+          const int bit = code & 63;
+          if ((word >> bit) & 1ull) r = last_start + (int)I.pre[w] + __popcll(word & ((1ull << bit) - 1ull));
+        }
+      }
+      found += r >= 0 ? 1 : 0;
+      nbr[(int64_t)k * n_out + o] = r;
+    }
+  }
+  if (n_pairs) {
+    for (int off = 32; off > 0; off >>= 1) found += __shfl_xor(found, off);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(n_pairs, (unsigned long long)found);
+  }
+}
+
+extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals,
+                                int64_t cap, const int32_t* start, const uint64_t* bits, const uint16_t* pre,
+                                int32_t unit_src, int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr,
+                                int64_t* n_pairs, pp_stream_t stream) {
+  PP_REQUIRE(out_coords || n_out == 0, "pp_kernel_map_bi: null coordinates");
+  PP_REQUIRE(bkeys && bvals && start && bits && pre && nbr, "pp_kernel_map_bi: null index");
+  PP_REQUIRE(sign == 1 || sign == -1, "pp_kernel_map_bi: sign must be +1 or -1");
+  PP_REQUIRE(unit_src >= 1 && (unit_src & (unit_src - 1)) == 0, "pp_kernel_map_bi: unit must be a power of two");
+  hipStream_t s = pp_s(stream);
+  if (n_pairs) PP_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int64_t), s));
+  if (n_out == 0) return PP_OK;
+  int unit_shift = 0;
+  while ((1 << unit_shift) < unit_src) ++unit_shift;
+  BlockIndex I{bkeys, bvals, cap, start, bits, pre};
+  hipLaunchKernelGGL(k_kernel_map_bi, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, (const int4*)out_coords, n_out, I,
+                     unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

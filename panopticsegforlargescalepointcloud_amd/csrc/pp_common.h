@@ -89,6 +89,34 @@ __device__ inline int64_t pp_hash_insert_slot(uint64_t* keys, int64_t cap, uint6
   }
 }
 
+// ---- internal row-order key (pp_morton_order) ------------------------------------------------------------------------
+// key = batch << 48 | X(qx) | Y(qy) | Z(qz) with q = (coordinate + 32768) / unit: every axis contributes its own bits, so
+// the keys of the 27 neighbours of a voxel are ORs of 9 per-axis terms.  block_bits <= 1: Z-order.  block_bits = B >= 2:
+// [Z-order of q >> B][parity of q][Z-order of (q >> 1) & (2^(B-1) - 1)].  In both layouts the low 12 bits enumerate the
+// positions inside a group of <= 4096 voxels (a 16^3 block for B = 0 and B = 4) -- the block index relies on that.
+__host__ __device__ inline uint64_t pp_spread3_64(uint64_t x) {
+  x &= 0xFFFFull;
+  x = (x | (x << 32)) & 0x1F00000000FFFFull;
+  x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+__host__ __device__ inline uint64_t pp_order_axis(uint32_t q, int axis, int block_bits) {
+  if (block_bits <= 1) return pp_spread3_64(q) << axis;
+  const int hb = block_bits - 1;
+  const uint64_t inner = pp_spread3_64((q >> 1) & ((1u << hb) - 1u));
+  const uint64_t par = (uint64_t)(q & 1u);
+  const uint64_t outer = pp_spread3_64(q >> block_bits);
+  return ((outer << (3 * block_bits)) | (par << (3 * hb)) | inner) << axis;
+}
+__host__ __device__ inline uint64_t pp_order_key(int b, int x, int y, int z, int unit_shift, int block_bits) {
+  return ((uint64_t)(uint16_t)b << 48) | pp_order_axis((uint32_t)(x + 32768) >> unit_shift, 0, block_bits) |
+         pp_order_axis((uint32_t)(y + 32768) >> unit_shift, 1, block_bits) |
+         pp_order_axis((uint32_t)(z + 32768) >> unit_shift, 2, block_bits);
+}
+
 // internal device primitives (pp_scan.hip)
 size_t pp_scan_workspace(int64_t n);
 // exclusive prefix sum of int32; total (device int32[1], may be NULL) receives the grand total

@@ -253,19 +253,7 @@ __global__ __launch_bounds__(256) void k_morton_keys(const int4* __restrict__ co
     atomicAdd(&info[1], 1);
     key[i] = ~0ull;
   } else {
-    const uint64_t x = (uint64_t)(c.y + 32768) >> unit_shift, y = (uint64_t)(c.z + 32768) >> unit_shift,
-                   z = (uint64_t)(c.w + 32768) >> unit_shift;
-    if (block_bits <= 1) {
-      key[i] = ((uint64_t)(uint16_t)c.x << 48) | pp_spread3(x) | (pp_spread3(y) << 1) | (pp_spread3(z) << 2);
-    } else {
-      // parity-grouped blocks: [batch][Z-order of the 2^B block][parity x,y,z][Z-order of the 2x2x2 cells in the block]
-      const int hb = block_bits - 1;
-      const uint64_t lm = (1ull << hb) - 1ull;
-      const uint64_t inner = pp_spread3((x >> 1) & lm) | (pp_spread3((y >> 1) & lm) << 1) | (pp_spread3((z >> 1) & lm) << 2);
-      const uint64_t par = (x & 1ull) | ((y & 1ull) << 1) | ((z & 1ull) << 2);
-      const uint64_t outer = pp_spread3(x >> block_bits) | (pp_spread3(y >> block_bits) << 1) | (pp_spread3(z >> block_bits) << 2);
-      key[i] = ((uint64_t)(uint16_t)c.x << 48) | (outer << (3 * block_bits)) | (par << (3 * hb)) | inner;
-    }
+    key[i] = pp_order_key(c.x, c.y, c.z, c.w, unit_shift, block_bits);
   }
   idx[i] = (int32_t)i;
 }

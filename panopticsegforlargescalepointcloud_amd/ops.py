@@ -168,6 +168,61 @@ def kernel_map(out_coords, table, ksize, step, sign):
     return nbr
 
 
+class BlockIndex:
+    """Block index of a coordinate level (csrc/pp_blockindex.hip): per group of <= 4096 voxels the first row, a
+    4096-bit occupancy map and prefix counts, plus a hash block key -> block number."""
+
+    __slots__ = ("unit", "block_bits", "n_blocks", "cap", "bkeys", "bvals", "start", "bits", "pre")
+
+
+def block_index_build(coords_sorted, unit, block_bits):
+    """coords_sorted int32 [n,4] in morton_order(unit, block_bits) order -> (BlockIndex, n_duplicate_rows)."""
+    lib = _lib.load()
+    coords = _need(coords_sorted, torch.int32, "coords_sorted")
+    n = coords.shape[0]
+    dev = coords.device
+    row_block = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    wsb = lib.pp_block_index_workspace(n)
+    ws = _ws(wsb, dev, tag="block_index")
+    _lib.check(lib.pp_block_index_count(_ptr(coords), n, int(unit), int(block_bits), _ptr(row_block), _ptr(counts), _ptr(ws),
+                                        wsb, _stream()), "pp_block_index_count")
+    nb, ndup, unsorted, oor = [int(v) for v in counts.tolist()]
+    if unsorted:
+        raise _lib.PanopticHipError("block_index_build: rows are not in morton_order(unit=%d, block_bits=%d) order" % (unit, block_bits))
+    if oor:
+        raise _lib.PanopticHipError("%d coordinates outside the 16-bit key range" % oor)
+    bi = BlockIndex()
+    bi.unit, bi.block_bits, bi.n_blocks = int(unit), int(block_bits), nb
+    bi.cap = int(lib.pp_block_index_capacity(nb))
+    bi.bkeys = torch.empty(bi.cap, dtype=torch.int64, device=dev)
+    bi.bvals = torch.empty(bi.cap, dtype=torch.int32, device=dev)
+    bi.start = torch.empty(max(nb, 1), dtype=torch.int32, device=dev)
+    bi.bits = torch.empty(max(nb, 1) * 64, dtype=torch.int64, device=dev)
+    bi.pre = torch.empty(max(nb, 1) * 64, dtype=torch.int16, device=dev)
+    if ndup == 0:
+        _lib.check(lib.pp_block_index_fill(_ptr(coords), n, int(unit), int(block_bits), _ptr(row_block), nb, _ptr(bi.bkeys),
+                                           _ptr(bi.bvals), bi.cap, _ptr(bi.start), _ptr(bi.bits), _ptr(bi.pre), _stream()),
+                   "pp_block_index_fill")
+    return bi, ndup
+
+
+def kernel_map_bi(out_coords, index, ksize, step, sign):
+    """nbr int32 [27, n_out] through a BlockIndex: row in the indexed level of out_coords + sign*offset*step (or -1)."""
+    if ksize != 3:
+        raise NotImplementedError("kernel_map_bi: 3x3x3 kernels only")
+    lib = _lib.load()
+    out_coords = _need(out_coords, torch.int32, "out_coords")
+    n_out = out_coords.shape[0]
+    nbr = torch.empty((27, n_out), dtype=torch.int32, device=out_coords.device)
+    pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
+    _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap, _ptr(index.start),
+                                    _ptr(index.bits), _ptr(index.pre), index.unit, index.block_bits, int(step), int(sign),
+                                    _ptr(nbr), _ptr(pairs), _stream()), "pp_kernel_map_bi")
+    nbr.pp_pairs = pairs
+    return nbr
+
+
 def kernel_map_transpose(nbr, n_in):
     """map of the transposed strided conv from the strided conv's map: out[k][nbr[k][o]] = o."""
     lib = _lib.load()

@@ -406,6 +406,42 @@ def test_morton_order_and_derived_maps(ops, oracle):
     assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))
 
 
+@pytest.mark.parametrize("block_bits", [0, 4, 5])
+def test_block_index_maps_match_oracle(ops, oracle, block_bits):
+    """kernel maps looked up through the block index (bitmap + popcount) == oracle maps, all map kinds, incl. voxels at
+    the ends of the 16-bit coordinate range and a fine level probing a coarser one (off-lattice neighbours)."""
+    rng = np.random.default_rng(31)
+    fine = surface(rng, n=6000, n_batch=3, extent=90)
+    edge = np.array([[2, 32767, 32767, 32767], [2, 32766, 32767, 32767], [2, -32768, -32768, -32768], [2, -32767, -32768, -32768]], np.int32)
+    fine = np.unique(np.concatenate([fine, edge]), axis=0).astype(np.int32)
+    perm = ops.morton_order(dev(fine), 1, block_bits).cpu().numpy()
+    fine = fine[perm]
+    idx, ndup = ops.block_index_build(dev(fine), 1, block_bits)
+    assert ndup == 0 and idx.n_blocks > 3
+    same = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1)
+    assert np.array_equal(same.cpu().numpy(), oracle.kernel_map(fine, fine, 3, 1, 1))
+    assert int(same.pp_pairs) == int((same >= 0).sum())
+    mirrored = ops.kernel_map_bi(dev(fine), idx, 3, 1, -1)
+    assert np.array_equal(mirrored.cpu().numpy(), oracle.kernel_map(fine, fine, 3, 1, -1))
+    for ts in (2, 4):
+        coarse = np.unique(np.concatenate([fine[:, :1], fine[:, 1:] // ts * ts], 1), axis=0).astype(np.int32)
+        coarse = coarse[ops.morton_order(dev(coarse), ts, block_bits).cpu().numpy()]
+        cidx, _ = ops.block_index_build(dev(coarse), ts, block_bits)
+        if ts == 2:
+            down = ops.kernel_map_bi(dev(coarse), idx, 3, 1, 1)          # coarse rows gather fine rows
+            assert np.array_equal(down.cpu().numpy(), oracle.kernel_map(coarse, fine, 3, 1, 1))
+            up = ops.kernel_map_bi(dev(fine), cidx, 3, 1, -1)            # fine rows probe the coarse level
+            assert np.array_equal(up.cpu().numpy(), oracle.kernel_map(fine, coarse, 3, 1, -1))
+            assert torch.equal(up, ops.kernel_map_transpose(down, len(fine)))
+        same_c = ops.kernel_map_bi(dev(coarse), cidx, 3, ts, 1)
+        assert np.array_equal(same_c.cpu().numpy(), oracle.kernel_map(coarse, coarse, 3, ts, 1))
+    # duplicates and unsorted input are reported
+    dup = np.concatenate([fine[:10], fine[9:10], fine[10:]])
+    assert ops.block_index_build(dev(dup), 1, block_bits)[1] == 1
+    with pytest.raises(Exception):
+        ops.block_index_build(dev(fine[::-1].copy()), 1, block_bits)
+
+
 @pytest.mark.parametrize("cin,cout,n_pts", [(16, 16, 3000), (16, 32, 3000), (64, 64, 2000), (96, 96, 1500), (32, 48, 2500),
                                            (192, 80, 1200), (16, 16, 1), (16, 16, 129), (48, 112, 700), (80, 80, 900), (112, 96, 500)])
 def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
