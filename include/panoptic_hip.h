@@ -110,7 +110,16 @@ int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, i
 int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals, int64_t cap,
                      const int32_t* start, const uint64_t* bits, const uint16_t* pre, int32_t unit_src,
                      int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,
-                     int64_t* n_pairs /*device, may be NULL*/, pp_stream_t stream);
+                     int64_t* n_pairs /*device, may be NULL*/, uint32_t* mask_out /*[n_out] occupied offsets, may be NULL*/,
+                     pp_stream_t stream);
+
+/* Tile schedule of a level: order[p] = p-th row to process.  Inside windows of `window` consecutive rows the rows are
+ * grouped by coordinate parity, then by their same-level neighbour mask (mask_out of pp_kernel_map_bi), so that the
+ * 16 rows of an MFMA tile occupy (nearly) the same kernel offsets.  pp_spconv_fwd takes it as row_order; outputs are
+ * identical with and without it. */
+size_t pp_tile_order_workspace(int64_t n);
+int pp_tile_order(const int32_t* coords, const uint32_t* mask, int64_t n, int32_t unit, int32_t window, int32_t* order,
+                  void* workspace, size_t workspace_bytes, pp_stream_t stream);
 
 /* Internal row order of a coordinate level, batch-major: perm[p] = input row holding the p-th smallest key.
  * unit = tensor stride of the level (coordinates are multiples of it).
@@ -141,7 +150,8 @@ int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin,
                    int32_t transpose_w, float* packed, pp_stream_t stream);
 int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in /*rows of in0 (and in1)*/,
                   const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
-                  const float* shift, int32_t relu, const float* residual, float* out,
+                  const float* shift, int32_t relu, const float* residual,
+                  const int32_t* row_order /*optional tile schedule (pp_tile_order); NULL = row order*/, float* out,
                   pp_stream_t stream);
 
 /* K3b/K4b  block-compacted rulebook and the convolution on it (the fast path for 3x3x3 kernels with Cin % 16 == 0).

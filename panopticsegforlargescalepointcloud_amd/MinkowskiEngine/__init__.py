@@ -35,6 +35,11 @@ RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.0"))
 # internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order,
 # -1 = caller order with row-level hash tables)
 ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
+# tile schedule window (rows): processing order of a level's rows = (window, parity, same-level neighbour mask); 0 = off.
+# OFF by default: it raises the useful share of executed MFMA tiles (0.31 -> 0.43 at the finest level) but the extra
+# indirection (scattered index loads / output stores, one radix sort per level) costs more than it saves end to end
+# (242 -> 251..257 ms per step for windows of 64..65536 rows, profiles/r01_i_notes.md).
+TILE_WINDOW = int(os.environ.get("PP_TILE_WINDOW", "0"))
 
 
 def _want_rulebook(conv, x, ts_out, cin, sign):
@@ -99,6 +104,7 @@ class CoordinateManager:
                              "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
         self.levels = {1: level}
         self.maps = {}
+        self.tile_orders = {}
         self.rulebooks = {}
         self.densities = {}
 
@@ -122,6 +128,10 @@ class CoordinateManager:
 
     def level(self, ts):
         return self.levels[ts]
+
+    def tile_order(self, ts):
+        """processing order of the rows of level ts for the convolution kernels (None until its same-level map exists)"""
+        return self.tile_orders.get(ts)
 
     def to_internal(self, feats):
         return feats if self.perm is None else feats[self.perm]
@@ -164,7 +174,11 @@ class CoordinateManager:
             else:
                 src = self.levels[ts_from]
                 if src.index is not None:
-                    m = ops.kernel_map_bi(self.levels[ts_to].coords, src.index, ksize, min(ts_from, ts_to), sign)
+                    want = ts_from == ts_to and TILE_WINDOW > 0 and ts_to not in self.tile_orders
+                    m = ops.kernel_map_bi(self.levels[ts_to].coords, src.index, ksize, min(ts_from, ts_to), sign, want_mask=want)
+                    if want:
+                        self.tile_orders[ts_to] = ops.tile_order(self.levels[ts_to].coords, m.pp_mask, ts_to, TILE_WINDOW)
+                        del m.pp_mask
                 else:
                     m = ops.kernel_map(self.levels[ts_to].coords, src.table, ksize, min(ts_from, ts_to), sign)
             self.maps[key] = m
@@ -240,13 +254,13 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------------------
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K):
+    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, order_out=None, order_in=None):
         feats = feats.contiguous()
         packed = ops.pack_weight(kernel)
         cout = kernel.shape[-1]
-        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K)
+        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=order_out)
         ctx.save_for_backward(feats, kernel)
-        ctx.nbr, ctx.inv_fn, ctx.K = nbr, inv_fn, K
+        ctx.nbr, ctx.inv_fn, ctx.K, ctx.order_in = nbr, inv_fn, K, order_in
         return out
 
     @staticmethod
@@ -256,10 +270,10 @@ class _SparseConvFn(torch.autograd.Function):
         din = dw = None
         if ctx.needs_input_grad[0]:
             packed_t = ops.pack_weight(kernel, transpose=True)
-            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K)
+            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in)
         if ctx.needs_input_grad[1]:
             dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K).reshape(kernel.shape)
-        return din, dw, None, None, None, None
+        return din, dw, None, None, None, None, None, None
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
@@ -394,8 +408,10 @@ class _ConvBase(nn.Module):
 
     def forward(self, x):
         ts_out, nbr, inv_fn = self.out_stride_and_map(x)
-        n_out = x.coordinate_manager.level(ts_out).n
-        feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume)
+        cm = x.coordinate_manager
+        n_out = cm.level(ts_out).n
+        feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume, cm.tile_order(ts_out),
+                                    cm.tile_order(x.tensor_stride))
         if self.bias is not None:
             feats = feats + self.bias
         return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=ts_out)
@@ -535,7 +551,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
                                   relu=relu, residual=res)
     else:
         feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
-                               scale=scale, shift=shift, relu=relu, residual=res)
+                               scale=scale, shift=shift, relu=relu, residual=res, row_order=cm.tile_order(ts_out))
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

@@ -12,6 +12,7 @@ struct SpconvArgs {
   const float* scale;
   const float* shift;
   const float* residual;
+  const int32_t* row_order;  // optional processing order of the output rows (tile schedule); results do not depend on it
   float* out;
   int64_t n_out;
   int c0, c1, K, cout, NT, relu;

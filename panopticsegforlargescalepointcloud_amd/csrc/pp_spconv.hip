@@ -237,8 +237,8 @@ static void launch_fwd(int ntw, dim3 grid, hipStream_t s, const SpconvArgs& a) {
 extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                              const float* packed_weight,
                              const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
-                             const float* shift, int32_t relu, const float* residual, float* out,
-                             pp_stream_t stream) {
+                             const float* shift, int32_t relu, const float* residual, const int32_t* row_order,
+                             float* out, pp_stream_t stream) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
@@ -248,7 +248,7 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
   if (n_out == 0) return PP_OK;
   SpconvArgs a;
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
-  a.residual = residual; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
+  a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
   a.NT = pp_nt(cout); a.relu = relu;
   const int max_ntw = mode16 ? 4 : 7;
   int groups = (a.NT + max_ntw - 1) / max_ntw;

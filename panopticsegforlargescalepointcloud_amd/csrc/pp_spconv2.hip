@@ -226,10 +226,13 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     constexpr int KPL = 64 / R >= 1 ? 64 / R : 1;
     constexpr int NL = (F2_MAXK + KPL - 1) / KPL;
     const int rr = lane % R, kh = lane / R;
-    const int64_t row = row_base + rr;
-    const bool rv = row < a.n_out;
+    const bool rv = row_base + rr < a.n_out;
+    // tile schedule: the wave's 32 "slots" may name any output rows (rows with similar neighbour masks are scheduled
+    // into the same tile by the coordinate manager); without one, slot = row
+    const int64_t slot = rv ? row_base + rr : a.n_out - 1;
+    const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
     int v[NL];
-    const int64_t rowc = rv ? row : a.n_out - 1;
+    const int64_t rowc = row;
     if (a.nbr) {
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
@@ -353,8 +356,9 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
       for (int rt = 0; rt < T; ++rt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = row_base + rt * 16 + q * 4 + r;
-          if (row < a.n_out) {
+          const int64_t slot = row_base + rt * 16 + q * 4 + r;
+          if (slot < a.n_out) {
+            const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
             float v = acc[rt][jt][r] * sc + sh;
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.residual) v += a.residual[row * a.cout + col];

@@ -207,7 +207,7 @@ def block_index_build(coords_sorted, unit, block_bits):
     return bi, ndup
 
 
-def kernel_map_bi(out_coords, index, ksize, step, sign):
+def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False):
     """nbr int32 [27, n_out] through a BlockIndex: row in the indexed level of out_coords + sign*offset*step (or -1)."""
     if ksize != 3:
         raise NotImplementedError("kernel_map_bi: 3x3x3 kernels only")
@@ -216,11 +216,28 @@ def kernel_map_bi(out_coords, index, ksize, step, sign):
     n_out = out_coords.shape[0]
     nbr = torch.empty((27, n_out), dtype=torch.int32, device=out_coords.device)
     pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
+    mask = torch.empty(max(n_out, 1), dtype=torch.int32, device=out_coords.device) if want_mask else None
     _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap, _ptr(index.start),
                                     _ptr(index.bits), _ptr(index.pre), index.unit, index.block_bits, int(step), int(sign),
-                                    _ptr(nbr), _ptr(pairs), _stream()), "pp_kernel_map_bi")
+                                    _ptr(nbr), _ptr(pairs), _ptr(mask), _stream()), "pp_kernel_map_bi")
     nbr.pp_pairs = pairs
+    if want_mask:
+        nbr.pp_mask = mask  # int32 [n_out]: bit k set <=> offset k occupied
     return nbr
+
+
+def tile_order(coords, mask, unit, window=16384):
+    """processing order (int32 [n]) of a level's rows: (window, coordinate parity, neighbour mask) -- see pp_tile_order"""
+    lib = _lib.load()
+    coords = _need(coords, torch.int32, "coords")
+    mask = _need(mask, torch.int32, "mask")
+    n = coords.shape[0]
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=coords.device)
+    wsb = lib.pp_tile_order_workspace(n)
+    ws = _ws(wsb, coords.device, tag="tile_order")
+    _lib.check(lib.pp_tile_order(_ptr(coords), _ptr(mask), n, int(unit), int(window), _ptr(order), _ptr(ws), wsb, _stream()),
+               "pp_tile_order")
+    return order[:n]
 
 
 def kernel_map_transpose(nbr, n_in):
@@ -263,7 +280,8 @@ def pack_weight(weight, transpose=False):
     return packed
 
 
-def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None):
+def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
+               row_order=None):
     lib = _lib.load()
     in0 = _need(in0, torch.float32, "in0")
     in1 = _need(in1, torch.float32, "in1")
@@ -282,7 +300,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
-                                 _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd")
+                                 _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out), _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None))

@@ -12,6 +12,32 @@ import bench  # noqa: E402
 from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, synthetic as syn  # noqa: E402
 
 
+def vorder_stats(cm, ts, name, W=16384):
+    """useful@16 of every map INTO level ts when its rows are processed in (window, parity, same-level mask) order"""
+    lvl = cm.level(ts)
+    n = lvl.n
+    same = cm.kernel_map(ts, ts, 3, 1)
+    K = 27
+    bits = ((same >= 0).to(torch.int64) << torch.arange(K, device=same.device)[:, None]).sum(0)
+    q = (lvl.coords[:, 1:].to(torch.int64) + 32768) // ts
+    par = (q[:, 0] & 1) | ((q[:, 1] & 1) << 1) | ((q[:, 2] & 1) << 2)
+    key = ((torch.arange(n, device=same.device) // W) << 30) | (par << 27) | bits
+    order = torch.sort(key)[1]
+    out = [name]
+    for label, m in (("same", same), ("up", cm.maps.get((ts * 2, ts, 3, -1))), ("down", cm.maps.get((ts // 2, ts, 3, 1)) if ts > 1 else None)):
+        if m is None:
+            continue
+        v = (m >= 0)
+        P = int(v.sum())
+        for tag, vv in (("phys", v), ("vord", v[:, order])):
+            mm = (n + 15) // 16 * 16
+            pad = torch.zeros((K, mm), dtype=torch.bool, device=same.device)
+            pad[:, :n] = vv
+            act = pad.view(K, mm // 16, 16).any(2)
+            out.append("%s %s %.3f" % (label, tag, P / (float(act.sum()) * 16)))
+    print("| " + " | ".join(out) + " |")
+
+
 def stats(nbr, name):
     K, n = nbr.shape
     valid = nbr >= 0
@@ -70,6 +96,9 @@ def main():
         stats(cm.kernel_map(ts, ts2, 3, 1), "ts%d->%d down" % (ts, ts2))
         stats(cm.kernel_map(ts2, ts, 3, -1), "ts%d->%d up" % (ts2, ts))
         ts = ts2
+    print()
+    for ts in (1, 2, 4, 8):
+        vorder_stats(cm, ts, "level ts%d" % ts)
 
 
 if __name__ == "__main__":

@@ -406,6 +406,38 @@ def test_morton_order_and_derived_maps(ops, oracle):
     assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))
 
 
+def test_tile_schedule_changes_nothing_but_the_order(ops, oracle):
+    """pp_tile_order is a permutation grouping rows by (window, parity, mask); pp_spconv_fwd gives bit-identical output
+    with and without it (same per-row summation order), also with cat / BN / ReLU / residual fused."""
+    rng = np.random.default_rng(32)
+    fine = surface(rng, n=5000, n_batch=2, extent=70)
+    fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+    idx, _ = ops.block_index_build(dev(fine), 1, 4)
+    nbr = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1, want_mask=True)
+    mask = nbr.pp_mask.cpu().numpy().astype(np.int64)
+    want_mask = ((nbr.cpu().numpy() >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+    assert np.array_equal(mask, want_mask)
+    order = ops.tile_order(dev(fine), nbr.pp_mask, 1, 1024)
+    o = order.cpu().numpy()
+    n = len(fine)
+    assert np.array_equal(np.sort(o), np.arange(n))
+    par = (fine[:, 1] & 1) | ((fine[:, 2] & 1) << 1) | ((fine[:, 3] & 1) << 2)
+    key = ((o // 1024).astype(np.int64) << 30) | (par[o].astype(np.int64) << 27) | mask[o]
+    assert np.all(np.diff(key) >= 0)
+    for cin, cout, c1 in [(16, 16, 0), (64, 64, 0), (32, 48, 32), (96, 80, 0)]:
+        x = rng.normal(size=(n, cin)).astype(np.float32)
+        x1 = rng.normal(size=(n, c1)).astype(np.float32) if c1 else None
+        w = (rng.normal(size=(27, cin + c1, cout)) * 0.1).astype(np.float32)
+        res = rng.normal(size=(n, cout)).astype(np.float32)
+        sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+        kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+        a = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), nbr, n, cout, 27, **kw)
+        b = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), nbr, n, cout, 27, row_order=order, **kw)
+        assert torch.equal(a, b)
+        want = oracle.spconv_fwd(x, w, nbr.cpu().numpy(), n, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
+        np.testing.assert_allclose(b.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("block_bits", [0, 4, 5])
 def test_block_index_maps_match_oracle(ops, oracle, block_bits):
     """kernel maps looked up through the block index (bitmap + popcount) == oracle maps, all map kinds, incl. voxels at
