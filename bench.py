@@ -226,8 +226,19 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": prof["flops"] / secs / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None  # PMC pass is a separate rocprofv3 run, see profiles/
-        roof.update({"kernel": "k_spconv_fwd", "launches_per_step": prof["launches"] // max(args.steps, 1),
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json;
+        # a PMC pass cannot run inside the timed bench), next to the algorithmic bytes per launch it is compared with
+        roof["traffic"] = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+            except Exception:
+                pass
+        roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)
+        roof.update({"kernel": "k_spconv_fwd3 (pp_spconv_fwd)", "launches_per_step": prof["launches"] // max(args.steps, 1),
                      "avg_launch_us": 1e3 * prof["ms"] / max(prof["launches"], 1),
                      "alg_GB_per_step": prof["bytes"] / args.steps / 1e9, "alg_TFLOP_per_step": prof["flops"] / args.steps / 1e12,
                      "hbm_GBps": prof["bytes"] / secs / 1e9, "mfma_TFLOPs": prof["flops"] / secs / 1e12,
