@@ -1,6 +1,9 @@
 """Training-step micro-benchmark (BASELINE.json configs[4] shape on ONE GPU, fp32 like the reference):
 batch of 4 cylinders, forward (train-mode BN through the HIP statistics kernels) + losses + backward through every
-sparse convolution + Adam step.  usage (GPU box): python profiles/train_microbench.py [n_cylinders] [voxels_per_cyl]"""
+sparse convolution + (N > 1: bucketed gradient all-reduce) + Adam step.
+usage (GPU box): python profiles/train_microbench.py [n_cylinders] [voxels_per_cyl]
+data parallel:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 profiles/train_microbench.py
+                 (every rank trains on its own batch of n_cylinders; PP_DIST_BACKEND=gloo to try it on one GPU)"""
 import os
 import sys
 import time
@@ -13,6 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from panopticsegforlargescalepointcloud_amd import synthetic as syn  # noqa: E402
 from panopticsegforlargescalepointcloud_amd.applications import Data  # noqa: E402
+from panopticsegforlargescalepointcloud_amd.training import train_step  # noqa: E402
 
 
 def make_batch(scene, tiles, ids):
@@ -35,10 +39,16 @@ def make_batch(scene, tiles, ids):
 def main():
     ncyl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 80_000
-    dev = torch.device("cuda")
-    scene, tiles, _ = bench.build_scene(per * 4, 2, 0.05, 2022)
-    model = bench.build_model(dev, 0.05)[0].train()
-    data, n = make_batch(scene, tiles, list(range(ncyl)))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get("PP_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    scene, tiles, _ = bench.build_scene(per * 4 * world, 2 * world, 0.05, 2022)
+    model = bench.build_model(dev, 0.05)[0].train()   # same seed on every rank => identical replicas
+    ids = [(rank * ncyl + i) % len(tiles) for i in range(ncyl)]
+    data, n = make_batch(scene, tiles, ids)
     data = data.to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     for epoch, tag in [(1, "epoch <= prepare_epoch (heads + losses)"), (100, "epoch > prepare_epoch (+ grouping, ScorerUnet, score loss)")]:
@@ -46,16 +56,22 @@ def main():
         for it in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            model.set_input(data, dev)
-            opt.zero_grad(set_to_none=True)
-            model.forward(epoch=epoch)
-            model.backward(epoch)
-            opt.step()
+            train_step(model, data, opt, epoch, dev, world)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         t = float(np.median(times[2:]))
-        print("%-62s %7.1f ms/step  %6.2f M points/s  (batch %d cylinders, %d voxels, loss %.4f)" %
-              (tag, 1e3 * t, n / t / 1e6, ncyl, n, float(model.loss)))
+        if world > 1:
+            # replicas must stay identical: compare a parameter checksum across ranks
+            chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+            allc = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(allc, chk)
+            assert all(abs(float(c) - float(allc[0])) < 1e-6 * max(1.0, abs(float(allc[0]))) for c in allc), "replicas diverged"
+        if rank == 0:
+            print("%-62s %7.1f ms/step  %6.2f M points/s  (%d rank(s) x %d cylinders, %d voxels/rank, loss %.4f)" %
+                  (tag, 1e3 * t, world * n / t / 1e6, world, ncyl, n, float(model.loss)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -83,3 +83,61 @@ def test_exchange_single_process_is_identity():
     r = _tile_results(3, 4000)
     out = exchange_tile_results(r)
     assert sorted(out) == [0, 1, 2] and all(torch.equal(out[t][1], r[t][1]) for t in r)
+
+
+# ---------------------------------------------------------------- data-parallel gradient averaging (config C5)
+def _dp_model():
+    torch.manual_seed(5)
+    return torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(),
+                               torch.nn.Linear(300, 7), torch.nn.Linear(7, 3))  # last layer: never used -> no gradient
+
+
+def _dp_batch(rank):
+    g = torch.Generator().manual_seed(50 + rank)
+    return torch.randn(64, 40, generator=g), torch.randn(64, 7, generator=g)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticsegforlargescalepointcloud_amd.training import allreduce_gradients
+    model = _dp_model()
+    x, y = _dp_batch(rank)
+    loss = torch.nn.functional.mse_loss(model[:5](x), y)
+    loss.backward()
+    if rank == 1:  # a parameter that got a gradient on ONE rank only must still be reduced on both
+        model[5].weight.grad = torch.ones_like(model[5].weight)
+    n_buckets = allreduce_gradients(list(model.parameters()), world, bucket_bytes=200_000)
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    q.put((rank, n_buckets, flat.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    from panopticsegforlargescalepointcloud_amd.training import gradient_buckets
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected: mean of the two ranks' gradients (missing gradients count as zeros)
+    grads = []
+    for rank in range(world):
+        model = _dp_model()
+        x, y = _dp_batch(rank)
+        torch.nn.functional.mse_loss(model[:5](x), y).backward()
+        if rank == 1:
+            model[5].weight.grad = torch.ones_like(model[5].weight)
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()]))
+    want = ((grads[0] + grads[1]) / 2).numpy()
+    for rank, n_buckets, blob in got:
+        np.testing.assert_allclose(np.frombuffer(blob, np.float32), want, rtol=1e-6, atol=1e-7)
+        assert n_buckets == len(gradient_buckets(list(_dp_model().parameters()), 200_000)) and n_buckets >= 2
