@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict_
   const int d = deg[g];
   for (int t = sl; t < d; t += 16) {
     int j = list[g * nsample + t];
-    if (VL[j] > lk) {
+    // L[j] <= j always, so a neighbour with j <= lk cannot be improved: skip its label load.  In the first sweep
+    // (lk = g) that is every smaller-index neighbour -- with nsample = 200 on collapsed instances almost all of them.
+    if (j > lk && VL[j] > lk) {
       int old = atomicMin(&L[j], lk);
       if (old > lk) ch = true;
     }
