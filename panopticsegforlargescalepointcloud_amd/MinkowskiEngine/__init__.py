@@ -447,8 +447,9 @@ class MinkowskiBatchNorm(nn.Module):
     def folded(self):
         """(scale, shift) of the eval-mode affine map, cached until a parameter/buffer changes."""
         bn = self.bn
-        tag = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-               bn.weight.data_ptr(), bn.weight.device)
+        p, b = bn._parameters, bn._buffers  # direct dict access: nn.Module.__getattr__ costs ~1 us per attribute
+        w, bias, mean, var = p["weight"], p["bias"], b["running_mean"], b["running_var"]
+        tag = (w._version, bias._version, mean._version, var._version, w.data_ptr())
         if self._folded is None or self._folded[0] != tag:
             with torch.no_grad():
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
