@@ -54,3 +54,90 @@ def thing_panoptic_quality(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes, io
             pqs.append(sq * rq)
     out["PQ"] = float(np.mean(pqs)) if pqs else 0.0
     return out
+
+
+def panoptic_evaluation(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes=(2, 3, 4, 6, 7, 8), stuff_classes=(0, 1, 5),
+                        num_classes=9, iou_threshold=0.5):
+    """The reference's final scene evaluation (torch_points3d/datasets/panoptic/npm3d.py:107-397, `final_eval`) restated
+    with one (prediction, ground-truth) contingency table instead of per-pair boolean masks and per-point loops.
+    Labels are 0-based like the reference's inputs (ground truth -1 = unlabelled); instance id -1 = none.
+    Quirks kept on purpose: classes are those with ground-truth POINTS; only points that are thing in the ground truth
+    or in the prediction enter the instance part; an instance's class is the (smallest) mode of its semantic labels;
+    a prediction is a true positive when its best IoU with a ground-truth instance OF ITS CLASS reaches the threshold
+    (no one-to-one matching); the mIoU numerator also carries class "unlabelled" when it occurs.
+    Returns a dict of the quantities the reference logs (means over the classes present in the ground truth)."""
+    pred_sem = np.asarray(pred_sem).reshape(-1).astype(np.int64) + 1
+    gt_sem = np.asarray(gt_sem).reshape(-1).astype(np.int64) + 1
+    pred_ins = np.asarray(pred_ins).reshape(-1).astype(np.int64)
+    gt_ins = np.asarray(gt_ins).reshape(-1).astype(np.int64)
+    C = num_classes + 1
+    things = np.asarray(thing_classes, np.int64) + 1
+    stuff = np.asarray(stuff_classes, np.int64) + 1
+    # ---- semantic part
+    gt_cnt = np.bincount(gt_sem, minlength=C).astype(np.float64)
+    pr_cnt = np.bincount(pred_sem, minlength=C).astype(np.float64)
+    tp_cnt = np.bincount(gt_sem[gt_sem == pred_sem], minlength=C).astype(np.float64)
+    have = gt_cnt > 0
+    iou = np.where(have, tp_cnt / np.maximum(gt_cnt + pr_cnt - tp_cnt, 1), 0.0)
+    sem_final = [c for c in range(1, C) if have[c]]
+    out = {"oAcc": tp_cnt.sum() / pr_cnt.sum(), "mAcc": float(np.mean(tp_cnt[sem_final] / gt_cnt[sem_final])),
+           "IoU": iou, "mIoU": float(iou.sum() / len(sem_final))}
+    # ---- instances: only points that are thing in gt or prediction
+    is_thing = np.zeros(C, bool)
+    is_thing[things] = True
+    keep = is_thing[gt_sem] | is_thing[pred_sem]
+    ps, gs, pi, gi = pred_sem[keep], gt_sem[keep], pred_ins[keep], gt_ins[keep]
+
+    def groups(ids, sem):
+        m = ids != -1
+        u, inv = np.unique(ids[m], return_inverse=True)
+        full = np.full(len(ids), -1, np.int64)
+        full[m] = inv
+        size = np.bincount(inv, minlength=len(u))
+        cls = _mode_per_group(inv, sem[m], len(u), C) if len(u) else np.zeros(0, np.int64)
+        return full, size, cls
+    pid, p_size, p_cls = groups(pi, ps)
+    gid, g_size, g_cls = groups(gi, gs)
+    both = (pid >= 0) & (gid >= 0)
+    ng = max(len(g_size), 1)
+    pairs, inter = np.unique(pid[both] * ng + gid[both], return_counts=True)
+    pa, ga = pairs // ng, pairs % ng
+    pair_iou = inter / (p_size[pa] + g_size[ga] - inter)
+    same = p_cls[pa] == g_cls[ga]
+    best_p = np.zeros(len(p_size))
+    np.maximum.at(best_p, pa[same], pair_iou[same])
+    best_g = np.zeros(len(g_size))
+    np.maximum.at(best_g, ga[same], pair_iou[same])
+    mucov, mwcov, prec, rec, rq, sq, pq = (np.zeros(C) for _ in range(7))
+    for c in range(C):
+        gm, pm = g_cls == c, p_cls == c
+        if gm.any() and pm.any():
+            mucov[c] = best_g[gm].mean()
+            mwcov[c] = (best_g[gm] * g_size[gm]).sum() / g_size[gm].sum()
+        if pm.any():
+            tp_mask = pm & (best_p >= iou_threshold) & bool(gm.any())
+            tp = float(tp_mask.sum())
+            prec[c] = tp / pm.sum()
+            rec[c] = tp / gm.sum() if gm.any() else 0.0
+            rq[c] = 2 * prec[c] * rec[c] / (prec[c] + rec[c]) if prec[c] + rec[c] > 0 else 0.0
+            sq[c] = best_p[tp_mask].sum() / tp if tp else 0.0
+            pq[c] = sq[c] * rq[c]
+    thing_only = np.zeros(C, bool)
+    thing_only[things] = True
+    prec, rec, rq, sq, pq = (np.where(thing_only, v, 0.0) for v in (prec, rec, rq, sq, pq))
+    for c in stuff:
+        ok = iou[c] >= iou_threshold
+        rq[c], sq[c] = (1.0, iou[c]) if ok else (0.0, 0.0)
+        pq[c] = rq[c] * sq[c]
+    things_final = [c for c in things if have[c]]
+    stuff_final = [c for c in stuff if have[c]]
+    mp, mr = float(np.mean(prec[things_final])), float(np.mean(rec[things_final]))
+    out.update({
+        "MUCov": mucov[things], "mMUCov": float(np.mean(mucov[things_final])), "MWCov": mwcov[things],
+        "mMWCov": float(np.mean(mwcov[things_final])), "Precision": prec[things], "mPrecision": mp, "Recall": rec[things],
+        "mRecall": mr, "F1": 2 * mp * mr / (mp + mr) if mp + mr > 0 else 0.0,
+        "RQ": rq[1:], "SQ": sq[1:], "PQ": pq[1:], "meanRQ": float(np.mean(rq[sem_final])), "meanSQ": float(np.mean(sq[sem_final])),
+        "meanPQ": float(np.mean(pq[sem_final])), "PQ_things": pq[things], "meanRQ_things": float(np.mean(rq[things_final])),
+        "meanSQ_things": float(np.mean(sq[things_final])), "meanPQ_things": float(np.mean(pq[things_final])),
+        "PQ_stuff": pq[stuff], "meanPQ_stuff": float(np.mean(pq[stuff_final])) if stuff_final else 0.0})
+    return out

@@ -239,10 +239,77 @@ def make_hdbscan():
     print("hdbscan:", {k: int(cases["labels_" + k].max()) + 1 for k in names})
 
 
+def make_final_eval():
+    """Runs the reference's OWN final_eval (torch_points3d/datasets/panoptic/npm3d.py:107-397) on synthetic label arrays.
+    The module itself cannot be imported (torch_geometric, omegaconf, ...), so the function definition is extracted
+    from the file with `ast` and executed with numpy/scipy; it only logs its results, so the log lines are parsed."""
+    import ast
+    import re
+    import tempfile
+    from scipy import stats
+    path = os.path.join(REF, "torch_points3d/datasets/panoptic/npm3d.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "final_eval"][0]
+    ns = {"np": np, "stats": stats, "os": os, "write_ply": lambda *a, **k: None, "torch": torch}
+    if not hasattr(np, "int"):
+        np.int, np.float = int, float  # removed from numpy >= 1.24; the reference was written against 1.19
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(77)
+    cases, names = {}, []
+    for t in range(4):
+        n = 6000
+        n_inst = 25
+        gt_ins = rng.integers(0, n_inst, size=n)
+        thing = np.array([2, 3, 4, 6, 7, 8])
+        stuff = np.array([0, 1, 5])
+        inst_cls = np.where(rng.random(n_inst) < 0.75, rng.choice(thing, n_inst), rng.choice(stuff, n_inst))
+        if t == 3:
+            inst_cls[inst_cls == 7] = 6               # a thing class without ground truth
+        gt_sem = inst_cls[gt_ins]
+        gt_ins_lab = np.where(np.isin(gt_sem, stuff), -1, gt_ins)
+        unl = rng.random(n) < 0.03
+        gt_sem = np.where(unl, -1, gt_sem)
+        gt_ins_lab = np.where(unl, -1, gt_ins_lab)
+        pred_sem = np.where(rng.random(n) < 0.85, np.maximum(gt_sem, 0), rng.integers(0, 9, size=n))
+        pred_ins = np.where(np.isin(pred_sem, stuff), -1, gt_ins + 100)
+        # split / merge / drop some predicted instances
+        split = rng.random(n) < 0.2
+        pred_ins = np.where((pred_ins >= 0) & split & (gt_ins % 3 == 0), pred_ins + 1000, pred_ins)
+        pred_ins = np.where((pred_ins >= 0) & (gt_ins % 7 == 1), 107, pred_ins)
+        pred_ins = np.where((pred_ins >= 0) & (gt_ins % 11 == 5), -1, pred_ins)
+        pos = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32))
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                ns["final_eval"](pred_sem.copy(), pred_ins.copy(), pred_ins.copy(), pos, gt_sem.copy(), gt_ins_lab.copy())
+                log = open("evaluation.txt").read()
+            finally:
+                os.chdir(cwd)
+        name = "e%d" % t
+        names.append(name)
+        cases["pred_sem_" + name], cases["pred_ins_" + name] = pred_sem.astype(np.int64), pred_ins.astype(np.int64)
+        cases["gt_sem_" + name], cases["gt_ins_" + name] = gt_sem.astype(np.int64), gt_ins_lab.astype(np.int64)
+        for line in log.splitlines():
+            if ":" not in line:
+                continue
+            key, val = line.split(":", 1)
+            nums = [float(v) for v in re.findall(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?|nan", val)]
+            if nums:
+                cases["log_%s_%s" % (name, re.sub(r"[^A-Za-z0-9]+", "_", key.strip()))] = np.asarray(nums)
+    cases["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "final_eval_cases.npz"), **cases)
+    print("final_eval:", {k: cases[k].tolist() for k in cases if k.startswith("log_e0_") and ("mean" in k or "mIoU" in k or "F1" in k)})
+
+
 if __name__ == "__main__":
+    if "--final-eval-only" in sys.argv:
+        make_final_eval()
+        sys.exit(0)
     make_hdbscan()
     if "--hdbscan-only" in sys.argv:
         sys.exit(0)
     make_meanshift()
     make_losses()
     make_nms()
+    make_final_eval()
