@@ -434,6 +434,7 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
         self._folded = None
+        self._fold_fast = None
 
     # bn_schedulers.py:6-31 sets `.momentum` on the module
     @property
@@ -446,6 +447,8 @@ class MinkowskiBatchNorm(nn.Module):
 
     def folded(self):
         """(scale, shift) of the eval-mode affine map, cached until a parameter/buffer changes."""
+        if self._fold_fast is not None and not torch.is_grad_enabled():
+            return self._fold_fast  # inference fast path: validated once per eval()/load_state_dict (see train())
         bn = self.bn
         p, b = bn._parameters, bn._buffers  # direct dict access: nn.Module.__getattr__ costs ~1 us per attribute
         w, bias, mean, var = p["weight"], p["bias"], b["running_mean"], b["running_var"]
@@ -455,7 +458,22 @@ class MinkowskiBatchNorm(nn.Module):
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
                 shift = bn.bias - bn.running_mean * scale
             self._folded = (tag, scale.contiguous(), shift.contiguous())
+        if not self.training:
+            self._fold_fast = (self._folded[1], self._folded[2])
         return self._folded[1], self._folded[2]
+
+    def train(self, mode=True):
+        self._fold_fast = None  # re-validate the folded affine after any switch of mode (weights may have been trained)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._fold_fast = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): parameters are replaced
+        self._fold_fast = None
+        self._folded = None
+        return super()._apply(fn, *args, **kwargs)
 
     def features_forward(self, feats, relu=False):
         bn = self.bn

@@ -240,7 +240,10 @@ class PointGroup3heads(nn.Module):
             batch_cluster = Data(x=backbone_features[pts], coords=self.input.coords[pts], batch=b, pos=None)
             out = self.ScorerUnet(batch_cluster)
             cluster_feats = scatter(out.x, b, dim=0, reduce="max", dim_size=hi - lo)
-            scores.append(self.ScorerHead(cluster_feats).squeeze(-1))
+            # Linear(16, 1) + Sigmoid written as a reduction: a [P,16]x[16,1] GEMM goes through hipBLASLt, whose
+            # dispatch costs milliseconds of host time per call for 0.1 ms of work
+            lin = self.ScorerHead[0]
+            scores.append(torch.sigmoid((cluster_feats * lin.weight[0]).sum(1) + lin.bias[0]))
         return (scores[0] if len(scores) == 1 else torch.cat(scores)), None
 
     # ------------------------------------------------------------------ losses / backward

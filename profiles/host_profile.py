@@ -1,5 +1,6 @@
 import cProfile, pstats, sys, io
-sys.argv = ["bench.py", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--points", "1400000", "--grid", "3"]
+sys_points = sys.argv[1] if len(sys.argv) > 1 else "1400000"
+sys.argv = ["bench.py", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--points", sys_points, "--grid", "3"]
 sys.path.insert(0, "/root/repo")
 import runpy
 pr = cProfile.Profile()
@@ -11,5 +12,5 @@ except SystemExit:
 pr.disable()
 s = io.StringIO()
 ps = pstats.Stats(pr, stream=s).sort_stats("tottime")
-ps.print_stats(28)
-print(s.getvalue()[:6000])
+ps.print_stats(45)
+print(s.getvalue()[:9000])
