@@ -32,15 +32,84 @@
 
 struct HDDesc {
   int32_t lo, hi, q0, s;
+  int32_t t0, pad0, pad1, pad2;  // t0: global number of the sample's first candidate tile (tile = HD_TILE consecutive points)
 };
 
 struct HDArgs {
   const float* x;
   const HDDesc* desc;
+  const double* tlo;  // per candidate tile: bounding box (HD_MAXD doubles each)
+  const double* thi;
   int dim;
   double* core2;
   int32_t* comp;
   const int32_t* active;  // per sample: still more than one component
+};
+
+// Bounding box of every candidate tile.  Pruning rule used by both scans: the squared distance from a query to the box,
+// accumulated with the SAME operations and order as a point distance (t = gap; d += t * t), is a lower bound of the
+// computed distance to every point of the tile -- each rounding step is monotone -- so a tile whose bound cannot beat
+// the query's current best is skipped without changing any result.
+__global__ __launch_bounds__(HD_TILE) void k_hd_tile_bbox(const float* __restrict__ x, const HDDesc* __restrict__ desc,
+                                                          int dim, double* tlo, double* thi) {
+  // grid.x = query blocks; a query block covers HD_QPB / HD_TILE consecutive tiles of its sample
+  __shared__ double slo[HD_TILE / 64][HD_MAXD], shi[HD_TILE / 64][HD_MAXD];
+  const HDDesc d = desc[blockIdx.x];
+  for (int sub = 0; sub < HD_QPB / HD_TILE; ++sub) {
+    const int j0 = d.q0 + sub * HD_TILE;
+    if (j0 >= d.hi) break;
+    const int j = j0 + (int)threadIdx.x;
+    const int tile = d.t0 + (j0 - d.lo) / HD_TILE;
+    for (int c = 0; c < HD_MAXD; ++c) {
+      double v = (c < dim && j < d.hi) ? (double)x[(size_t)j * dim + c] : 0.0;
+      double lo = (c < dim && j < d.hi) ? v : INFINITY, hi = (c < dim && j < d.hi) ? v : -INFINITY;
+      for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, off));
+        hi = fmax(hi, __shfl_xor(hi, off));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6][c] = lo;
+        shi[threadIdx.x >> 6][c] = hi;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD_MAXD) {
+      double lo = slo[0][threadIdx.x], hi = shi[0][threadIdx.x];
+      for (int w = 1; w < HD_TILE / 64; ++w) {
+        lo = fmin(lo, slo[w][threadIdx.x]);
+        hi = fmax(hi, shi[w][threadIdx.x]);
+      }
+      if ((int)threadIdx.x >= dim) lo = hi = 0.0;
+      tlo[(size_t)tile * HD_MAXD + threadIdx.x] = lo;
+      thi[(size_t)tile * HD_MAXD + threadIdx.x] = hi;
+    }
+    __syncthreads();
+  }
+}
+__device__ inline double hd_box_dist2(const double* q, const double* lo, const double* hi, int D) {
+  double d2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < HD_MAXD; ++c)
+    if (c < D) {
+      const double a = lo[c] - q[c], b = q[c] - hi[c];
+      const double t = fmax(fmax(a, b), 0.0);
+      d2 += t * t;
+    }
+  return d2;
+}
+// tiles are visited outwards from the query block's own tile (nearest in index = nearest in space for voxel-sorted
+// points), so the bounds tighten early: visit order c, c+1, c-1, c+2, ...
+struct HDTileWalk {
+  int up, down, n, step;
+  __device__ HDTileWalk(int centre, int ntiles) : up(centre), down(centre - 1), n(ntiles), step(0) {}
+  __device__ int next() {  // -1 when exhausted
+    for (;;) {
+      if (up >= n && down < 0) return -1;
+      const bool take_up = (step++ & 1) == 0;
+      if (take_up && up < n) return up++;
+      if (!take_up && down >= 0) return down--;
+    }
+  }
 };
 
 template <int KMAX>
@@ -61,9 +130,25 @@ __global__ __launch_bounds__(HD_TPB) void k_hd_core(HDArgs A, const int32_t* kth
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) best[u][k] = INFINITY;
   }
-  for (int j0 = d.lo; j0 < d.hi; j0 += HD_TILE) {
+  const int ntiles = (d.hi - d.lo + HD_TILE - 1) / HD_TILE;
+  HDTileWalk walk((d.q0 - d.lo) / HD_TILE, ntiles);
+  for (int tl = walk.next(); tl >= 0; tl = walk.next()) {
+    const int j0 = d.lo + tl * HD_TILE;
     const int cnt = min(HD_TILE, d.hi - j0);
-    __syncthreads();
+    // skip the tile when no query of the block can still lower its kth-smallest distance with it
+    const double* blo = A.tlo + (size_t)(d.t0 + tl) * HD_MAXD;
+    const double* bhi = A.thi + (size_t)(d.t0 + tl) * HD_MAXD;
+    bool need = false;
+#pragma unroll
+    for (int u = 0; u < HD_Q; ++u)
+      if (qi[u] < d.hi) {
+        double bk = best[u][0];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k == kth) bk = best[u][k];
+        need = need || hd_box_dist2(q[u], blo, bhi, D) < bk;
+      }
+    if (!__syncthreads_or(need)) continue;
     if ((int)threadIdx.x < cnt) {
 #pragma unroll
       for (int c = 0; c < HD_MAXD; ++c)
@@ -145,9 +230,20 @@ __global__ __launch_bounds__(HD_TPB) void k_hd_best_edge(HDArgs A, HDRound R) {
   // is the whole query block inside one component?  (then single-component tiles of it can be skipped outright)
   const int c00 = A.comp[d.q0];
   const int blk_uniform = __syncthreads_and(qc[0] == c00 && qc[1] == c00);
-  for (int j0 = d.lo; j0 < d.hi; j0 += HD_TILE) {
+  const int ntiles = (d.hi - d.lo + HD_TILE - 1) / HD_TILE;
+  HDTileWalk walk((d.q0 - d.lo) / HD_TILE, ntiles);
+  for (int tl = walk.next(); tl >= 0; tl = walk.next()) {
+    const int j0 = d.lo + tl * HD_TILE;
     const int cnt = min(HD_TILE, d.hi - j0);
-    __syncthreads();
+    // bound test first: a tile whose box is farther than every query's current best edge cannot contribute
+    // (w >= d2 >= box distance; ties need w == best, which a strictly larger bound excludes)
+    const double* blo = A.tlo + (size_t)(d.t0 + tl) * HD_MAXD;
+    const double* bhi = A.thi + (size_t)(d.t0 + tl) * HD_MAXD;
+    bool need = false;
+#pragma unroll
+    for (int u = 0; u < HD_Q; ++u)
+      if (qi[u] < d.hi) need = need || hd_box_dist2(q[u], blo, bhi, D) <= bw[u];
+    if (!__syncthreads_or(need)) continue;
     int mine = A.comp[j0];
     if ((int)threadIdx.x < cnt) {
 #pragma unroll
@@ -478,6 +574,7 @@ extern "C" size_t pp_hdbscan_workspace(int64_t m, int32_t n_samples) {
   const size_t mm = (size_t)std::max<int64_t>(m, 1), ns = (size_t)std::max<int32_t>(n_samples, 1);
   size_t b = 0;
   b += pp_align((mm / HD_QPB + ns + 2) * sizeof(HDDesc));
+  b += 2 * pp_align((mm / HD_TILE + ns + 2) * HD_MAXD * 8);  // tile bounding boxes
   b += 8 * pp_align((ns + 2) * 4);
   b += 5 * pp_align(mm * 8);          // core2, pw, pe, cw, ce
   b += 8 * pp_align(mm * 4);          // comp, next, parent, eu, ev, slot_sample, perm a/b
@@ -509,7 +606,7 @@ extern "C" int pp_hdbscan(const float* x, int64_t m, int32_t dim, const int64_t*
   std::vector<int32_t> h_offs(ns + 1), h_ok(ns), h_eoff(ns + 1), h_ncomp(ns), h_active(ns), h_kth(ns);
   int max_kth = 0;
   std::vector<HDDesc> h_desc;
-  int64_t max_n = 0, n_edges = 0;
+  int64_t max_n = 0, n_edges = 0, n_tiles = 0;
   for (int s = 0; s <= ns; ++s) {
     PP_REQUIRE(s == 0 || sample_offsets[s] >= sample_offsets[s - 1], "pp_hdbscan: sample_offsets must be non-decreasing");
     h_offs[s] = (int32_t)sample_offsets[s];
@@ -529,13 +626,17 @@ extern "C" int pp_hdbscan(const float* x, int64_t m, int32_t dim, const int64_t*
       max_n = std::max<int64_t>(max_n, n);
       max_kth = std::max(max_kth, h_kth[s]);
     }
-    for (int q0 = h_offs[s]; q0 < h_offs[s + 1]; q0 += HD_QPB) h_desc.push_back({h_offs[s], h_offs[s + 1], q0, s});
+    for (int q0 = h_offs[s]; q0 < h_offs[s + 1]; q0 += HD_QPB)
+      h_desc.push_back({h_offs[s], h_offs[s + 1], q0, s, (int32_t)n_tiles, 0, 0, 0});
+    n_tiles += (n + HD_TILE - 1) / HD_TILE;
   }
   h_eoff[ns] = (int32_t)n_edges;
   const unsigned nblk = (unsigned)h_desc.size();
 
   PPArena ar(workspace, workspace_bytes);
   HDDesc* desc = ar.take<HDDesc>(mm / HD_QPB + ns + 2);
+  double* tlo = ar.take<double>((mm / HD_TILE + ns + 2) * HD_MAXD);
+  double* thi = ar.take<double>((mm / HD_TILE + ns + 2) * HD_MAXD);
   int32_t* offs = ar.take<int32_t>(ns + 2);
   int32_t* eoff = ar.take<int32_t>(ns + 2);
   int32_t* ok = ar.take<int32_t>(ns + 2);
@@ -591,7 +692,8 @@ extern "C" int pp_hdbscan(const float* x, int64_t m, int32_t dim, const int64_t*
   PP_HIP(hipStreamSynchronize(st));
 
   if (nblk > 0 && n_edges > 0) {
-    HDArgs A{x, desc, dim, core2, comp, active};
+    HDArgs A{x, desc, tlo, thi, dim, core2, comp, active};
+    k_hd_tile_bbox<<<nblk, HD_TILE, 0, st>>>(x, desc, dim, tlo, thi);
     HDRound R{pw, pe, cw, ce, next, parent, ncomp, nedge, eu, ev, ew};
     // core distances; the neighbour rank is per sample (clamped for tiny samples, see h_kth)
     if (max_kth < 8) k_hd_core<8><<<nblk, HD_TPB, 0, st>>>(A, kths);
