@@ -99,7 +99,7 @@ struct BQScan {
 };
 
 // counts hits with local index <= T; optionally appends them to buf (LDS, capacity BQ_CAP) and/or out
-__device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_t* out, int out_cap) {
+__device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_t* out, int out_cap, int64_t out_stride) {
   int total = 0;
   for (int c = 0; c < 27; ++c) {
     const int st = __shfl(s.my_start, c);
@@ -119,7 +119,7 @@ __device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_
       if (hit) {
         int pos = total + __popcll(m & ((1ull << lane) - 1ull));
         if (buf && pos < BQ_CAP) buf[pos] = idx;
-        if (out && pos < out_cap) out[pos] = idx;
+        if (out && pos < out_cap) out[(int64_t)pos * out_stride] = idx;
       }
       total += __popcll(m);
     }
@@ -127,19 +127,26 @@ __device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_
   return total;
 }
 
+// Neighbour lists are stored "t-major" in cell-sorted point order: list[t * M + p] = t-th neighbour (a local index) of
+// the point at cell-sorted position p, so that the lanes of a wave (consecutive p) read and write consecutive words.
+//
+// Fallback: one wave per query, for the queries the cell kernel below could not serve (neighbourhood larger than its LDS
+// buffer, or hash-aliased cells).  Hits are compacted into an LDS buffer; beyond nsample hits the nsample-th smallest
+// index is found by bisection.
 __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                     const uint64_t* __restrict__ keys,
                                                     const int32_t* __restrict__ cell_start,
                                                     const int32_t* __restrict__ cell_end, int64_t cap, int64_t M,
-                                                    float radius, int nsample, int32_t* __restrict__ list,
+                                                    float radius, int nsample, const int32_t* __restrict__ fb_list,
+                                                    const int32_t* __restrict__ fb_count, int32_t* __restrict__ list,
                                                     int32_t* __restrict__ deg) {
   __shared__ int lds[4][BQ_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t p = (int64_t)blockIdx.x * 4 + wave;
-  if (p >= M) return;
+  const int n_fb = fb_count[0];
   int* buf = lds[wave];
+  for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < n_fb; w += (int64_t)gridDim.x * 4) {
+  const int64_t p = fb_list[w];
   const float4 q = spos[p];
-  const int a = __float_as_int(q.w);
   BQScan s;
   s.spos = spos; s.sbc = sbc; s.qx = q.x; s.qy = q.y; s.qz = q.z; s.r2 = radius * radius; s.qbc = sbc[p];
   s.my_start = 0; s.my_cnt = 0;
@@ -153,16 +160,16 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
       s.my_cnt = cell_end[slot] - s.my_start;
     }
   }
-  int32_t* out = list + (int64_t)a * nsample;
-  const int total = bq_scan(s, lane, 0x7FFFFFFF, buf, nullptr, 0);
+  int32_t* out = list + p;  // column p, stride M
+  const int total = bq_scan(s, lane, 0x7FFFFFFF, buf, nullptr, 0, 0);
   if (total <= nsample) {
     if (total <= BQ_CAP) {
-      for (int t = lane; t < total; t += 64) out[t] = buf[t];
+      for (int t = lane; t < total; t += 64) out[(int64_t)t * M] = buf[t];
     } else {
-      bq_scan(s, lane, 0x7FFFFFFF, nullptr, out, nsample);
+      bq_scan(s, lane, 0x7FFFFFFF, nullptr, out, nsample, M);
     }
-    if (lane == 0) deg[a] = total;
-    return;
+    if (lane == 0) deg[p] = total;
+    continue;
   }
   // more than nsample hits: threshold T = nsample-th smallest local index (indices are distinct)
   int lo = 0, hi = (int)M - 1;
@@ -174,36 +181,154 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
       if (c >= nsample) hi = mid; else lo = mid + 1;
     }
-    int w = 0;
+    int wpos = 0;
     for (int t0 = 0; t0 < total; t0 += 64) {
       int t = t0 + lane;
       bool keep = t < total && buf[t] <= lo;
       unsigned long long m = __ballot(keep);
-      if (keep) out[w + __popcll(m & ((1ull << lane) - 1ull))] = buf[t];
-      w += __popcll(m);
+      if (keep) out[(int64_t)(wpos + __popcll(m & ((1ull << lane) - 1ull))) * M] = buf[t];
+      wpos += __popcll(m);
     }
   } else {
     while (lo < hi) {
       int mid = lo + ((hi - lo) >> 1);
-      int c = bq_scan(s, lane, mid, nullptr, nullptr, 0);
+      int c = bq_scan(s, lane, mid, nullptr, nullptr, 0, 0);
       if (c >= nsample) hi = mid; else lo = mid + 1;
     }
-    bq_scan(s, lane, lo, nullptr, out, nsample);
+    bq_scan(s, lane, lo, nullptr, out, nsample, M);
   }
-  if (lane == 0) deg[a] = nsample;
+  if (lane == 0) deg[p] = nsample;
+  }
+}
+
+// Main ball query: one workgroup per occupied cell.  The same-(batch,class) points of the 27 neighbouring cells are
+// staged in LDS once, sorted by local index (bitonic), and every query of the cell (one lane each) walks them in
+// ascending index order -- broadcast LDS reads, no global traffic -- appending hits until it has nsample of them:
+// exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
+#define BQC_CAP 2048
+__global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
+                                                          const uint64_t* __restrict__ keys,
+                                                          const int32_t* __restrict__ cell_start,
+                                                          const int32_t* __restrict__ cell_end, int64_t cap, int64_t M,
+                                                          float radius, int nsample,
+                                                          const int32_t* __restrict__ cell_p0,
+                                                          const int32_t* __restrict__ n_cells, int32_t* __restrict__ list,
+                                                          int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count) {
+  __shared__ float cx[BQC_CAP], cy[BQC_CAP], cz[BQC_CAP];
+  __shared__ int ca[BQC_CAP];
+  __shared__ int nb_start[27], nb_cnt[27];
+  __shared__ int n_in, total_sh;
+  const int tid = threadIdx.x;
+  const float r2 = radius * radius;
+  const int ncell = n_cells[0];
+  for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const int p0 = cell_p0[c], p1 = c + 1 < ncell ? cell_p0[c + 1] : (int)M;
+    const float4 q0 = spos[p0];
+    const int bc0 = sbc[p0];
+    const int ccx = (int)floorf(q0.x / radius), ccy = (int)floorf(q0.y / radius), ccz = (int)floorf(q0.z / radius);
+    __syncthreads();  // previous cell's LDS contents are dead
+    if (tid < 27) {
+      int st = 0, cn = 0;
+      int64_t slot = pp_hash_find_slot(keys, cap, rg_cell_key(bc0, ccx + (tid % 3 - 1), ccy + ((tid / 3) % 3 - 1), ccz + (tid / 9 - 1)));
+      if (slot >= 0) {
+        st = cell_start[slot];
+        cn = cell_end[slot] - st;
+      }
+      nb_start[tid] = st;
+      nb_cnt[tid] = cn;
+    }
+    if (tid == 0) n_in = 0;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int k = 0; k < 27; ++k) t += nb_cnt[k];
+      total_sh = t;
+    }
+    __syncthreads();
+    if (total_sh > BQC_CAP) {  // too many candidates for the buffer: hand the whole cell to the per-query kernel
+      for (int qq = p0 + tid; qq < p1; qq += 256) fb_list[atomicAdd(fb_count, 1)] = qq;
+      continue;
+    }
+    for (int k = 0; k < 27; ++k) {
+      const int st = nb_start[k], cn = nb_cnt[k];
+      for (int t = tid; t < cn; t += 256) {
+        if (sbc[st + t] == bc0) {
+          const float4 pt = spos[st + t];
+          const int w = atomicAdd(&n_in, 1);
+          cx[w] = pt.x; cy[w] = pt.y; cz[w] = pt.z; ca[w] = __float_as_int(pt.w);
+        }
+      }
+    }
+    __syncthreads();
+    const int ncand = n_in;
+    int npad = 2;
+    while (npad < ncand) npad <<= 1;
+    for (int t = ncand + tid; t < npad; t += 256) ca[t] = 0x7FFFFFFF;
+    __syncthreads();
+    // bitonic sort by local index, payload = the three coordinates
+    for (int k2 = 2; k2 <= npad; k2 <<= 1) {
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < npad; t += 256) {
+          const int l = t ^ j;
+          if (l > t) {
+            const int va = ca[t], vb = ca[l];
+            const bool up = (t & k2) == 0;
+            if ((va > vb) == up) {
+              ca[t] = vb; ca[l] = va;
+              float f;
+              f = cx[t]; cx[t] = cx[l]; cx[l] = f;
+              f = cy[t]; cy[t] = cy[l]; cy[l] = f;
+              f = cz[t]; cz[t] = cz[l]; cz[l] = f;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int qq = p0 + tid; qq < p1; qq += 256) {
+      const float4 q = spos[qq];
+      // hash-aliased slot (another cell or class behind the same key): leave the query to the per-query kernel
+      if (sbc[qq] != bc0 || (int)floorf(q.x / radius) != ccx || (int)floorf(q.y / radius) != ccy ||
+          (int)floorf(q.z / radius) != ccz) {
+        fb_list[atomicAdd(fb_count, 1)] = qq;
+        continue;
+      }
+      int cnt = 0;
+      for (int j = 0; j < ncand; ++j) {
+        const float dx = q.x - cx[j], dy = q.y - cy[j], dz = q.z - cz[j];
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d2 < r2) {
+          list[(int64_t)cnt * M + qq] = ca[j];
+          if (++cnt == nsample) break;
+        }
+      }
+      deg[qq] = cnt;
+    }
+  }
+}
+
+// run starts of the cell-sorted order -> list of occupied cells
+__global__ __launch_bounds__(256) void k_rg_cell_flags(const uint32_t* __restrict__ sorted_slot, int64_t M, int32_t* flag) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < M) flag[p] = (p == 0 || sorted_slot[p - 1] != sorted_slot[p]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_rg_cell_list(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank,
+                                                      int64_t M, int32_t* cell_p0) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < M && flag[p]) cell_p0[rank[p]] = (int32_t)p;
 }
 
 // ---------------------------------------------------------------------------------------------
-// label propagation (16 lanes per point)
+// label propagation: one lane per point (cell-sorted position p; labels live in local-index space)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict__ list, const int32_t* __restrict__ deg,
-                                                      int32_t* L, int32_t* pushed, int64_t M, int nsample,
-                                                      int32_t* changed) {
-  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int sl = threadIdx.x & 15;
-  if (g >= M) return;
+                                                      const float4* __restrict__ spos, int32_t* L, int32_t* pushed,
+                                                      int64_t M, int32_t* changed) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int g = __float_as_int(spos[p].w);
   volatile int32_t* VL = L;
-  int lk0 = VL[g];
+  const int lk0 = VL[g];
   int lk = lk0;
   for (;;) {  // pointer jumping: L[x] <= x always, and L[L[k]] is an ancestor of k
     int pnt = VL[lk];
@@ -211,25 +336,22 @@ __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict_
     lk = pnt;
   }
   bool ch = false;
-  if (sl == 0 && lk < lk0) {
+  if (lk < lk0) {
     atomicMin(&L[g], lk);
     ch = true;
   }
   // frontier: a point re-walks its neighbour list only when it has a smaller label to push than last time
   // (labels only decrease, so a label already pushed can never be needed again by the same neighbours)
-  if (pushed[g] <= lk) {
-    if (ch) changed[0] = 1;
-    return;
-  }
-  if (sl == 0) pushed[g] = lk;
-  const int d = deg[g];
-  for (int t = sl; t < d; t += 16) {
-    int j = list[g * nsample + t];
-    // L[j] <= j always, so a neighbour with j <= lk cannot be improved: skip its label load.  In the first sweep
-    // (lk = g) that is every smaller-index neighbour -- with nsample = 200 on collapsed instances almost all of them.
-    if (j > lk && VL[j] > lk) {
-      int old = atomicMin(&L[j], lk);
-      if (old > lk) ch = true;
+  if (pushed[p] > lk) {
+    pushed[p] = lk;
+    const int d = deg[p];
+    for (int t = 0; t < d; ++t) {
+      const int j = list[(int64_t)t * M + p];
+      // L[j] <= j always, so a neighbour with j <= lk cannot be improved: skip its label load
+      if (j > lk && VL[j] > lk) {
+        int old = atomicMin(&L[j], lk);
+        if (old > lk) ch = true;
+      }
     }
   }
   if (ch) changed[0] = 1;
@@ -431,8 +553,18 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   if (rc) return rc;
   hipLaunchKernelGGL(k_rg_cells, dim3(mb), dim3(256), 0, s, sorted_slot, sorted_local, M, pos, sel, bc, cell_start,
                      cell_end, spos, sbc);
-  hipLaunchKernelGGL(k_ball_query, dim3(pp_blocks(M, 4)), dim3(256), 0, s, spos, sbc, ckeys, cell_start, cell_end, cap,
-                     M, radius, nsample, list, deg);
+  // occupied cells = runs of equal slot in the sorted order (flag / rank / slot_of / local are free by now)
+  int32_t* cell_p0 = (int32_t*)slot_of;
+  int32_t* fb_list = (int32_t*)rkey2;  // free until the root sort below
+  hipLaunchKernelGGL(k_rg_cell_flags, dim3(mb), dim3(256), 0, s, sorted_slot, M, flag);
+  PP_LAUNCH_CHECK();
+  rc = pp_exclusive_scan_i32(flag, rank, M, misc + 4, ar.cur(), ar.left(), s);  // misc[4] = number of cells
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_rg_cell_list, dim3(mb), dim3(256), 0, s, flag, rank, M, cell_p0);
+  hipLaunchKernelGGL(k_ball_query_cells, dim3((unsigned)std::min<int64_t>(M, 4096)), dim3(256), 0, s, spos, sbc, ckeys,
+                     cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg, fb_list, misc + 5);
+  hipLaunchKernelGGL(k_ball_query, dim3((unsigned)std::min<int64_t>(pp_blocks(M, 4), 2048)), dim3(256), 0, s, spos, sbc,
+                     ckeys, cell_start, cell_end, cap, M, radius, nsample, fb_list, misc + 5, list, deg);
   hipLaunchKernelGGL(k_iota, dim3(mb), dim3(256), 0, s, L, M);
   int32_t* pushed = size;  // reused as the cluster-size array once the fixpoint is reached
   hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks(M)), dim3(256), 0, s, pushed, 0x7FFFFFFF, M);
@@ -441,8 +573,7 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   for (int round = 0; round < 4096; ++round) {
     PP_HIP(hipMemsetAsync(misc + 2, 0, sizeof(int32_t), s));
     for (int it = 0; it < 4; ++it)
-      hipLaunchKernelGGL(k_rg_propagate, dim3(pp_blocks(M * 16, 256)), dim3(256), 0, s, list, deg, L, pushed, M, nsample,
-                         misc + 2);
+      hipLaunchKernelGGL(k_rg_propagate, dim3(mb), dim3(256), 0, s, list, deg, spos, L, pushed, M, misc + 2);
     PP_LAUNCH_CHECK();
     PP_HIP(hipMemcpyAsync(h, misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PP_HIP(hipStreamSynchronize(s));
