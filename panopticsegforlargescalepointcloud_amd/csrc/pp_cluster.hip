@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
 // staged in LDS once, sorted by local index (bitonic), and every query of the cell (one lane each) walks them in
 // ascending index order -- broadcast LDS reads, no global traffic -- appending hits until it has nsample of them:
 // exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
-#define BQC_CAP 2048
+#define BQC_CAP 1536
 __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                           const uint64_t* __restrict__ keys,
                                                           const int32_t* __restrict__ cell_start,
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
                                                           const int32_t* __restrict__ cell_p0,
                                                           const int32_t* __restrict__ n_cells, int32_t* __restrict__ list,
                                                           int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count) {
-  __shared__ float cx[BQC_CAP], cy[BQC_CAP], cz[BQC_CAP];
-  __shared__ int ca[BQC_CAP];
-  __shared__ int nb_start[27], nb_cnt[27];
-  __shared__ int n_in, total_sh;
+  __shared__ float4 raw[BQC_CAP];   // candidates as loaded: 27 runs, each ascending in local index (.w)
+  __shared__ float4 cand[BQC_CAP];  // merged: ascending in local index
+  __shared__ int nb_start[27], nb_cnt[27], nb_off[28];
+  __shared__ int n_bad;
   const int tid = threadIdx.x;
   const float r2 = radius * radius;
   const int ncell = n_cells[0];
@@ -237,70 +237,92 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
       nb_start[tid] = st;
       nb_cnt[tid] = cn;
     }
-    if (tid == 0) n_in = 0;
+    if (tid == 0) n_bad = 0;
     __syncthreads();
     if (tid == 0) {
       int t = 0;
-      for (int k = 0; k < 27; ++k) t += nb_cnt[k];
-      total_sh = t;
+      for (int k = 0; k < 27; ++k) {
+        nb_off[k] = t;
+        t += nb_cnt[k];
+      }
+      nb_off[27] = t;
     }
     __syncthreads();
-    if (total_sh > BQC_CAP) {  // too many candidates for the buffer: hand the whole cell to the per-query kernel
+    const int total = nb_off[27];
+    bool fallback = total > BQC_CAP;  // too many candidates for the buffer
+    if (!fallback) {
+      // flat over all candidates: every lane busy, a few rounds instead of 27
+      int bad = 0;
+      for (int f = tid; f < total; f += 256) {
+        int lo = 0, hi = 27;  // run of slot f: last k with nb_off[k] <= f
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (nb_off[mid] <= f) lo = mid; else hi = mid;
+        }
+        const int src = nb_start[lo] + (f - nb_off[lo]);
+        raw[f] = spos[src];
+        bad += sbc[src] != bc0 ? 1 : 0;  // another (batch, class) behind an aliased cell key
+      }
+      if (bad) atomicAdd(&n_bad, bad);
+      __syncthreads();
+      fallback = n_bad != 0;
+    }
+    if (fallback) {  // hand the whole cell to the per-query kernel
       for (int qq = p0 + tid; qq < p1; qq += 256) fb_list[atomicAdd(fb_count, 1)] = qq;
       continue;
     }
-    for (int k = 0; k < 27; ++k) {
-      const int st = nb_start[k], cn = nb_cnt[k];
-      for (int t = tid; t < cn; t += 256) {
-        if (sbc[st + t] == bc0) {
-          const float4 pt = spos[st + t];
-          const int w = atomicAdd(&n_in, 1);
-          cx[w] = pt.x; cy[w] = pt.y; cz[w] = pt.z; ca[w] = __float_as_int(pt.w);
-        }
+    // 27-way merge by ranking: position = own offset in its run + number of smaller indices in every other run
+    // (indices are distinct; every run is ascending) -- ~26 short binary searches per candidate instead of a full sort
+    for (int f = tid; f < total; f += 256) {
+      int lo = 0, hi = 27;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (nb_off[mid] <= f) lo = mid; else hi = mid;
       }
+      const float4 me = raw[f];
+      const int key = __float_as_int(me.w);
+      int pos = f - nb_off[lo];
+      for (int k = 0; k < 27; ++k) {
+        const int n = nb_cnt[k];
+        if (k == lo || n == 0) continue;
+        const float4* run = raw + nb_off[k];
+        int a0 = 0, a1 = n;  // first element of the run with index > key
+        while (a0 < a1) {
+          const int mid = (a0 + a1) >> 1;
+          if (__float_as_int(run[mid].w) < key) a0 = mid + 1; else a1 = mid;
+        }
+        pos += a0;
+      }
+      cand[pos] = me;
     }
     __syncthreads();
-    const int ncand = n_in;
-    int npad = 2;
-    while (npad < ncand) npad <<= 1;
-    for (int t = ncand + tid; t < npad; t += 256) ca[t] = 0x7FFFFFFF;
-    __syncthreads();
-    // bitonic sort by local index, payload = the three coordinates
-    for (int k2 = 2; k2 <= npad; k2 <<= 1) {
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < npad; t += 256) {
-          const int l = t ^ j;
-          if (l > t) {
-            const int va = ca[t], vb = ca[l];
-            const bool up = (t & k2) == 0;
-            if ((va > vb) == up) {
-              ca[t] = vb; ca[l] = va;
-              float f;
-              f = cx[t]; cx[t] = cx[l]; cx[l] = f;
-              f = cy[t]; cy[t] = cy[l]; cy[l] = f;
-              f = cz[t]; cz[t] = cz[l]; cz[l] = f;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
     for (int qq = p0 + tid; qq < p1; qq += 256) {
       const float4 q = spos[qq];
-      // hash-aliased slot (another cell or class behind the same key): leave the query to the per-query kernel
-      if (sbc[qq] != bc0 || (int)floorf(q.x / radius) != ccx || (int)floorf(q.y / radius) != ccy ||
-          (int)floorf(q.z / radius) != ccz) {
+      // hash-aliased slot (another cell behind the same key): leave the query to the per-query kernel
+      if ((int)floorf(q.x / radius) != ccx || (int)floorf(q.y / radius) != ccy || (int)floorf(q.z / radius) != ccz) {
         fb_list[atomicAdd(fb_count, 1)] = qq;
         continue;
       }
       int cnt = 0;
-      for (int j = 0; j < ncand; ++j) {
-        const float dx = q.x - cx[j], dy = q.y - cy[j], dz = q.z - cz[j];
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (d2 < r2) {
-          list[(int64_t)cnt * M + qq] = ca[j];
-          if (++cnt == nsample) break;
+      int j = 0;
+      for (; j + 4 <= total && cnt < nsample; j += 4) {  // four candidates per round: one LDS latency instead of four
+        float4 pc[4];
+        bool hit[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pc[u] = cand[j + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = q.x - pc[u].x, dy = q.y - pc[u].y, dz = q.z - pc[u].z;
+          hit[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (hit[u] && cnt < nsample) list[(int64_t)(cnt++) * M + qq] = __float_as_int(pc[u].w);
+      }
+      for (; j < total && cnt < nsample; ++j) {
+        const float4 pc = cand[j];
+        const float dx = q.x - pc.x, dy = q.y - pc.y, dz = q.z - pc.z;
+        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2) list[(int64_t)(cnt++) * M + qq] = __float_as_int(pc.w);
       }
       deg[qq] = cnt;
     }
