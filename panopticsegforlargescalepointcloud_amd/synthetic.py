@@ -48,6 +48,52 @@ def urban_points(n_points, extent, rng, objects_per_m2=0.12):
     return pos[inside], cls[inside], inst[inside]
 
 
+FOR_NUM_CLASSES = 2
+FOR_STUFF = (0,)  # torch_points3d/datasets/panoptic/treeins.py:34-36 (non-tree = stuff, tree = thing)
+
+
+def forest_points(n_points, extent, rng, trees_per_m2=0.04):
+    """FOR-instance-like raw points: 60 % ground, 40 % trees (stem = vertical cylinder r 0.2 m,
+    h ~15 m; crown = ellipsoid shell on top).  Returns pos, cls (0 ground / 1 tree), inst (0 = none)."""
+    n_ground = int(0.6 * n_points)
+    n_tree = n_points - n_ground
+    g = np.empty((n_ground, 3), np.float32)
+    g[:, :2] = rng.uniform(0, extent, size=(n_ground, 2))
+    g[:, 2] = 0.3 * np.sin(g[:, 0] / 7.0) + rng.normal(0, 0.03, n_ground)
+    n_inst = max(4, int(trees_per_m2 * extent * extent))
+    t_id = rng.integers(0, n_inst, n_tree)
+    cen = rng.uniform(0, extent, size=(n_inst, 2))
+    height = rng.uniform(10, 18, n_inst)
+    crown_r = rng.uniform(1.5, 3.0, n_inst)
+    is_stem = rng.random(n_tree) < 0.3
+    t = np.empty((n_tree, 3), np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n_tree)
+    # stems
+    t[:, 0] = cen[t_id, 0] + 0.2 * np.cos(ang)
+    t[:, 1] = cen[t_id, 1] + 0.2 * np.sin(ang)
+    t[:, 2] = rng.uniform(0, 1, n_tree) * height[t_id] * 0.7
+    # crowns: points on an ellipsoid shell around (cx, cy, 0.75 h)
+    u = rng.normal(size=(n_tree, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    cr = ~is_stem
+    t[cr, 0] = cen[t_id[cr], 0] + u[cr, 0] * crown_r[t_id[cr]]
+    t[cr, 1] = cen[t_id[cr], 1] + u[cr, 1] * crown_r[t_id[cr]]
+    t[cr, 2] = 0.75 * height[t_id[cr]] + u[cr, 2] * 0.3 * height[t_id[cr]]
+    pos = np.concatenate([g, t]).astype(np.float32)
+    cls = np.concatenate([np.zeros(n_ground, np.int64), np.ones(n_tree, np.int64)])
+    inst = np.concatenate([np.zeros(n_ground, np.int64), t_id + 1])
+    inside = (pos[:, 0] >= 0) & (pos[:, 0] <= extent) & (pos[:, 1] >= 0) & (pos[:, 1] <= extent)
+    return pos[inside], cls[inside], inst[inside]
+
+
+def forest_scene(n_voxels_target, voxel=0.10, seed=2022, raw_per_voxel=1.5):
+    rng = np.random.default_rng(seed)
+    extent = float(np.sqrt(0.6 * n_voxels_target / (0.7 / (voxel * voxel))))
+    pos, cls, inst = forest_points(int(n_voxels_target * raw_per_voxel), extent, rng)
+    pos, coords, cls, inst = voxelise(pos, cls, inst, voxel, rng)
+    return Scene(pos, coords, cls, inst, voxel, extent)
+
+
 def voxelise(pos, cls, inst, voxel, rng):
     """GridSampling3D(mode='last'): shuffle, keep one real point per voxel."""
     perm = rng.permutation(len(pos))
