@@ -250,6 +250,27 @@ int pp_hdbscan(const float* x /*[m,dim]*/, int64_t m, int32_t dim, const int64_t
                int32_t* labels /*[m]*/, int32_t* n_clusters /*[n_samples]*/, void* workspace,
                size_t workspace_bytes, pp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * f1  voxelisation + cylinder cutting (the step before the path)
+ * pp_voxelize       replaces: GridSampling3D(size, quantize_coords=True),
+ *                   torch_points3d/core/data_transform/grid_transform.py:181-198 (+ torch_geometric voxel_grid /
+ *                   consecutive_cluster): coords = round-half-even(pos / size); one row per occupied voxel ordered
+ *                   by (batch, z, y, x); rep_index[v] = LAST input point of voxel v (the reference shuffles first);
+ *                   inverse[i] = voxel row of point i; counts = {voxels, points outside the 16-bit range}.
+ *                   coords int32 [n,4] / rep_index [n] are capacities.
+ * pp_cylinder_pairs replaces: CylinderSampling (KDTree.query_radius, inclusive) for ALL centres at once,
+ *                   transforms.py:388-441: (point, cylinder) pairs, point-major; call once with NULL outputs to
+ *                   get n_pairs, then with buffers; pp_group_by_key(pair_cyl, pair_point) gives the index lists.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_voxelize_workspace(int64_t n);
+int pp_voxelize(const float* pos /*[n,3]*/, const int64_t* batch /*[n] or NULL*/, int64_t n, float voxel_size,
+                int32_t* coords, int32_t* rep_index, int32_t* inverse /*[n]*/, int32_t* counts /*int32[2]*/,
+                void* workspace, size_t workspace_bytes, pp_stream_t stream);
+size_t pp_cylinder_pairs_workspace(int64_t n);
+int pp_cylinder_pairs(const float* pos /*[n,3]*/, int64_t n, const float* centres_xy /*[n_cyl,2]*/, int32_t n_cyl,
+                      float radius, int64_t* pair_point, int32_t* pair_cyl, int64_t capacity, int32_t* n_pairs,
+                      void* workspace, size_t workspace_bytes, pp_stream_t stream);
+
 /* Group points by a small integer key into CSR form (stable: ascending point order inside a group).
  * key[i] in [0,n_groups) or -1 (dropped).  ids[i] (int64) is what gets written (NULL -> i).
  * offsets [n_groups+1], out [n] capacity, total[0] = #kept.  Used to turn labels into the

@@ -265,3 +265,33 @@ def proposal_intersections(clusters, n_points):
     _chk(lib().ppo_proposal_intersections(_p(offs), _p(pts), C.c_int32(n), C.c_int64(n_points), _p(inter)),
          "proposal_intersections")
     return inter
+
+
+# ------------------------------------------------------------------ f1: voxelisation / cylinder cutting (NumPy restatements)
+def voxelize(pos, voxel_size, batch=None):
+    """GridSampling3D(size, quantize_coords=True) -- torch_points3d/core/data_transform/grid_transform.py:181-198 with
+    torch_geometric's voxel_grid / consecutive_cluster: coords = round-half-even(pos / size) on the float32 quotient,
+    voxels ordered by (batch, z, y, x), representative = last point of the voxel in input order.
+    Returns (coords int32 [V,4] (b,x,y,z), rep_index int64 [V], inverse int64 [n])."""
+    pos = np.asarray(pos, np.float32)
+    n = len(pos)
+    b = np.zeros(n, np.int64) if batch is None else np.asarray(batch, np.int64)
+    q = np.rint(pos / np.float32(voxel_size)).astype(np.int64)
+    key = (b << 48) | ((q[:, 2] + 32768) << 32) | ((q[:, 1] + 32768) << 16) | (q[:, 0] + 32768)
+    uniq, inverse = np.unique(key, return_inverse=True)
+    rep = np.zeros(len(uniq), np.int64)
+    rep[inverse] = np.arange(n)  # later points overwrite earlier ones: the last point of each voxel wins
+    coords = np.stack([b[rep], q[rep, 0], q[rep, 1], q[rep, 2]], 1).astype(np.int32)
+    return coords, rep, inverse.astype(np.int64)
+
+
+def cylinder_tiles(pos, centres_xy, radius):
+    """CylinderSampling (KDTree.query_radius: inclusive) for every centre -- transforms.py:388-441; ascending indices."""
+    pos = np.asarray(pos, np.float32)
+    r2 = np.float32(radius) * np.float32(radius)
+    out = []
+    for c in np.asarray(centres_xy, np.float32):
+        dx, dy = pos[:, 0] - c[0], pos[:, 1] - c[1]
+        d2 = (dy.astype(np.float64) ** 2 + (dx * dx).astype(np.float64)).astype(np.float32)  # fmaf(dy, dy, dx * dx)
+        out.append(np.nonzero(d2 <= r2)[0])
+    return out

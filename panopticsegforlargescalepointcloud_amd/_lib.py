@@ -58,6 +58,10 @@ SIGNATURES = {
     "pp_meanshift": (C.c_int, [vp, i64, i32, vp, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]),
     "pp_hdbscan_workspace": (sz, [i64, i32]),
     "pp_hdbscan": (C.c_int, [vp, i64, i32, vp, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, sz, vp]),
+    "pp_voxelize_workspace": (sz, [i64]),
+    "pp_voxelize": (C.c_int, [vp, vp, i64, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_cylinder_pairs_workspace": (sz, [i64]),
+    "pp_cylinder_pairs": (C.c_int, [vp, i64, vp, i32, f32, vp, vp, i64, vp, vp, sz, vp]),
     "pp_group_by_key_workspace": (sz, [i64]),
     "pp_group_by_key": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
     "pp_segment_reduce_workspace": (sz, [i64]),

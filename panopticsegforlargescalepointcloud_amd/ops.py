@@ -567,6 +567,48 @@ def hdbscan(x, sample_offsets, min_cluster_size=15, min_samples=5, cluster_selec
     return labels[:m], ncl[:ns]
 
 
+def voxelize(pos, voxel_size, batch=None):
+    """GridSampling3D(quantize_coords=True) on the GPU: (coords int32 [V,4] (b,x,y,z), rep_index int64 [V], inverse int64 [n])."""
+    lib = _lib.load()
+    pos = _need(pos, torch.float32, "pos")
+    batch = _need(batch, torch.int64, "batch")
+    n = pos.shape[0]
+    dev = pos.device
+    coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+    rep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    wsb = lib.pp_voxelize_workspace(n)
+    ws = _ws(wsb, dev, tag="voxelize")
+    _lib.check(lib.pp_voxelize(_ptr(pos), _ptr(batch), n, float(voxel_size), _ptr(coords), _ptr(rep), _ptr(inv), _ptr(counts),
+                               _ptr(ws), wsb, _stream()), "pp_voxelize")
+    nv, bad = counts.tolist()
+    if bad:
+        raise _lib.PanopticHipError("%d points outside the +-32767-voxel coordinate range" % bad)
+    return coords[:nv], rep[:nv].long(), inv[:n].long()
+
+
+def cylinder_tiles(pos, centres_xy, radius):
+    """CylinderSampling for all centres at once -> ClusterCSR (one ascending index list per cylinder)."""
+    lib = _lib.load()
+    pos = _need(pos, torch.float32, "pos")
+    cen = _need(centres_xy, torch.float32, "centres_xy")
+    n, nc = pos.shape[0], cen.shape[0]
+    dev = pos.device
+    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.pp_cylinder_pairs_workspace(n)
+    ws = _ws(wsb, dev, tag="cylinders")
+    _lib.check(lib.pp_cylinder_pairs(_ptr(pos), n, _ptr(cen), nc, float(radius), None, None, 0, _ptr(n_pairs), _ptr(ws), wsb,
+                                     _stream()), "pp_cylinder_pairs")
+    total = int(n_pairs.item())
+    pp = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    pc = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.pp_cylinder_pairs(_ptr(pos), n, _ptr(cen), nc, float(radius), _ptr(pp), _ptr(pc), total, _ptr(n_pairs), _ptr(ws),
+                                     wsb, _stream()), "pp_cylinder_pairs")
+    offs, out, tot = group_by_key(pc[:total].contiguous(), nc, ids=pp[:total].contiguous())
+    return ClusterCSR(offs, out[:total], nc)
+
+
 def group_by_key(key, n_groups, ids=None):
     lib = _lib.load()
     key = _need(key, torch.int32, "key")

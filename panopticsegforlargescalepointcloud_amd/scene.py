@@ -17,6 +17,7 @@ from .applications import Data
 
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
+from . import ops  # noqa: E402
 from .ops import overlapping_pairs  # noqa: E402,F401  (kept importable from here)
 
 
@@ -239,3 +240,29 @@ class TileRunner:
         labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)
         self._tick("nms+paint", t0)
         return labels, res, counts
+
+
+def tile_batch_gpu(pos, coords, voxel, centres_xy, radius):
+    """Row f1 on the device: cut a voxelised scene (pos f32 [U,3], coords i32 [U,3], both on the GPU) into vertical
+    cylinders (`ops.cylinder_tiles`, CylinderSampling semantics) and collate them into one batch with the layout of
+    SURVEY.md 8 a0 -- pos centred per cylinder (z kept), integer coords shifted by the rounded centre, features
+    x = (x_rel, y_rel, z_rel, z), batch, origin_id -- exactly what `synthetic.tile_batch` builds with NumPy.
+    Returns a dict of device tensors plus `tiles` (ops.ClusterCSR of origin ids per cylinder)."""
+    dev = pos.device
+    tiles = ops.cylinder_tiles(pos, centres_xy, radius)
+    idx = tiles.points                                     # origin ids, tile-major, ascending inside a tile
+    sizes = tiles.sizes().long()
+    nt = tiles.n
+    b = torch.repeat_interleave(torch.arange(nt, device=dev), sizes)
+    p = pos[idx]
+    # float32 means exactly like NumPy's pairwise p.mean(0) are not reproducible with atomics: accumulate in float64
+    cen = torch.zeros((nt, 3), dtype=torch.float64, device=dev).index_add_(0, b, p.double())
+    cen = (cen / sizes.clamp(min=1)[:, None].double()).float()
+    cen[:, 2] = 0.0
+    pc = p - cen[b]
+    shift = torch.round(cen / voxel).to(torch.int32)
+    ci = coords[idx] - shift[b]
+    mean_pc = torch.zeros((nt, 3), dtype=torch.float64, device=dev).index_add_(0, b, pc.double())
+    mean_pc = (mean_pc / sizes.clamp(min=1)[:, None].double()).float()
+    x = torch.cat([pc - mean_pc[b], pc[:, 2:3]], 1)
+    return {"pos": pc, "coords": ci, "batch": b, "x": x, "origin_id": idx, "tiles": tiles}

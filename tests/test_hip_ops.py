@@ -512,3 +512,26 @@ def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
         got = ops.spconv_fwd_rb(dev(x[:, :h].copy()), ops.pack_weight(dev(W)), rb, cout, in1=dev(x[:, h:].copy()),
                                 scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_voxelize_and_cylinder_tiles_match_oracle(ops, oracle):
+    rng = np.random.default_rng(42)
+    pos = (rng.normal(0, 6, size=(60000, 3))).astype(np.float32)
+    pos[:500] = np.round(pos[:500] / 0.05) * 0.05 + 0.025
+    batch = np.sort(rng.integers(0, 4, size=len(pos)))
+    wc, wr, wi = oracle.voxelize(pos, 0.05, batch)
+    coords, rep, inv = ops.voxelize(dev(pos), 0.05, dev(batch))
+    assert np.array_equal(coords.cpu().numpy(), wc) and np.array_equal(rep.cpu().numpy(), wr)
+    assert np.array_equal(inv.cpu().numpy(), wi)
+    c2, r2, i2 = ops.voxelize(dev(pos), 0.12)                    # no batch vector
+    w2 = oracle.voxelize(pos, 0.12)
+    assert np.array_equal(c2.cpu().numpy(), w2[0]) and np.array_equal(r2.cpu().numpy(), w2[1])
+    cen = rng.uniform(-8, 8, size=(9, 2)).astype(np.float32)
+    csr = ops.cylinder_tiles(dev(pos), dev(cen), 3.0)
+    want = oracle.cylinder_tiles(pos, cen, 3.0)
+    got = csr.to_list()
+    assert len(got) == len(want) == 9
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
+    with pytest.raises(Exception):
+        ops.voxelize(dev(np.array([[1e9, 0, 0]], np.float32)), 0.05)

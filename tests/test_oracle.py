@@ -347,3 +347,30 @@ def test_proposal_intersections_match_dense_mm(oracle):
     for i, c in enumerate(clusters):
         mask[i, c] = 1
     assert np.array_equal(inter, (mask @ mask.T).astype(np.int32))
+
+
+# ---------------------------------------------------------------- f1: voxelisation / cylinders
+def test_voxelize_and_cylinders_restatements(oracle):
+    rng = np.random.default_rng(41)
+    pos = (rng.normal(0, 3, size=(5000, 3))).astype(np.float32)
+    pos[:200] = np.round(pos[:200] / 0.05) * 0.05 + 0.025          # exact .5 quotients: round-half-even matters
+    batch = np.sort(rng.integers(0, 3, size=5000))
+    coords, rep, inv = oracle.voxelize(pos, 0.05, batch)
+    # independent statement with torch: torch.round + unique rows
+    q = torch.round(torch.from_numpy(pos) / 0.05).long()
+    full = torch.cat([torch.from_numpy(batch)[:, None], q], 1)
+    uniq, inv_t = torch.unique(full[:, [0, 3, 2, 1]], dim=0, return_inverse=True)   # sort key (b, z, y, x)
+    assert len(uniq) == len(coords) and np.array_equal(inv, inv_t.numpy())
+    assert np.array_equal(coords, uniq[:, [0, 3, 2, 1]].numpy().astype(np.int32))
+    last = np.zeros(len(uniq), np.int64)
+    for i, v in enumerate(inv_t.tolist()):
+        last[v] = i
+    assert np.array_equal(rep, last)
+    # cylinders vs sklearn's KDTree (what CylinderSampling calls)
+    from sklearn.neighbors import KDTree
+    cen = rng.uniform(-4, 4, size=(7, 2)).astype(np.float32)
+    tiles = oracle.cylinder_tiles(pos, cen, 1.7)
+    tree = KDTree(pos[:, :2].astype(np.float64), leaf_size=50)
+    for c, t in zip(cen, tiles):
+        want = np.sort(tree.query_radius(c[None].astype(np.float64), r=1.7)[0])
+        assert len(np.setxor1d(t, want)) <= 1      # float32 vs float64 distance exactly at the rim

@@ -39,3 +39,30 @@ def test_scene_labels_and_pq_match_oracle():
     pq_cpu = thing_panoptic_quality(scene.cls, asm_cpu.ins_pre, scene.cls, scene.inst, syn.THING_CLASSES)
     assert abs(pq_gpu["PQ"] - pq_cpu["PQ"]) < 1e-9
     assert pq_gpu["PQ"] > 0.5  # synthetic head statistics are good, so grouping must recover most instances
+
+
+def test_tile_batch_on_the_gpu_matches_numpy_collation():
+    """voxelise -> cut cylinders -> collate on the GPU (row f1) vs the NumPy generator path on the same raw cloud."""
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd import ops, synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.scene import tile_batch_gpu
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(8)
+    raw, cls, inst = syn.urban_points(120_000, 30.0, rng)
+    coords, rep, inv = ops.voxelize(torch.from_numpy(raw).to(dev), 0.05)
+    wc, wr, _ = oracle.voxelize(raw, 0.05)
+    assert np.array_equal(rep.cpu().numpy(), wr)
+    pos_v = torch.from_numpy(raw).to(dev)[rep]                    # one REAL point per voxel
+    coords3 = coords[:, 1:].contiguous()
+    cen = torch.tensor([[8.0, 8.0], [16.0, 9.0], [22.0, 21.0], [9.0, 22.0]], device=dev)
+    got = tile_batch_gpu(pos_v, coords3, 0.05, cen, 7.5)
+    # NumPy side: same voxels, cylinders from the oracle, collation from the synthetic generator
+    scene = syn.Scene(raw[wr], wc[:, 1:], cls[wr], inst[wr], 0.05, 30.0)
+    tiles = oracle.cylinder_tiles(scene.pos, cen.cpu().numpy(), 7.5)
+    want = syn.tile_batch(scene, tiles, [0, 1, 2, 3])
+    assert np.array_equal(got["origin_id"].cpu().numpy(), want["origin_id"])
+    assert np.array_equal(got["batch"].cpu().numpy(), want["batch"])
+    assert np.array_equal(got["coords"].cpu().numpy(), want["coords"])
+    # the cylinder mean is accumulated in float64 on the GPU and in float32 (pairwise) by NumPy: ~1e-4 m apart
+    np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=3e-4)
+    np.testing.assert_allclose(got["x"].cpu().numpy(), want["x"], atol=5e-4)
