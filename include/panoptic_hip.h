@@ -131,8 +131,9 @@ int pp_tile_order(const int32_t* coords, const uint32_t* mask, int64_t n, int32_
  * The caller-visible row order of stride-1 tensors is unchanged (applications/minkowski.py:193).
  * info[1] = rows outside the key range. */
 size_t pp_morton_order_workspace(int64_t n);
-int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t block_bits, int32_t* perm, void* workspace,
-                    size_t workspace_bytes, int32_t* info /*int32[2]*/, pp_stream_t stream);
+int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t block_bits, int32_t* perm,
+                    int32_t* sorted_coords /*[n,4] or NULL: coords[perm], decoded from the sorted keys (no gather)*/,
+                    void* workspace, size_t workspace_bytes, int32_t* info /*int32[2]*/, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  sparse convolution forward  replaces: ME ConvolutionForward (gather-GEMM-scatter per offset),

@@ -90,10 +90,9 @@ class CoordinateManager:
         self.sorted = bool(reorder) and ORDER_BLOCK_BITS >= 0
         if self.sorted:
             if coords.shape[0] > 1:
-                self.perm = ops.morton_order(coords, 1, ORDER_BLOCK_BITS)
+                self.perm, coords = ops.morton_order(coords, 1, ORDER_BLOCK_BITS, want_sorted=True)
                 self.inv_perm = torch.empty_like(self.perm)
                 self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
-                coords = coords[self.perm].contiguous()
             index, ndup = ops.block_index_build(coords, 1, ORDER_BLOCK_BITS)
             level = _Level(coords, index=index)
         else:
@@ -147,7 +146,7 @@ class CoordinateManager:
             if self.sorted:
                 # first-appearance order of the parents follows the fine level only roughly: sort the level itself
                 if out.shape[0] > 1:
-                    out = out[ops.morton_order(out, ts_out, ORDER_BLOCK_BITS)].contiguous()
+                    out = ops.morton_order(out, ts_out, ORDER_BLOCK_BITS, want_sorted=True)[1]
                 index, _ = ops.block_index_build(out, ts_out, ORDER_BLOCK_BITS)
                 self.levels[ts_out] = _Level(out, index=index)
             else:

@@ -37,7 +37,7 @@ SIGNATURES = {
     "pp_tile_order_workspace": (sz, [i64]),
     "pp_tile_order": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, sz, vp]),
     "pp_morton_order_workspace": (sz, [i64]),
-    "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, sz, vp, vp]),
+    "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp, vp]),
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),

@@ -111,6 +111,25 @@ __host__ __device__ inline uint64_t pp_order_axis(uint32_t q, int axis, int bloc
   const uint64_t outer = pp_spread3_64(q >> block_bits);
   return ((outer << (3 * block_bits)) | (par << (3 * hb)) | inner) << axis;
 }
+// inverse of pp_order_axis: one axis' q from a key
+__host__ __device__ inline uint32_t pp_compact3_64(uint64_t x) {
+  x &= 0x1249249249249249ull;
+  x = (x | (x >> 2)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x >> 4)) & 0x100F00F00F00F00Full;
+  x = (x | (x >> 8)) & 0x1F0000FF0000FFull;
+  x = (x | (x >> 16)) & 0x1F00000000FFFFull;
+  x = (x | (x >> 32)) & 0xFFFFull;
+  return (uint32_t)x;
+}
+__host__ __device__ inline uint32_t pp_order_axis_inv(uint64_t key, int axis, int block_bits) {
+  key >>= axis;
+  if (block_bits <= 1) return pp_compact3_64(key);
+  const int hb = block_bits - 1;
+  const uint32_t inner = pp_compact3_64(key & ((1ull << (3 * hb)) - 1ull));
+  const uint32_t par = (uint32_t)((key >> (3 * hb)) & 1ull);
+  const uint32_t outer = pp_compact3_64(key >> (3 * block_bits));
+  return (outer << block_bits) | (inner << 1) | par;
+}
 __host__ __device__ inline uint64_t pp_order_key(int b, int x, int y, int z, int unit_shift, int block_bits) {
   return ((uint64_t)(uint16_t)b << 48) | pp_order_axis((uint32_t)(x + 32768) >> unit_shift, 0, block_bits) |
          pp_order_axis((uint32_t)(y + 32768) >> unit_shift, 1, block_bits) |

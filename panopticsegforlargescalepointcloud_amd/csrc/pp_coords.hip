@@ -257,12 +257,24 @@ __global__ __launch_bounds__(256) void k_morton_keys(const int4* __restrict__ co
   }
   idx[i] = (int32_t)i;
 }
+// rows in sorted order straight from the sorted keys (the key is a bijection of the coordinate): no gather needed
+__global__ __launch_bounds__(256) void k_morton_decode(const uint64_t* __restrict__ skey, int64_t n, int unit_shift,
+                                                       int block_bits, int4* out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = skey[i];
+  const uint64_t body = k & 0xFFFFFFFFFFFFull;
+  out[i] = make_int4((int)(k >> 48), (int)(pp_order_axis_inv(body, 0, block_bits) << unit_shift) - 32768,
+                     (int)(pp_order_axis_inv(body, 1, block_bits) << unit_shift) - 32768,
+                     (int)(pp_order_axis_inv(body, 2, block_bits) << unit_shift) - 32768);
+}
 extern "C" size_t pp_morton_order_workspace(int64_t n) {
   size_t m = (size_t)std::max<int64_t>(n, 1);
   return 2 * pp_align(m * 8) + pp_align(m * 4) + pp_sort_pairs_workspace(n) + 1024;
 }
 extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t block_bits, int32_t* perm,
-                               void* workspace, size_t workspace_bytes, int32_t* info, pp_stream_t stream) {
+                               int32_t* sorted_coords, void* workspace, size_t workspace_bytes, int32_t* info,
+                               pp_stream_t stream) {
   PP_REQUIRE(perm && info, "pp_morton_order: null output");
   PP_REQUIRE(unit >= 1 && (unit & (unit - 1)) == 0 && unit <= 16384, "pp_morton_order: unit must be a power of two");
   PP_REQUIRE(block_bits >= 0 && block_bits <= 8, "pp_morton_order: block_bits in [0,8]");
@@ -280,5 +292,12 @@ extern "C" int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, i
   hipLaunchKernelGGL(k_morton_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, n, key, idx, info,
                      unit_shift, block_bits);
   PP_LAUNCH_CHECK();
-  return pp_sort_pairs_u64(key, key2, idx, perm, n, 64, ar.cur(), ar.left(), s);
+  int rc = pp_sort_pairs_u64(key, key2, idx, perm, n, 64, ar.cur(), ar.left(), s);
+  if (rc) return rc;
+  if (sorted_coords) {  // only meaningful when info[1] == 0 (every row inside the key range)
+    hipLaunchKernelGGL(k_morton_decode, dim3(pp_blocks(n, 256)), dim3(256), 0, s, key2, n, unit_shift, block_bits,
+                       (int4*)sorted_coords);
+    PP_LAUNCH_CHECK();
+  }
+  return PP_OK;
 }

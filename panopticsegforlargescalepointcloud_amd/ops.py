@@ -256,8 +256,9 @@ def kernel_map_transpose(nbr, n_in):
     return out
 
 
-def morton_order(coords, unit=1, block_bits=0):
-    """perm (int64 [n]): rows of `coords` in batch-major Z-order (block_bits=0) or parity-grouped block order."""
+def morton_order(coords, unit=1, block_bits=0, want_sorted=False):
+    """perm (int64 [n]): rows of `coords` in batch-major Z-order (block_bits=0) or parity-grouped block order.
+    want_sorted: also return coords[perm], decoded from the sorted keys instead of gathered."""
     lib = _lib.load()
     coords = _need(coords, torch.int32, "coords")
     n = coords.shape[0]
@@ -266,7 +267,11 @@ def morton_order(coords, unit=1, block_bits=0):
     info = torch.zeros(2, dtype=torch.int32, device=dev)
     wsb = lib.pp_morton_order_workspace(n)
     ws = _ws(wsb, dev)
-    _lib.check(lib.pp_morton_order(_ptr(coords), n, int(unit), int(block_bits), _ptr(perm), _ptr(ws), wsb, _ptr(info), _stream()), "pp_morton_order")
+    srt = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) if want_sorted else None
+    _lib.check(lib.pp_morton_order(_ptr(coords), n, int(unit), int(block_bits), _ptr(perm), _ptr(srt), _ptr(ws), wsb, _ptr(info),
+                                   _stream()), "pp_morton_order")
+    if want_sorted:
+        return perm[:n].long(), srt[:n]
     return perm[:n].long()
 
 

@@ -395,6 +395,10 @@ def test_morton_order_and_derived_maps(ops, oracle):
         return (int(c[0]) << 48) | (z([v >> B for v in q], 16 - B) << (3 * B)) | (par << (3 * (B - 1))) | inner
     keys2 = [key2(c) for c in coarse2[p2]]
     assert keys2 == sorted(keys2) and len(set(keys2)) == len(keys2)
+    # coords[perm] decoded from the sorted keys == gathered, for every layout and unit
+    for unit, bb, arr in [(1, 0, fine), (1, 4, fine), (2, 3, coarse2), (2, 5, coarse2)]:
+        pm, srt = ops.morton_order(dev(arr), unit, bb, want_sorted=True)
+        assert np.array_equal(srt.cpu().numpy(), arr[pm.cpu().numpy()])
     # derived maps == probed maps
     table, _ = ops.hash_build(d)
     coarse, ctable, _ = ops.stride_coords(d, 2)
