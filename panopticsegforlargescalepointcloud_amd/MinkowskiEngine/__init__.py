@@ -187,6 +187,23 @@ class CoordinateManager:
 # ------------------------------------------------------------------------------------------------
 # sparse tensor
 # ------------------------------------------------------------------------------------------------
+class GatheredRows:
+    """`base[index]` that has not been gathered yet.  Passed as the features of a SparseTensor it is resolved together
+    with the internal row permutation in ONE gather (base[index[perm]]) -- the proposal scorer feeds millions of
+    duplicated backbone rows this way (PointGroup3heads._compute_score)."""
+
+    def __init__(self, base, index):
+        self.base, self.index = base, index
+        self.shape = (index.shape[0], base.shape[1])
+        self.device = base.device
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def materialise(self, perm=None):
+        return self.base[self.index if perm is None else self.index[perm]]
+
+
 class SparseTensor:
     """features + coordinate manager + tensor stride.  `feats` is the internal (Morton-ordered) feature matrix every
     kernel works on; `.F` / `.C` give the caller-visible view (row i of F belongs to row i of the coordinates passed
@@ -200,7 +217,10 @@ class SparseTensor:
             if dev.type != "cuda":
                 raise ops._lib.PanopticHipError("SparseTensor must live on a HIP device (no CPU fallback)")
             coordinate_manager = CoordinateManager(coordinates.to(dev))
-            features = coordinate_manager.to_internal(features.to(dev))
+            if isinstance(features, GatheredRows):
+                features = features.materialise(coordinate_manager.perm)
+            else:
+                features = coordinate_manager.to_internal(features.to(dev))
         self.feats = features
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = int(tensor_stride)

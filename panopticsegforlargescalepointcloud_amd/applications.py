@@ -176,7 +176,9 @@ class MinkowskiEncoder(BaseMinkowski):
 
 
 class MinkowskiUnet(BaseMinkowski):
-    def forward(self, data, *args, **kwargs):
+    def forward(self, data, *args, internal_order=False, **kwargs):
+        """internal_order=True returns features and batch ids in the coordinate manager's row order (no un-permute
+        gather) -- enough for order-independent consumers such as the per-proposal max of the scorer."""
         self._set_input(data)
         data = self.input
         stack_down = []
@@ -187,7 +189,10 @@ class MinkowskiUnet(BaseMinkowski):
         stack_down.append(None)
         for i in range(len(self.up_modules)):
             data = self.up_modules[i](data, stack_down.pop())
-        out = Data(x=data.F, pos=self.xyz, batch=data.C[:, 0])
+        if internal_order:
+            out = Data(x=data.feats, pos=None, batch=data.coordinate_manager.level(1).coords[:, 0])
+        else:
+            out = Data(x=data.F, pos=self.xyz, batch=data.C[:, 0])
         if self.has_mlp_head:
             out.x = self.mlp(out.x)
         return out

@@ -15,6 +15,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .. import MinkowskiEngine as ME
 from .. import ops
 from ..applications import Data, Minkowski
 from ..modules import MLP, Seq, fused_head
@@ -237,9 +238,10 @@ class PointGroup3heads(nn.Module):
             p0, p1 = int(offsets[lo].item()), int(offsets[hi].item())
             pts = csr.points[p0:p1]
             b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi])
-            batch_cluster = Data(x=backbone_features[pts], coords=self.input.coords[pts], batch=b, pos=None)
-            out = self.ScorerUnet(batch_cluster)
-            cluster_feats = scatter(out.x, b, dim=0, reduce="max", dim_size=hi - lo)
+            # one gather for "rows of the proposals" + "internal row order", none for the way back (the max is order-free)
+            batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
+            out = self.ScorerUnet(batch_cluster, internal_order=True)
+            cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo)
             # Linear(16, 1) + Sigmoid written as a reduction: a [P,16]x[16,1] GEMM goes through hipBLASLt, whose
             # dispatch costs milliseconds of host time per call for 0.1 ms of work
             lin = self.ScorerHead[0]
