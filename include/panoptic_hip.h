@@ -106,7 +106,18 @@ int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int32_t unit, 
                          int32_t* counts /*int32[4]*/, void* workspace, size_t workspace_bytes, pp_stream_t stream);
 int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
                         const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals, int64_t cap,
-                        int32_t* start, uint64_t* bits, uint16_t* pre, pp_stream_t stream);
+                        int32_t* start, uint64_t* bits, uint16_t* pre,
+                        uint64_t* bkey_ord /*[n_blocks] block keys in block order, may be NULL*/, pp_stream_t stream);
+/* The next coarser level (tensor stride unit_coarse = 2 x the indexed level's) computed from the index alone: with
+ * the parity-block order the coarse bitmaps are bit permutations of the fine ones (replaces K2, pp_stride_coords +
+ * sort + pp_block_index_* for strided convolutions, api_modules.py:256-271).  Output arrays have the capacities of
+ * the fine level (nb_fine blocks, cap = pp_block_index_capacity(nb_fine), n_fine rows for coords [.,4]);
+ * counts = {coarse blocks, coarse rows}.  Rows come out in the coarse level's own order. */
+size_t pp_block_index_coarsen_workspace(int64_t nb_fine);
+int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_bits, int64_t nb_fine, int32_t unit_coarse,
+                           int32_t block_bits, uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
+                           uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord, int32_t* coords, int32_t* counts /*int32[2]*/,
+                           void* workspace, size_t workspace_bytes, pp_stream_t stream);
 int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals, int64_t cap,
                      const int32_t* start, const uint64_t* bits, const uint16_t* pre, int32_t unit_src,
                      int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,

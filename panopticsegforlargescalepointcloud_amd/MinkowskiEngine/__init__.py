@@ -35,6 +35,8 @@ RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.0"))
 # internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order,
 # -1 = caller order with row-level hash tables)
 ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
+# build coarser levels from the finer level's block index (PP_COARSEN=0: hash + sort path, for A/B runs)
+COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
 # tile schedule window (rows): processing order of a level's rows = (window, parity, same-level neighbour mask); 0 = off.
 # OFF by default: it raises the useful share of executed MFMA tiles (0.31 -> 0.43 at the finest level) but the extra
 # indirection (scattered index loads / output stores, one radix sort per level) costs more than it saves end to end
@@ -142,6 +144,11 @@ class CoordinateManager:
         ts_out = ts_in * stride
         if ts_out not in self.levels:
             src = self.levels[ts_in]
+            if self.sorted and stride == 2 and ORDER_BLOCK_BITS == 4 and src.index is not None and COARSEN_FROM_INDEX:
+                # the coarse level is a bit permutation of the fine level's occupancy bitmaps: no hash, no sort
+                index, out = ops.block_index_coarsen(src.index, src.n)
+                self.levels[ts_out] = _Level(out, index=index)
+                return ts_out
             out, table, _ = ops.stride_coords(src.coords, ts_out)
             if self.sorted:
                 # first-appearance order of the parents follows the fine level only roughly: sort the level itself

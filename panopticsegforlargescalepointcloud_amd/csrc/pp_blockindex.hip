@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_bi_hash_fill(uint64_t* keys, int64_t ca
 __global__ __launch_bounds__(256) void k_bi_scatter(const int4* __restrict__ coords, int64_t n, int unit_shift,
                                                     int block_bits, const int32_t* __restrict__ row_block,
                                                     uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
-                                                    unsigned long long* bits) {
+                                                    unsigned long long* bits, uint64_t* bkey_ord) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_bi_scatter(const int4* __restrict__ coo
   if (i == 0 || row_block[i - 1] != b) {  // first row of the block: owns start[] and the hash entry
     start[b] = (int32_t)i;
     const uint64_t blk = key >> 12;
+    if (bkey_ord) bkey_ord[b] = blk;
     const uint64_t mask = (uint64_t)cap - 1;
     uint64_t s = pp_mix64(blk) & mask;
     for (;;) {
@@ -145,7 +146,8 @@ extern "C" int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int
 }
 extern "C" int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
                                    const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals,
-                                   int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, pp_stream_t stream) {
+                                   int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord,
+                                   pp_stream_t stream) {
   PP_REQUIRE(bkeys && bvals && start && bits && pre, "pp_block_index_fill: null output");
   PP_REQUIRE(cap >= 2 * n_blocks && (cap & (cap - 1)) == 0, "pp_block_index_fill: cap must be a power of two >= 2 n_blocks");
   hipStream_t s = pp_s(stream);
@@ -156,9 +158,168 @@ extern "C" int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int3
   if (n_blocks > 0) PP_HIP(hipMemsetAsync(bits, 0, sizeof(uint64_t) * BI_WORDS * (size_t)n_blocks, s));
   if (n == 0) return PP_OK;
   hipLaunchKernelGGL(k_bi_scatter, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords_sorted, n, unit_shift,
-                     block_bits, row_block, bkeys, bvals, cap, start, (unsigned long long*)bits);
+                     block_bits, row_block, bkeys, bvals, cap, start, (unsigned long long*)bits, bkey_ord);
   PP_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bi_prefix, dim3(pp_blocks(n_blocks, 4)), dim3(256), 0, s, bits, n_blocks, pre);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- next coarser level straight from the index (no row hash, no sort) -----------------------------------------------
+// With the parity-block key (block_bits = 4) the coarse level (tensor stride doubled: Q = q >> 1) is a pure function of
+// the fine level's bitmaps: the 8 fine blocks that share (q >> 5) form one coarse block; inside a fine block the coarse
+// voxel of a position depends only on its half coordinates h = (q >> 1) & 7 -- the eight parity copies collapse (OR) --
+// and lands at the coarse code  [h & 1 per axis][Z-order of (octant << 2 | h >> 1)].  Fine blocks are sorted, so the
+// children of a coarse block are consecutive.  Everything below works on blocks (~300 voxels each), not on rows.
+__device__ inline uint32_t bi_compact3_9(uint32_t z) {  // bits 0,3,6 -> 0,1,2
+  return (z & 1u) | ((z >> 2) & 2u) | ((z >> 4) & 4u);
+}
+__device__ inline uint32_t bi_spread3_3(uint32_t v) {  // bits 0,1,2 -> 0,3,6
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+__device__ inline uint64_t bi_parent_key(uint64_t fkey) {  // key >> 12 of the fine block -> key >> 12 of its coarse block
+  const uint64_t outer_mask = (1ull << 36) - 1ull;
+  return (fkey & ~outer_mask) | ((fkey & outer_mask) >> 3);
+}
+__global__ __launch_bounds__(256) void k_bic_flags(const uint64_t* __restrict__ fkey, int64_t nb, int32_t* flag) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) flag[b] = (b == 0 || bi_parent_key(fkey[b]) != bi_parent_key(fkey[b - 1])) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_bic_first_child(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank,
+                                                         int64_t nb, int32_t* first_child) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb && flag[b]) first_child[rank[b]] = (int32_t)b;
+}
+// one wave per coarse block: its bitmap from the children's bitmaps, its voxel count and key
+__global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ fbits,
+                                                  int64_t nb_f, const int32_t* __restrict__ first_child,
+                                                  const int32_t* __restrict__ n_coarse, uint64_t* cbits, int32_t* ccount,
+                                                  uint64_t* ckey) {
+  __shared__ unsigned long long lds[4][BI_WORDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbc = n_coarse[0];
+  const int64_t c = (int64_t)blockIdx.x * 4 + wave;
+  if (c >= nbc) return;
+  unsigned long long* w = lds[wave];
+  w[lane] = 0ull;
+  const int b0 = first_child[c], b1 = c + 1 < nbc ? first_child[c + 1] : (int)nb_f;
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t oct = (uint32_t)(fkey[b] & 7ull);  // low bits of the fine block's Z-order position: x, y, z
+    // lanes 0..7: word j of the octant's 512-bit occupancy = OR over the 8 parity copies
+    if (lane < 8) {
+      unsigned long long o = 0ull;
+#pragma unroll
+      for (int par = 0; par < 8; ++par) o |= fbits[(size_t)b * BI_WORDS + par * 8 + lane];
+      while (o) {
+        const int bit = __builtin_ctzll(o);
+        o &= o - 1ull;
+        const uint32_t z = (uint32_t)lane * 64u + (uint32_t)bit;  // Z-order of the half coordinates h (9 bits)
+        const uint32_t hx = bi_compact3_9(z), hy = bi_compact3_9(z >> 1), hz = bi_compact3_9(z >> 2);
+        const uint32_t par2 = (hx & 1u) | ((hy & 1u) << 1) | ((hz & 1u) << 2);
+        const uint32_t vx = ((oct & 1u) << 2) | (hx >> 1), vy = (((oct >> 1) & 1u) << 2) | (hy >> 1),
+                       vz = (((oct >> 2) & 1u) << 2) | (hz >> 1);
+        const uint32_t code = (par2 << 9) | bi_spread3_3(vx) | (bi_spread3_3(vy) << 1) | (bi_spread3_3(vz) << 2);
+        atomicOr(&w[code >> 6], 1ull << (code & 63u));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long mine = w[lane];
+  cbits[(size_t)c * BI_WORDS + lane] = mine;
+  int cnt = __popcll(mine);
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane == 0) {
+    ccount[c] = cnt;
+    ckey[c] = bi_parent_key(fkey[b0]);
+  }
+}
+// one wave per coarse block: prefix counts, hash entry, coordinate rows (decoded from block key + code)
+__global__ __launch_bounds__(256) void k_bic_finish(const uint64_t* __restrict__ ckey, const uint64_t* __restrict__ cbits,
+                                                    const int32_t* __restrict__ cstart, const int32_t* __restrict__ n_coarse,
+                                                    int unit_shift, uint64_t* bkeys, int32_t* bvals, int64_t cap,
+                                                    uint16_t* cpre, int4* coords) {
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_coarse[0]) return;
+  unsigned long long word = cbits[(size_t)c * BI_WORDS + lane];
+  const int cnt = __popcll(word);
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int before = incl - cnt;
+  cpre[(size_t)c * BI_WORDS + lane] = (uint16_t)before;
+  const uint64_t blk = ckey[c];
+  if (lane == 0) {
+    const uint64_t mask = (uint64_t)cap - 1;
+    uint64_t s = pp_mix64(blk) & mask;
+    for (;;) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&bkeys[s], (unsigned long long)PP_EMPTY_KEY,
+                                                (unsigned long long)blk);
+      if (prev == PP_EMPTY_KEY) {
+        bvals[s] = (int32_t)c;
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+  }
+  int row = cstart[c] + before;
+  while (word) {
+    const int bit = __builtin_ctzll(word);
+    word &= word - 1ull;
+    const uint64_t key = (blk << 12) | (uint64_t)(lane * 64 + bit);
+    const uint64_t body = key & 0xFFFFFFFFFFFFull;
+    coords[row++] = make_int4((int)(key >> 48), (int)(pp_order_axis_inv(body, 0, 4) << unit_shift) - 32768,
+                              (int)(pp_order_axis_inv(body, 1, 4) << unit_shift) - 32768,
+                              (int)(pp_order_axis_inv(body, 2, 4) << unit_shift) - 32768);
+  }
+}
+
+extern "C" size_t pp_block_index_coarsen_workspace(int64_t nb_fine) {
+  const size_t m = (size_t)std::max<int64_t>(nb_fine, 1);
+  return 4 * pp_align(m * 4) + pp_scan_workspace(nb_fine) + 1024;
+}
+// All outputs have capacity nb_fine blocks (cap = pp_block_index_capacity(nb_fine)) resp. n_fine rows; counts = {coarse
+// blocks, coarse rows}.  unit_coarse = tensor stride of the NEW level.  block_bits must be 4.
+extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_bits, int64_t nb_fine,
+                                      int32_t unit_coarse, int32_t block_bits, uint64_t* bkeys, int32_t* bvals,
+                                      int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord,
+                                      int32_t* coords, int32_t* counts, void* workspace, size_t workspace_bytes,
+                                      pp_stream_t stream) {
+  PP_REQUIRE(f_bkey_ord && f_bits && bkeys && bvals && start && bits && pre && bkey_ord && coords && counts,
+             "pp_block_index_coarsen: null pointer");
+  PP_REQUIRE(block_bits == 4, "pp_block_index_coarsen: needs the parity-block row order (block_bits = 4)");
+  PP_REQUIRE(unit_coarse >= 2 && (unit_coarse & (unit_coarse - 1)) == 0, "pp_block_index_coarsen: unit must be a power of two >= 2");
+  PP_REQUIRE(cap >= 2 * nb_fine && (cap & (cap - 1)) == 0, "pp_block_index_coarsen: cap must be a power of two >= 2 nb_fine");
+  if (workspace_bytes < pp_block_index_coarsen_workspace(nb_fine)) return PP_ERR_WORKSPACE;
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_bi_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, bkeys, cap);
+  PP_LAUNCH_CHECK();
+  if (nb_fine == 0) return PP_OK;
+  int unit_shift = 0;
+  while ((1 << unit_shift) < unit_coarse) ++unit_shift;
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* flag = ar.take<int32_t>((size_t)nb_fine);
+  int32_t* rank = ar.take<int32_t>((size_t)nb_fine);
+  int32_t* first_child = ar.take<int32_t>((size_t)nb_fine);
+  int32_t* ccount = ar.take<int32_t>((size_t)nb_fine);
+  const unsigned gb = pp_blocks(nb_fine, 256), gw = pp_blocks(nb_fine, 4);
+  hipLaunchKernelGGL(k_bic_flags, dim3(gb), dim3(256), 0, s, f_bkey_ord, nb_fine, flag);
+  PP_LAUNCH_CHECK();
+  int rc = pp_exclusive_scan_i32(flag, rank, nb_fine, counts, ar.cur(), ar.left(), s);  // counts[0] = coarse blocks
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bic_first_child, dim3(gb), dim3(256), 0, s, flag, rank, nb_fine, first_child);
+  PP_HIP(hipMemsetAsync(ccount, 0, sizeof(int32_t) * (size_t)nb_fine, s));
+  hipLaunchKernelGGL(k_bic_bits, dim3(gw), dim3(256), 0, s, f_bkey_ord, f_bits, nb_fine, first_child, counts, bits, ccount,
+                     bkey_ord);
+  PP_LAUNCH_CHECK();
+  rc = pp_exclusive_scan_i32(ccount, start, nb_fine, counts + 1, ar.cur(), ar.left(), s);  // counts[1] = coarse rows
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bic_finish, dim3(gw), dim3(256), 0, s, bkey_ord, bits, start, counts, unit_shift, bkeys, bvals, cap,
+                     pre, (int4*)coords);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -539,3 +539,34 @@ def test_voxelize_and_cylinder_tiles_match_oracle(ops, oracle):
         assert np.array_equal(g.cpu().numpy(), w)
     with pytest.raises(Exception):
         ops.voxelize(dev(np.array([[1e9, 0, 0]], np.float32)), 0.05)
+
+
+def test_coarser_levels_from_the_block_index(ops, oracle):
+    """pp_block_index_coarsen (bit permutation of the occupancy bitmaps) == strided coordinates + sort + index build,
+    level after level, incl. several batch elements, voxels at the ends of the range and isolated voxels."""
+    rng = np.random.default_rng(51)
+    fine = surface(rng, n=9000, n_batch=3, extent=120)
+    edge = np.array([[1, 32767, 32767, 32767], [1, 32766, 32766, 32767], [1, -32768, -32768, -32768], [2, -32767, 5, 9]], np.int32)
+    fine = np.unique(np.concatenate([fine, edge]), axis=0).astype(np.int32)
+    fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+    idx, _ = ops.block_index_build(dev(fine), 1, 4)
+    cur_idx, cur = idx, fine
+    ts = 1
+    for _ in range(5):
+        ts *= 2
+        got_idx, got = ops.block_index_coarsen(cur_idx, len(cur))
+        want = np.unique(np.concatenate([cur[:, :1], cur[:, 1:] // ts * ts], 1), axis=0).astype(np.int32)
+        want = want[ops.morton_order(dev(want), ts, 4).cpu().numpy()]
+        assert np.array_equal(got.cpu().numpy(), want), ts
+        ref_idx, _ = ops.block_index_build(dev(want), ts, 4)
+        assert got_idx.n_blocks == ref_idx.n_blocks and got_idx.unit == ts
+        nb = ref_idx.n_blocks
+        assert torch.equal(got_idx.bits[: nb * 64], ref_idx.bits[: nb * 64])
+        assert torch.equal(got_idx.pre[: nb * 64], ref_idx.pre[: nb * 64])
+        assert torch.equal(got_idx.start[:nb], ref_idx.start[:nb]) and torch.equal(got_idx.bkey_ord[:nb], ref_idx.bkey_ord[:nb])
+        # maps through the derived index == oracle
+        same = ops.kernel_map_bi(got, got_idx, 3, ts, 1)
+        assert np.array_equal(same.cpu().numpy(), oracle.kernel_map(want, want, 3, ts, 1))
+        down = ops.kernel_map_bi(got, cur_idx, 3, ts // 2, 1)
+        assert np.array_equal(down.cpu().numpy(), oracle.kernel_map(want, cur, 3, ts // 2, 1))
+        cur_idx, cur = got_idx, want
