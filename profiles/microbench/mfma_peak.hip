@@ -69,6 +69,36 @@ __global__ __launch_bounds__(256, 2) void kmix(float* out, int iters, float a, f
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// 32 MFMAs per iteration in the convolution kernel's pattern: 2 row tiles x 4 column tiles x 4 k-slices, every
+// instruction with its own A / B registers (8 + 16 distinct loop-invariant registers), 8 accumulator chains
+__global__ __launch_bounds__(256, 2) void kpattern(float* out, int iters, float a, float b) {
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 A[2], B[4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) A[t] = (f32x4){a + t, a * 2 + threadIdx.x, a - t, a + 3.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) B[c] = (f32x4){b + c, b * 2 + threadIdx.x, b - c, b + 5.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][u], B[c][u], acc[t][c], 0, 0, 0);
+    asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += acc[t][c][0] + acc[t][c][1] + acc[t][c][2] + acc[t][c][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // 16 MFMAs + NS scalar ALU ops per iteration
 template <int NS>
 __global__ __launch_bounds__(256, 2) void ksalu(float* out, int iters, float a, float b, int seed) {
@@ -157,6 +187,7 @@ int main() {
     run("16x16x4 f32, 2 chains", [&] { k16<2><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 2 * 2048);
     run("16x16x4 f32, 4 chains", [&] { k16<4><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 4 * 2048);
     run("16x16x4 f32, 8 chains", [&] { k16<8><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 4.0 * 8 * 2048);
+    run("conv pattern: 32 mfma, 24 operand regs", [&] { kpattern<<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 32.0 * 2048);
     run("16 mfma + 32 valu / iter", [&] { kmix<32><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
     run("16 mfma + 64 valu / iter", [&] { kmix<64><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
     run("16 mfma + 128 valu / iter", [&] { kmix<128><<<blocks, 256>>>(out, iters, 1.f, 2.f); }, waves * iters * 16.0 * 2048);
