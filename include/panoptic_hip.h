@@ -185,8 +185,9 @@ int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1,
 
 /* K5  weight gradient             replaces: ME ConvolutionBackward (dW part), reached from
  *                                 loss.backward(), torch_points3d/models/panoptic/PointGroup3heads.py:636-639
- * dw[k] (+)= sum_o in[nbr[k][o]]^T . dout[o]          dw is float32 [K,cin,cout], zeroed by the callee. */
-int pp_spconv_bwd_weight(const float* in, int32_t cin, const float* dout, int32_t cout,
+ * dw[k] (+)= sum_o in[nbr[k][o]]^T . dout[o]          dw is float32 [K,cin,cout], zeroed by the callee.
+ * in is [n_in,cin] (n_in bounds the gathers: indices in nbr are < n_in), dout is [n_out,cout]. */
+int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
                          const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -200,6 +201,20 @@ int pp_affine_act(const float* x, int64_t n, int32_t c, const float* scale, cons
                   int32_t act, float slope, const float* residual, float* y, pp_stream_t stream);
 int pp_bn_bwd_reduce(const float* x, const float* dy, int64_t n, int32_t c, double* sum_dy,
                      double* sum_dy_x, pp_stream_t stream);
+/* Training-mode BatchNorm1d over [n,c] (c <= 256, n >= 1), three launches each way, no atomics (run-to-run
+ * reproducible).  replaces: torch BatchNorm1d forward/backward under ME.MinkowskiBatchNorm in train mode,
+ * api_modules.py:40,53,269 (model.train() path of base_model / PointGroup3heads.py:120-173).
+ * fwd: batch mean / biased variance in float64 -> y = act((x-mean)*rstd*weight + bias) (relu != 0 fuses the ReLU);
+ *      running_mean/var (nullable pair) updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance);
+ *      save_mean/save_rstd [c] float64 are kept for the backward.  weight/bias nullable (affine=False).
+ * bwd: y_relu non-null masks dy by (y_relu > 0) first; dx [n,c]; dweight/dbias [c] (nullable). */
+size_t pp_bn_train_workspace(int64_t n, int32_t c);
+int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, double eps,
+                    double momentum, float* running_mean, float* running_var, int32_t relu, float* y,
+                    double* save_mean, double* save_rstd, void* ws, size_t ws_bytes, pp_stream_t stream);
+int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_t n, int32_t c,
+                    const float* weight, const double* save_mean, const double* save_rstd, float* dx,
+                    float* dweight, float* dbias, void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Heads                           replaces: Semantic/Offset/Embed MLP heads in eval mode,

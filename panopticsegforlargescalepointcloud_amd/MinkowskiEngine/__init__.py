@@ -303,42 +303,22 @@ class _SparseConvFn(torch.autograd.Function):
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
-    """y = (x - mean) * rstd * w + b with batch statistics (biased variance), stats from pp_channel_stats."""
+    """y = act((x - mean) * rstd * w + b) with batch statistics (biased variance); pp_bn_train_fwd / pp_bn_train_bwd:
+    three launches each way, running statistics updated inside the forward's finalize kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
+    def forward(ctx, x, weight, bias, eps, relu, momentum, running):
         x = x.contiguous()
-        n = x.shape[0]
-        s, ss = ops.channel_stats(x)
-        mean = s / n
-        var = torch.clamp(ss / n - mean * mean, min=0.0)
-        rstd = torch.rsqrt(var + eps)
-        scale = (weight.double() * rstd).float()
-        shift = (bias.double() - mean * weight.double() * rstd).float()
-        y = ops.affine_act(x, scale, shift, act=1 if relu else 0)
+        rm, rv = running if running is not None else (None, None)
+        y, mean, rstd = ops.bn_train_fwd(x, weight, bias, eps, momentum, rm, rv, relu)
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
-        ctx.relu = relu
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        return y
 
     @staticmethod
-    def backward(ctx, dy, _dm, _dv):
+    def backward(ctx, dy):
         x, weight, mean, rstd, y = ctx.saved_tensors
-        dy = dy.contiguous()
-        if ctx.relu:
-            dy = dy * (y > 0)
-        n = x.shape[0]
-        s1, s2 = ops.bn_bwd_reduce(x, dy)  # sum(dy), sum(dy*x)
-        w = weight.double()
-        m2 = (s2 - mean * s1) * rstd / n  # mean(dy * xhat)
-        a = (w * rstd).float()
-        b = (-w * m2 * rstd * rstd).float()
-        c = (w * rstd * (-s1 / n + mean * m2 * rstd)).float()
-        t = ops.affine_act(x, b, c)
-        dx = ops.affine_act(dy, a, None, residual=t)
-        dweight = ((s2 - mean * s1) * rstd).float()
-        dbias = s1.float()
-        return dx, dweight, dbias, None, None
+        dx, dweight, dbias = ops.bn_train_bwd(x, dy.contiguous(), y, weight, mean, rstd)
+        return dx, dweight, dbias, None, None, None, None
 
 
 class _AffineFn(torch.autograd.Function):
@@ -504,14 +484,15 @@ class MinkowskiBatchNorm(nn.Module):
     def features_forward(self, feats, relu=False):
         bn = self.bn
         if self.training or not bn.track_running_stats:
-            y, mean, var = _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu)
+            running = None
+            mom = 0.0
+            if bn.track_running_stats:
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                running = (bn.running_mean, bn.running_var)  # updated in place by the finalize kernel
+                self._folded = None  # ... which does not bump the tensors' version counters
+            y = _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu, mom, running)
             if bn.track_running_stats:
                 with torch.no_grad():
-                    n = feats.shape[0]
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    unbiased = var * (n / max(n - 1, 1))
-                    bn.running_mean.mul_(1 - mom).add_(mean.float() * mom)
-                    bn.running_var.mul_(1 - mom).add_(unbiased.float() * mom)
                     bn.num_batches_tracked += 1
             return y
         scale, shift = self.folded()

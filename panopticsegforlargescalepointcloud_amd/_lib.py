@@ -16,6 +16,7 @@ vp = C.c_void_p
 i32 = C.c_int32
 i64 = C.c_int64
 f32 = C.c_float
+f64 = C.c_double
 sz = C.c_size_t
 
 # name -> (restype, argtypes); kept in the order of include/panoptic_hip.h
@@ -48,10 +49,13 @@ SIGNATURES = {
     "pp_rulebook_offsets": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "pp_rulebook_fill": (C.c_int, [vp, i64, vp, vp, vp, vp]),
     "pp_spconv_fwd_rb": (C.c_int, [vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp]),
-    "pp_spconv_bwd_weight": (C.c_int, [vp, i32, vp, i32, vp, i32, i64, vp, vp]),
+    "pp_spconv_bwd_weight": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
     "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),
     "pp_affine_act": (C.c_int, [vp, i64, i32, vp, vp, i32, f32, vp, vp, vp]),
     "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
+    "pp_bn_train_workspace": (sz, [i64, i32]),
+    "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_bn_train_bwd": (C.c_int, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "pp_region_grow_workspace": (sz, [i64, i32]),
     "pp_region_grow_workspace_for": (sz, [i64, i64, i32]),

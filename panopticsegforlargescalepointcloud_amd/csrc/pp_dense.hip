@@ -158,6 +158,262 @@ extern "C" int pp_affine_act(const float* x, int64_t n, int32_t c, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// training-mode BatchNorm1d in three launches, no atomics (bit-reproducible run to run):
+//   k_bn_partial  : every block strides over rows, float64 accumulators per thread (4 rows in flight), LDS reduction
+//                   over the rows a block step covers -> partial[block][2][c]
+//   k_bn_finalize : 16 channels per block, 16 slices over the block partials -> statistics + per-channel coefficients
+//   forward  : y  = act(x*scale + shift)                      (k_affine_act*)
+//   backward : dx = a*dy' + b*x + c, dy' = dy masked by y > 0 when the ReLU was fused into the forward
+// MODE 0: sum x, sum x^2;  MODE 1: sum dy, sum dy*x;  MODE 2: as 1 with the ReLU mask
+// ---------------------------------------------------------------------------------------------
+#define BN_MAX_BLOCKS 512
+
+template <int VEC>
+__device__ __forceinline__ void bn_ld(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 q = *(const float4*)p;
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC, int MODE>
+__device__ __forceinline__ void bn_acc(const float (&a)[VEC], const float (&d)[VEC], const float (&m)[VEC],
+                                       double (&s0)[VEC], double (&s1)[VEC]) {
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    if (MODE == 0) {
+      double v = (double)a[u];
+      s0[u] += v;
+      s1[u] += v * v;
+    } else {
+      double w = (MODE == 2 && !(m[u] > 0.f)) ? 0.0 : (double)d[u];
+      s0[u] += w;
+      s1[u] += w * (double)a[u];
+    }
+  }
+}
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ yr, int64_t n, int c,
+                                                    double* __restrict__ partial) {
+  __shared__ double sm[256 * 2 * VEC];
+  const int cv = c / VEC, rps = 256 / cv;
+  const int t = threadIdx.x, rin = t / cv, cc = t - rin * cv;
+  double s0[VEC], s1[VEC];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) s0[u] = s1[u] = 0.0;
+  if (rin < rps) {
+    const int64_t G = (int64_t)gridDim.x * rps;
+    int64_t r = (int64_t)blockIdx.x * rps + rin;
+    const int64_t co = (int64_t)cc * VEC;
+    for (; r + 3 * G < n; r += 4 * G) {
+      float a[4][VEC], d[4][VEC], m[4][VEC];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t o = (r + q * G) * c + co;
+        bn_ld<VEC>(x + o, a[q]);
+        if (MODE >= 1) bn_ld<VEC>(dy + o, d[q]);
+        if (MODE == 2) bn_ld<VEC>(yr + o, m[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bn_acc<VEC, MODE>(a[q], d[q], m[q], s0, s1);
+    }
+    for (; r < n; r += G) {
+      float a[VEC], d[VEC], m[VEC];
+      const int64_t o = r * c + co;
+      bn_ld<VEC>(x + o, a);
+      if (MODE >= 1) bn_ld<VEC>(dy + o, d);
+      if (MODE == 2) bn_ld<VEC>(yr + o, m);
+      bn_acc<VEC, MODE>(a, d, m, s0, s1);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    sm[t * 2 * VEC + u] = s0[u];
+    sm[t * 2 * VEC + VEC + u] = s1[u];
+  }
+  __syncthreads();
+  if (t < c) {
+    const int pc = t / VEC, u = t - pc * VEC;
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = 0; q < rps; ++q) {
+      a0 += sm[(q * cv + pc) * 2 * VEC + u];
+      a1 += sm[(q * cv + pc) * 2 * VEC + VEC + u];
+    }
+    partial[((int64_t)blockIdx.x * 2) * c + t] = a0;
+    partial[((int64_t)blockIdx.x * 2 + 1) * c + t] = a1;
+  }
+}
+
+struct BnFinalize {
+  const double* partial;
+  int nb, c, backward;
+  double n, eps, momentum;
+  const float *weight, *bias;
+  float *running_mean, *running_var;   // forward, nullable
+  float *k0, *k1, *k2;                 // forward: scale, shift, -   backward: a, b, c
+  double *save_mean, *save_rstd;       // forward: written; backward: read
+  float *dweight, *dbias;              // backward, nullable
+};
+
+__global__ __launch_bounds__(256) void k_bn_finalize(BnFinalize f) {
+  __shared__ double sm[2][16][16];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4, col = blockIdx.x * 16 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (col < f.c)
+    for (int b = j; b < f.nb; b += 16) {
+      a0 += f.partial[((int64_t)b * 2) * f.c + col];
+      a1 += f.partial[((int64_t)b * 2 + 1) * f.c + col];
+    }
+  sm[0][j][cl] = a0;
+  sm[1][j][cl] = a1;
+  __syncthreads();
+  if (j != 0 || col >= f.c) return;
+  a0 = a1 = 0.0;
+  for (int q = 0; q < 16; ++q) {
+    a0 += sm[0][q][cl];
+    a1 += sm[1][q][cl];
+  }
+  const double w = f.weight ? (double)f.weight[col] : 1.0;
+  if (!f.backward) {
+    const double mean = a0 / f.n;
+    double var = a1 / f.n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + f.eps);
+    const double b = f.bias ? (double)f.bias[col] : 0.0;
+    f.k0[col] = (float)(w * rstd);
+    f.k1[col] = (float)(b - mean * w * rstd);
+    f.save_mean[col] = mean;
+    f.save_rstd[col] = rstd;
+    if (f.running_mean) {
+      const double unbiased = var * (f.n / (f.n > 1.0 ? f.n - 1.0 : 1.0));
+      f.running_mean[col] = (float)((1.0 - f.momentum) * (double)f.running_mean[col] + f.momentum * mean);
+      f.running_var[col] = (float)((1.0 - f.momentum) * (double)f.running_var[col] + f.momentum * unbiased);
+    }
+  } else {
+    const double mean = f.save_mean[col], rstd = f.save_rstd[col];
+    const double g = (a1 - mean * a0) * rstd;  // sum(dy * xhat)
+    const double m2 = g / f.n;
+    f.k0[col] = (float)(w * rstd);
+    f.k1[col] = (float)(-w * m2 * rstd * rstd);
+    f.k2[col] = (float)(w * rstd * (-a0 / f.n + mean * m2 * rstd));
+    if (f.dweight) f.dweight[col] = (float)g;
+    if (f.dbias) f.dbias[col] = (float)a0;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bn_dx(const float* __restrict__ x, const float* __restrict__ dy,
+                                               const float* __restrict__ yr, int64_t nv, int c,
+                                               const float* __restrict__ ka, const float* __restrict__ kb,
+                                               const float* __restrict__ kc, float* __restrict__ dx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < nv; i += stride) {
+    const int col = (int)((i * VEC) % c);
+    float a[VEC], d[VEC], m[VEC], o[VEC];
+    bn_ld<VEC>(x + i * VEC, a);
+    bn_ld<VEC>(dy + i * VEC, d);
+    if (yr) bn_ld<VEC>(yr + i * VEC, m);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      float g = (yr && !(m[u] > 0.f)) ? 0.f : d[u];
+      o[u] = ka[col + u] * g + kb[col + u] * a[u] + kc[col + u];
+    }
+    if constexpr (VEC == 4)
+      *(float4*)(dx + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      dx[i] = o[0];
+  }
+}
+
+static inline size_t bn_partial_bytes(int c) { return (size_t)BN_MAX_BLOCKS * 2 * c * sizeof(double); }
+
+extern "C" size_t pp_bn_train_workspace(int64_t n, int32_t c) {
+  (void)n;
+  if (c < 1) return 0;
+  return bn_partial_bytes(c) + 4 * (size_t)c * sizeof(float) + 256;
+}
+
+template <int MODE>
+static int bn_partial_launch(const float* x, const float* dy, const float* yr, int64_t n, int c, double* partial,
+                             hipStream_t s, int* nblocks) {
+  const bool v4 = (c % 4 == 0);
+  const int cv = v4 ? c / 4 : c;
+  const int64_t rps = 256 / cv;
+  unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + rps * 4 - 1) / (rps * 4), BN_MAX_BLOCKS));
+  if (v4)
+    hipLaunchKernelGGL((k_bn_partial<4, MODE>), dim3(blocks), dim3(256), 0, s, x, dy, yr, n, c, partial);
+  else
+    hipLaunchKernelGGL((k_bn_partial<1, MODE>), dim3(blocks), dim3(256), 0, s, x, dy, yr, n, c, partial);
+  PP_LAUNCH_CHECK();
+  *nblocks = (int)blocks;
+  return PP_OK;
+}
+
+extern "C" int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, double eps,
+                               double momentum, float* running_mean, float* running_var, int32_t relu, float* y,
+                               double* save_mean, double* save_rstd, void* ws, size_t ws_bytes, pp_stream_t stream) {
+  PP_REQUIRE(c >= 1 && c <= 256, "pp_bn_train_fwd: c must be in [1,256]");
+  PP_REQUIRE(n >= 1, "pp_bn_train_fwd: batch statistics need at least one row");
+  PP_REQUIRE(x && y && save_mean && save_rstd && ws, "pp_bn_train_fwd: null pointer");
+  PP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "pp_bn_train_fwd: running_mean/var come together");
+  PP_REQUIRE(ws_bytes >= pp_bn_train_workspace(n, c), "pp_bn_train_fwd: workspace too small");
+  hipStream_t s = pp_s(stream);
+  double* partial = (double*)ws;
+  float* coef = (float*)((char*)ws + bn_partial_bytes(c));
+  int nb = 0;
+  int rc = bn_partial_launch<0>(x, nullptr, nullptr, n, c, partial, s, &nb);
+  if (rc != PP_OK) return rc;
+  BnFinalize f{};
+  f.partial = partial; f.nb = nb; f.c = c; f.backward = 0;
+  f.n = (double)n; f.eps = eps; f.momentum = momentum;
+  f.weight = weight; f.bias = bias; f.running_mean = running_mean; f.running_var = running_var;
+  f.k0 = coef; f.k1 = coef + c; f.k2 = nullptr; f.save_mean = save_mean; f.save_rstd = save_rstd;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 15) / 16), dim3(256), 0, s, f);
+  PP_LAUNCH_CHECK();
+  return pp_affine_act(x, n, c, coef, coef + c, relu ? 1 : 0, 0.f, nullptr, y, stream);
+}
+
+extern "C" int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_t n, int32_t c,
+                               const float* weight, const double* save_mean, const double* save_rstd, float* dx,
+                               float* dweight, float* dbias, void* ws, size_t ws_bytes, pp_stream_t stream) {
+  PP_REQUIRE(c >= 1 && c <= 256, "pp_bn_train_bwd: c must be in [1,256]");
+  PP_REQUIRE(n >= 1, "pp_bn_train_bwd: batch statistics need at least one row");
+  PP_REQUIRE(x && dy && dx && save_mean && save_rstd && ws, "pp_bn_train_bwd: null pointer");
+  PP_REQUIRE(ws_bytes >= pp_bn_train_workspace(n, c), "pp_bn_train_bwd: workspace too small");
+  hipStream_t s = pp_s(stream);
+  double* partial = (double*)ws;
+  float* coef = (float*)((char*)ws + bn_partial_bytes(c));
+  int nb = 0;
+  int rc = y_relu ? bn_partial_launch<2>(x, dy, y_relu, n, c, partial, s, &nb)
+                  : bn_partial_launch<1>(x, dy, nullptr, n, c, partial, s, &nb);
+  if (rc != PP_OK) return rc;
+  BnFinalize f{};
+  f.partial = partial; f.nb = nb; f.c = c; f.backward = 1;
+  f.n = (double)n; f.weight = weight;
+  f.k0 = coef; f.k1 = coef + c; f.k2 = coef + 2 * c;
+  f.save_mean = const_cast<double*>(save_mean); f.save_rstd = const_cast<double*>(save_rstd);
+  f.dweight = dweight; f.dbias = dbias;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 15) / 16), dim3(256), 0, s, f);
+  PP_LAUNCH_CHECK();
+  const int64_t total = n * c;
+  if (c % 4 == 0) {
+    unsigned blocks = (unsigned)std::min<int64_t>((total / 4 + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_bn_dx<4>, dim3(blocks), dim3(256), 0, s, x, dy, y_relu, total / 4, c, coef, coef + c,
+                       coef + 2 * c, dx);
+  } else {
+    unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_bn_dx<1>, dim3(blocks), dim3(256), 0, s, x, dy, y_relu, total, c, coef, coef + c, coef + 2 * c,
+                       dx);
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused head: Linear(no bias) -> folded BN -> LeakyReLU(0.2) -> Linear(+bias) [-> LogSoftmax] [-> argmax]
 // one thread per point; weights broadcast from LDS; 64 B in, <= 64 B out per point.
 // ---------------------------------------------------------------------------------------------

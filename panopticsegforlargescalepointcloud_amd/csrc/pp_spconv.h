@@ -30,3 +30,8 @@ __device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
 bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in);
 int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
 int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s);
+
+// pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows
+bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr);
+int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* dout, int cout, const int32_t* nbr,
+                          int K, int64_t n_out, float* dw, hipStream_t s);

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_spconv_bwd_weight(const float* __restri
   }
 }
 
-extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, const float* dout, int32_t cout,
+extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
                                     const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream) {
   PP_REQUIRE(in && dout && dw, "pp_spconv_bwd_weight: null pointer");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_bwd_weight: a kernel map is required unless K == 1");
@@ -332,6 +332,9 @@ extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, const float* d
   hipStream_t s = pp_s(stream);
   PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
   if (n_out == 0) return PP_OK;
+  static const int bww_ver = getenv("PP_BWW_VER") ? atoi(getenv("PP_BWW_VER")) : 2;
+  if (bww_ver >= 2 && pp_spconv_bww2_ok(cin, cout, n_in, nbr))
+    return pp_spconv_bww2_launch(in, cin, n_in, dout, cout, nbr, K, n_out, dw, s);
   dim3 grid(pp_blocks(n_out, 4 * BWW_ROWS_PER_WAVE), (unsigned)K, (unsigned)((cin + 15) / 16));
   int nto = pp_nt(cout);
 #define BWW_CASE(N) \

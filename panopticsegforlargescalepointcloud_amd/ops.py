@@ -401,7 +401,7 @@ def spconv_bwd_weight(inp, dout, nbr, K):
     dout = _need(dout, torch.float32, "dout")
     cin, cout = inp.shape[1], dout.shape[1]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=inp.device)
-    _lib.check(lib.pp_spconv_bwd_weight(_ptr(inp), cin, _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw),
+    _lib.check(lib.pp_spconv_bwd_weight(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw),
                                         _stream()), "pp_spconv_bwd_weight")
     return dw
 
@@ -425,6 +425,43 @@ def bn_bwd_reduce(x, dy):
     b = torch.empty(c, dtype=torch.float64, device=x.device)
     _lib.check(lib.pp_bn_bwd_reduce(_ptr(x), _ptr(dy), n, c, _ptr(a), _ptr(b), _stream()), "pp_bn_bwd_reduce")
     return a, b
+
+
+def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu):
+    """Training-mode BatchNorm1d (+ fused ReLU); running statistics (nullable) updated in place.
+    Returns (y, save_mean, save_rstd); the saved statistics are float64."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    n, c = x.shape
+    y = torch.empty_like(x)
+    stat = torch.empty(2, c, dtype=torch.float64, device=x.device)
+    nbytes = lib.pp_bn_train_workspace(n, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.pp_bn_train_fwd(_ptr(x), n, c, _ptr(_need(weight, torch.float32, "weight")),
+                                   _ptr(_need(bias, torch.float32, "bias")), float(eps), float(momentum),
+                                   _ptr(_need(running_mean, torch.float32, "running_mean")),
+                                   _ptr(_need(running_var, torch.float32, "running_var")), 1 if relu else 0,
+                                   _ptr(y), _ptr(stat[0]), _ptr(stat[1]), _ptr(ws), nbytes, _stream()),
+               "pp_bn_train_fwd")
+    return y, stat[0], stat[1]
+
+
+def bn_train_bwd(x, dy, y_relu, weight, save_mean, save_rstd):
+    """Backward of bn_train_fwd: (dx, dweight, dbias); y_relu (the forward output) masks dy when the ReLU was fused."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    dy = _need(dy, torch.float32, "dy")
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dwb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    nbytes = lib.pp_bn_train_workspace(n, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.pp_bn_train_bwd(_ptr(x), _ptr(dy), _ptr(_need(y_relu, torch.float32, "y_relu")), n, c,
+                                   _ptr(_need(weight, torch.float32, "weight")),
+                                   _ptr(_need(save_mean, torch.float64, "save_mean")),
+                                   _ptr(_need(save_rstd, torch.float64, "save_rstd")), _ptr(dx), _ptr(dwb[0]),
+                                   _ptr(dwb[1]), _ptr(ws), nbytes, _stream()), "pp_bn_train_bwd")
+    return dx, dwb[0], dwb[1]
 
 
 def affine_act(x, scale=None, shift=None, act=0, slope=0.0, residual=None):

@@ -137,6 +137,26 @@ def test_spconv_strided_and_transposed(ops, oracle):
     np.testing.assert_allclose(z.cpu().numpy(), z_want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 16), (64, 32), (32, 16), (48, 96), (16, 128), (16, 192), (20, 40), (96, 96)])
+def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
+    """every (ci tiles per wave, co tiles) instantiation of the pipelined weight gradient, ragged row counts, a strided
+    map (n_in != n_out, many missing neighbours) and a ragged channel count; float32 accumulation order differs from
+    the oracle's, hence the tolerance."""
+    rng = np.random.default_rng(60 + cin + cout)
+    fine = surface(rng, n=1500, n_batch=2, extent=36)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    for out_c, in_c, sign, st in [(fine, fine, 1, 1), (coarse, fine, 1, 1), (fine, coarse, -1, 1)]:
+        nbr = oracle.kernel_map(out_c, in_c, 3, st, sign)
+        x = rng.normal(size=(len(in_c), cin)).astype(np.float32)
+        g = rng.normal(size=(len(out_c), cout)).astype(np.float32)
+        want = np.zeros((27, cin, cout))
+        for k in range(27):
+            m = nbr[k] >= 0
+            want[k] = x[nbr[k][m]].astype(np.float64).T @ g[m].astype(np.float64)
+        dw = ops.spconv_bwd_weight(dev(x), dev(g), dev(nbr), 27)
+        np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 48), (96, 32), (4, 16)])
 def test_spconv_backward_matches_oracle(ops, oracle, cin, cout):
     rng = np.random.default_rng(6)
@@ -153,6 +173,51 @@ def test_spconv_backward_matches_oracle(ops, oracle, cin, cout):
     packedT = ops.pack_weight(dev(W), transpose=True)
     din = ops.spconv_fwd(dev(g), packedT, dev(nbr[::-1].copy()), n, cin, 27)
     np.testing.assert_allclose(din.cpu().numpy(), din_want, rtol=1e-4, atol=1e-4)
+
+
+def test_bn_train_fwd_bwd_matches_torch_float64(ops):
+    """pp_bn_train_fwd / pp_bn_train_bwd against torch's BatchNorm (float64, CPU autograd) incl. the fused ReLU and the
+    running statistics; two runs are bit-identical (no atomics).  Tolerance: float32 rounding of the outputs."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    for n, c in [(2, 4), (37, 6), (5000, 32), (4099, 96), (100_003, 64), (3001, 256), (777, 3)]:
+        for relu in (False, True):
+            x = (rng.normal(size=(n, c)) * rng.uniform(0.5, 3, c) + rng.normal(size=c) * 2).astype(np.float32)
+            w = rng.uniform(0.5, 1.5, c).astype(np.float32)
+            b = rng.normal(size=c).astype(np.float32)
+            dy = rng.normal(size=(n, c)).astype(np.float32)
+            rm0 = rng.normal(size=c).astype(np.float32)
+            rv0 = rng.uniform(0.5, 2, c).astype(np.float32)
+            xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+            wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+            bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+            rm, rv = torch.tensor(rm0, dtype=torch.float64), torch.tensor(rv0, dtype=torch.float64)
+            yt = F.batch_norm(xt, rm, rv, wt, bt, training=True, momentum=0.1, eps=1e-5)
+            if relu:
+                yt = torch.relu(yt)
+            yt.backward(torch.tensor(dy, dtype=torch.float64))
+            grm, grv = dev(rm0), dev(rv0)
+            y, mean, rstd = ops.bn_train_fwd(dev(x), dev(w), dev(b), 1e-5, 0.1, grm, grv, relu)
+            np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(grm.cpu().numpy(), rm.numpy(), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(grv.cpu().numpy(), rv.numpy(), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(mean.cpu().numpy(), x.astype(np.float64).mean(0), rtol=1e-9, atol=1e-9)
+            dx, dw, db = ops.bn_train_bwd(dev(x), dev(dy), y if relu else None, dev(w), mean, rstd)
+            scale = max(1.0, float(np.abs(xt.grad.numpy()).max()))
+            np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+            np.testing.assert_allclose(dw.cpu().numpy(), wt.grad.numpy(), rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(db.cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-3)
+            y2, mean2, rstd2 = ops.bn_train_fwd(dev(x), dev(w), dev(b), 1e-5, 0.1, None, None, relu)
+            assert torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+            dx2, dw2, db2 = ops.bn_train_bwd(dev(x), dev(dy), y if relu else None, dev(w), mean, rstd)
+            assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    # affine=False and the argument checks
+    x = dev(rng.normal(size=(100, 8)).astype(np.float32))
+    y, mean, rstd = ops.bn_train_fwd(x, None, None, 1e-5, 0.1, None, None, False)
+    np.testing.assert_allclose(y.cpu().numpy().mean(0), 0, atol=1e-6)
+    np.testing.assert_allclose(y.cpu().numpy().std(0), 1, atol=1e-3)
+    with pytest.raises(Exception):
+        ops.bn_train_fwd(x[:0], None, None, 1e-5, 0.1, None, None, False)
 
 
 def test_bn_pieces_and_heads(ops, oracle):
