@@ -71,6 +71,37 @@ class _Level:
         self.n = coords.shape[0]
 
 
+class _PermuteRowsFn(torch.autograd.Function):
+    """x[perm] for a full permutation: the gradient is one more gather (dy[inv]) instead of torch's sort-based
+    index_put(accumulate=True)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv):
+        ctx.inv = inv
+        return x[perm]
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[ctx.inv], None, None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """x[index] with repeated rows: the gradient is an atomic row scatter-add (index_add_)."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.index, ctx.n = index, x.shape[0]
+        return x[index]
+
+    @staticmethod
+    def backward(ctx, dy):
+        return torch.zeros((ctx.n,) + dy.shape[1:], dtype=dy.dtype, device=dy.device).index_add_(0, ctx.index, dy), None
+
+
+def _permute_rows(x, perm, inv):
+    return _PermuteRowsFn.apply(x, perm, inv) if x.requires_grad else x[perm]
+
+
 class CoordinateManager:
     """Coordinate levels (tensor stride -> COO rows + hash) and kernel maps, cached for one input.
 
@@ -135,10 +166,10 @@ class CoordinateManager:
         return self.tile_orders.get(ts)
 
     def to_internal(self, feats):
-        return feats if self.perm is None else feats[self.perm]
+        return feats if self.perm is None else _permute_rows(feats, self.perm, self.inv_perm)
 
     def to_caller(self, feats):
-        return feats if self.inv_perm is None else feats[self.inv_perm]
+        return feats if self.inv_perm is None else _permute_rows(feats, self.inv_perm, self.perm)
 
     def ensure_stride(self, ts_in, stride):
         ts_out = ts_in * stride
@@ -208,7 +239,8 @@ class GatheredRows:
         return self
 
     def materialise(self, perm=None):
-        return self.base[self.index if perm is None else self.index[perm]]
+        index = self.index if perm is None else self.index[perm]
+        return _GatherRowsFn.apply(self.base, index) if self.base.requires_grad else self.base[index]
 
 
 class SparseTensor:

@@ -161,12 +161,12 @@ extern "C" int pp_affine_act(const float* x, int64_t n, int32_t c, const float* 
 // training-mode BatchNorm1d in three launches, no atomics (bit-reproducible run to run):
 //   k_bn_partial  : every block strides over rows, float64 accumulators per thread (4 rows in flight), LDS reduction
 //                   over the rows a block step covers -> partial[block][2][c]
-//   k_bn_finalize : 16 channels per block, 16 slices over the block partials -> statistics + per-channel coefficients
+//   k_bn_finalize : 8 channels per block, 32 slices over the block partials -> statistics + per-channel coefficients
 //   forward  : y  = act(x*scale + shift)                      (k_affine_act*)
 //   backward : dx = a*dy' + b*x + c, dy' = dy masked by y > 0 when the ReLU was fused into the forward
 // MODE 0: sum x, sum x^2;  MODE 1: sum dy, sum dy*x;  MODE 2: as 1 with the ReLU mask
 // ---------------------------------------------------------------------------------------------
-#define BN_MAX_BLOCKS 512
+#define BN_MAX_BLOCKS 256
 
 template <int VEC>
 __device__ __forceinline__ void bn_ld(const float* __restrict__ p, float (&v)[VEC]) {
@@ -259,20 +259,31 @@ struct BnFinalize {
 };
 
 __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalize f) {
-  __shared__ double sm[2][16][16];
-  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4, col = blockIdx.x * 16 + cl;
+  // 8 channels per block, 32 slices over the block partials; the (<= BN_MAX_BLOCKS / 32) loads of a thread are
+  // independent and unrolled, so the kernel costs one memory latency, not one per partial block
+  __shared__ double sm[2][32][8];
+  const int cl = threadIdx.x & 7, j = threadIdx.x >> 3, col = blockIdx.x * 8 + cl;
   double a0 = 0.0, a1 = 0.0;
-  if (col < f.c)
-    for (int b = j; b < f.nb; b += 16) {
-      a0 += f.partial[((int64_t)b * 2) * f.c + col];
-      a1 += f.partial[((int64_t)b * 2 + 1) * f.c + col];
+  if (col < f.c) {
+    double v0[BN_MAX_BLOCKS / 32], v1[BN_MAX_BLOCKS / 32];
+#pragma unroll
+    for (int u = 0; u < BN_MAX_BLOCKS / 32; ++u) {
+      const int b = j + 32 * u;
+      v0[u] = b < f.nb ? f.partial[((int64_t)b * 2) * f.c + col] : 0.0;
+      v1[u] = b < f.nb ? f.partial[((int64_t)b * 2 + 1) * f.c + col] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < BN_MAX_BLOCKS / 32; ++u) {
+      a0 += v0[u];
+      a1 += v1[u];
+    }
+  }
   sm[0][j][cl] = a0;
   sm[1][j][cl] = a1;
   __syncthreads();
   if (j != 0 || col >= f.c) return;
   a0 = a1 = 0.0;
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 32; ++q) {
     a0 += sm[0][q][cl];
     a1 += sm[1][q][cl];
   }
@@ -372,7 +383,7 @@ extern "C" int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float
   f.n = (double)n; f.eps = eps; f.momentum = momentum;
   f.weight = weight; f.bias = bias; f.running_mean = running_mean; f.running_var = running_var;
   f.k0 = coef; f.k1 = coef + c; f.k2 = nullptr; f.save_mean = save_mean; f.save_rstd = save_rstd;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 15) / 16), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 7) / 8), dim3(256), 0, s, f);
   PP_LAUNCH_CHECK();
   return pp_affine_act(x, n, c, coef, coef + c, relu ? 1 : 0, 0.f, nullptr, y, stream);
 }
@@ -397,7 +408,7 @@ extern "C" int pp_bn_train_bwd(const float* x, const float* dy, const float* y_r
   f.k0 = coef; f.k1 = coef + c; f.k2 = coef + 2 * c;
   f.save_mean = const_cast<double*>(save_mean); f.save_rstd = const_cast<double*>(save_rstd);
   f.dweight = dweight; f.dbias = dbias;
-  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 15) / 16), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 7) / 8), dim3(256), 0, s, f);
   PP_LAUNCH_CHECK();
   const int64_t total = n * c;
   if (c % 4 == 0) {
@@ -538,6 +549,54 @@ __global__ __launch_bounds__(256) void k_seg_accum(const float* __restrict__ src
   else
     atomicAdd(&out[s * c + j], src[e]);
 }
+// few segments (n_seg * (c + 1) words fit in LDS): block-private accumulation, then one global atomic per touched
+// segment entry and block -- thousands of rows hammering a handful of output addresses is what made the
+// discriminative-loss reductions slow (a14).
+#define SEG_LDS_WORDS 12288
+#define SEG_LDS_ELEMS_PER_THREAD 32
+__global__ __launch_bounds__(256) void k_seg_accum_lds(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                                       int64_t total, int c, int n_seg, int reduce, float* out,
+                                                       int* out_ord, int32_t* cnt, int32_t* err) {
+  extern __shared__ int seg_sh[];
+  int* shv = seg_sh;                // [n_seg * c] float bits (sum) or ordered ints (max)
+  int* shc = seg_sh + n_seg * c;    // [n_seg]
+  const int nv = n_seg * c;
+  for (int t = threadIdx.x; t < nv; t += 256) shv[t] = reduce == 2 ? (int)0x80000000 : 0;
+  for (int t = threadIdx.x; t < n_seg; t += 256) shc[t] = 0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)blockIdx.x * (256 * SEG_LDS_ELEMS_PER_THREAD);
+#pragma unroll 4
+  for (int u = 0; u < SEG_LDS_ELEMS_PER_THREAD; ++u) {
+    const int64_t e = e0 + u * 256 + threadIdx.x;
+    if (e >= total) break;
+    const int64_t i = e / c;
+    const int j = (int)(e - i * c);
+    const int64_t sg = index[i];
+    if (sg < 0 || sg >= n_seg) {
+      if (j == 0) atomicAdd(err, 1);
+      continue;
+    }
+    if (reduce == 2)
+      atomicMax(&shv[sg * c + j], f2ord(src[e]));
+    else
+      atomicAdd((float*)&shv[sg * c + j], src[e]);
+    if (j == 0) atomicAdd(&shc[sg], 1);
+  }
+  __syncthreads();
+  // flush what this block touched (judged by value: a row may straddle two blocks, so the count, taken at column 0,
+  // says nothing about the other columns)
+  for (int t = threadIdx.x; t < nv; t += 256) {
+    const int v = shv[t];
+    if (reduce == 2) {
+      if (v != (int)0x80000000) atomicMax(&out_ord[t], v);
+    } else if (v != 0) {
+      atomicAdd(&out[t], __int_as_float(v));
+    }
+  }
+  for (int t = threadIdx.x; t < n_seg; t += 256)
+    if (shc[t]) atomicAdd(&cnt[t], shc[t]);
+}
+
 __global__ __launch_bounds__(256) void k_seg_finish(float* out, int* out_ord, const int32_t* __restrict__ cnt,
                                                     int64_t total, int c, int reduce) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -579,7 +638,12 @@ extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t
   } else {
     PP_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)total_out, s));
   }
-  if (n > 0) {
+  static const bool seg_lds = !(getenv("PP_SEG_LDS") && atoi(getenv("PP_SEG_LDS")) == 0);
+  if (seg_lds && n > 0 && n_seg * (c + 1) <= SEG_LDS_WORDS && n * c >= 65536) {
+    hipLaunchKernelGGL(k_seg_accum_lds, dim3(pp_blocks(n * c, 256 * SEG_LDS_ELEMS_PER_THREAD)), dim3(256),
+                       sizeof(int) * (size_t)(n_seg * (c + 1)), s, src, index, n * c, c, (int)n_seg, reduce, out,
+                       (int*)out, cnt, cnt + n_seg);
+  } else if (n > 0) {
     hipLaunchKernelGGL(k_seg_count, dim3(pp_blocks(n, 256)), dim3(256), 0, s, index, n, n_seg, cnt, cnt + n_seg);
     hipLaunchKernelGGL(k_seg_accum, dim3(pp_blocks(n * c, 256)), dim3(256), 0, s, src, index, n * c, c, n_seg, reduce,
                        out, (int*)out);

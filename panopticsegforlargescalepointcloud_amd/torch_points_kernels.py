@@ -33,18 +33,18 @@ def region_grow(pos, labels, batch, ignore_labels=[], nsample=16, radius=0.02, m
 
 
 def gt_layout(gt_instances, batch):
-    """Per-sample GT instance counts (cumulative) and sizes, the column layout of instance_iou."""
-    nb = int(batch.max().item()) + 1 if batch.numel() else 0
-    # ids are 1..k per batch element, 0 = none
-    k = torch.zeros(nb, dtype=torch.int64, device=batch.device).scatter_reduce(0, batch, gt_instances, "amax",
-                                                                                 include_self=True)
-    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=batch.device), torch.cumsum(k, 0)])
-    total = int(offs[-1].item())
-    sizes = torch.zeros(max(total, 1), dtype=torch.int64, device=batch.device)
-    m = gt_instances > 0
-    col = offs[batch[m]] + gt_instances[m] - 1
-    sizes.scatter_add_(0, col, torch.ones_like(col))
-    return offs.to(torch.int32), sizes[:total].to(torch.int32)
+    """Per-sample GT instance counts (cumulative) and sizes, the column layout of instance_iou.
+    One histogram over (batch, id) gives both: ids are 1..k per batch element (0 = none), k = the largest id present."""
+    dev = batch.device
+    if batch.numel() == 0:
+        return torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+    nb, g = (int(v) + 1 for v in torch.stack([batch.max(), gt_instances.max()]).tolist())
+    hist = torch.bincount(batch * g + gt_instances, minlength=nb * g).view(nb, g)
+    ids = torch.arange(g, device=dev)
+    k = ((hist > 0) * ids).amax(1)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(k, 0)])
+    sizes = hist[(ids > 0) & (ids <= k.view(-1, 1))]  # row-major: batch element by batch element, ids 1..k
+    return offs.to(torch.int32), sizes.to(torch.int32)
 
 
 def instance_iou_csr(csr, gt_instances, batch=None):

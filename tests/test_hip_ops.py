@@ -415,6 +415,47 @@ def test_group_by_key_and_segment_reduce(ops, oracle):
             assert np.array_equal(arg.cpu().numpy(), warg)
 
 
+@pytest.mark.parametrize("n,c,n_seg", [(200_000, 5, 40), (30_000, 16, 3000), (5000, 1, 7), (70_000, 1, 12000)])
+def test_segment_reduce_few_and_many_segments(ops, oracle, n, c, n_seg):
+    """both accumulation paths (block-private LDS for few segments, global atomics otherwise), empty segments and the
+    arg-max convention; sums differ from the oracle only by float32 summation order."""
+    rng = np.random.default_rng(n + c)
+    src = rng.normal(size=(n, c)).astype(np.float32)
+    index = rng.integers(0, n_seg, size=n)
+    index[index == 3] = 4
+    for red in ["sum", "mean", "max"]:
+        want, warg = oracle.segment_reduce(src, index, n_seg, red)
+        got, arg = ops.segment_reduce(dev(src), dev(index), n_seg, red, want_arg=True)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-3 if red == "sum" else 2e-4)
+        if red == "max":
+            assert np.array_equal(arg.cpu().numpy(), warg)
+    with pytest.raises(Exception):
+        index[17] = n_seg
+        ops.segment_reduce(dev(src), dev(index), n_seg, "sum")
+
+
+def test_segment_reduce_run_structured_index(ops):
+    """Morton-ordered points give long runs of equal segment ids (whole waves adding into one output address): the
+    shapes of the discriminative loss, repeated; sums against float64."""
+    rng = np.random.default_rng(99)
+    for rep in range(12):
+        n = int(rng.integers(15_000, 30_000))
+        n_seg = int(rng.integers(3, 24))
+        runs = rng.integers(1, 400, size=n)
+        index = np.repeat(rng.integers(0, n_seg, size=n), runs)[:n]
+        index[[1638, 3276, 8192]] = n_seg  # rows whose 5 columns straddle two thread blocks, alone in their segment
+        n_seg += 1
+        for c in (5, 1):
+            src = (rng.normal(size=(n, c)) * 3).astype(np.float32)
+            want = np.zeros((n_seg, c))
+            np.add.at(want, index, src.astype(np.float64))
+            got = ops.segment_reduce(dev(src), dev(index), n_seg, "sum")
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=5e-3)
+            cnt = np.maximum(np.bincount(index, minlength=n_seg), 1).reshape(-1, 1)
+            got = ops.segment_reduce(dev(src), dev(index), n_seg, "mean")
+            np.testing.assert_allclose(got.cpu().numpy(), want / cnt, rtol=1e-5, atol=1e-4)
+
+
 def test_instance_iou_and_intersections_match_goldens(ops, oracle):
     z = np.load(os.path.join(GOLD, "loss_cases.npz"))
     offs = z["cluster_offsets"]

@@ -261,3 +261,21 @@ def test_ply_io_and_checkpoint_layout(tmp_path):
     missing, unexpected = pio.load_checkpoint(ck, net2, weight_name="best_miou", optimizer=opt2)
     assert not missing and not unexpected
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+
+
+def test_gt_layout_histogram_matches_oracle():
+    """torch_points_kernels.gt_layout (one (batch, id) histogram) against the oracle's per-element loops, including
+    ids with no point, batch elements without instances and unsorted batch vectors."""
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd.torch_points_kernels import gt_layout
+    rng = np.random.default_rng(3)
+    for n, nb, kmax in [(1, 1, 0), (50, 1, 3), (4000, 4, 9), (3000, 6, 1), (2000, 3, 0)]:
+        batch = rng.integers(0, nb, n)
+        batch[0] = nb - 1
+        gt = rng.integers(0, kmax + 1, n) * (rng.random(n) < 0.6)
+        gt[(batch == 1) & (gt == 2)] = 0  # a hole in the id range of one element
+        off, sizes = gt_layout(torch.from_numpy(gt), torch.from_numpy(batch))
+        want_off, want_sizes = oracle.gt_layout(gt, batch)
+        assert off.dtype == torch.int32 and sizes.dtype == torch.int32
+        np.testing.assert_array_equal(off.numpy(), want_off)
+        np.testing.assert_array_equal(sizes.numpy(), want_sizes)
