@@ -340,6 +340,19 @@ int pp_proposal_intersections(const int32_t* prop_offsets, const int64_t* prop_p
                               int64_t n_points, int32_t* inter, void* workspace, size_t workspace_bytes,
                               pp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * f2  exact 1-nearest neighbour     replaces: torch_geometric knn(x=ref, y=query, k=1) / knn_interpolate(k=1) of the
+ *                                  full-resolution back-projection, metrics/panoptic_tracker_pointgroup_npm3d.py:564-566,
+ *                                  593-618; KD-tree query of the cylinder centre label, data_transform/transforms.py:239-240
+ * ref [n_ref,dim], query [n_query,dim] float32, dim in {2,3}.  idx[q] = index of the nearest reference point, dist2[q] =
+ * ((dx*dx + dy*dy) + dz*dz) in float32 without FMA; ties -> smallest reference index.  cell > 0 = edge of the search
+ * grid (2-4x the reference spacing).  max_dist > 0: queries with no reference point within max_dist get idx -1 and
+ * dist2 +inf; max_dist <= 0: unbounded exact search.  n_ref == 0: every idx is -1.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_nearest_workspace(int64_t n_ref);
+int pp_nearest(const float* ref, int64_t n_ref, const float* query, int64_t n_query, int32_t dim, float cell,
+               float max_dist, int64_t* idx, float* dist2, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,3 +295,84 @@ def cylinder_tiles(pos, centres_xy, radius):
         d2 = (dy.astype(np.float64) ** 2 + (dx * dx).astype(np.float64)).astype(np.float32)  # fmaf(dy, dy, dx * dx)
         out.append(np.nonzero(d2 <= r2)[0])
     return out
+
+
+def grid_cylinder_centres(pos, grid_size, u_based=False):
+    """Centre grid of GridCylinderSampling -- torch_points3d/core/data_transform/transforms.py:224-243: PCA(n_components=2)
+    of the xy coordinates, bounding box in the PCA frame, centres every grid_size from (min) to (max + grid_size)
+    exclusive (np.arange), x outer / y inner, mapped back with inverse_transform.  sklearn's PCA is the reference's own
+    dependency; u_based=True re-applies the sign rule of the pinned sklearn 0.24.2 (svd_flip on U: the sample with the
+    largest |projection| gets a positive coordinate), False keeps the installed sklearn's (>= 1.5: largest |entry| of each
+    component positive).  Returns float64 [m,2] (all grid nodes, empty cylinders included)."""
+    from sklearn.decomposition import PCA
+    xy = np.asarray(pos, np.float32)[:, :2]
+    pca = PCA(n_components=2)
+    pca.fit(xy)
+    comps = pca.components_.copy()
+    if u_based:
+        proj = np.dot(xy - pca.mean_, comps.T)
+        sel = np.argmax(np.abs(proj), axis=0)
+        comps = comps * np.sign(proj[sel, np.arange(2)])[:, None]
+    red = np.dot(xy - pca.mean_, comps.T)
+    minx, miny = np.min(red[:, 0]), np.min(red[:, 1])
+    maxx, maxy = np.max(red[:, 0]), np.max(red[:, 1])
+    out = []
+    for c_x in np.arange(minx, maxx + grid_size, grid_size):
+        for c_y in np.arange(miny, maxy + grid_size, grid_size):
+            out.append(np.dot(np.vstack((c_x, c_y)).T, comps) + pca.mean_)  # = pca.inverse_transform
+    return np.stack(out).reshape(-1, 2).astype(np.float64)
+
+
+def nearest(ref, query, max_dist=0.0):
+    """torch_geometric knn(x=ref, y=query, k=1) by brute force (metrics/panoptic_tracker_pointgroup_npm3d.py:593):
+    float32 squared distance ((dx*dx + dy*dy) + dz*dz), first minimum = smallest reference index.
+    Returns (idx int64 [-1 where nothing within max_dist > 0], dist2 float32)."""
+    ref = np.asarray(ref, np.float32)
+    query = np.asarray(query, np.float32)
+    nq, dim = query.shape
+    idx = np.full(nq, -1, np.int64)
+    d2 = np.full(nq, np.inf, np.float32)
+    if len(ref) == 0:
+        return idx, d2
+    for s in range(0, nq, 1024):
+        q = query[s:s + 1024]
+        d = np.zeros((len(q), len(ref)), np.float32)
+        for a in range(dim):
+            t = q[:, a:a + 1] - ref[None, :, a]
+            d = d + t * t if a else t * t
+        j = np.argmin(d, axis=1)
+        idx[s:s + 1024] = j
+        d2[s:s + 1024] = d[np.arange(len(q)), j]
+    if max_dist > 0:
+        far = d2 > np.float32(max_dist) * np.float32(max_dist)
+        idx[far] = -1
+        d2[far] = np.inf
+    return idx, d2
+
+
+def back_project(pos_full, votes, prediction_count, ins_pre, stuff_classes, max_dist=1.0, min_points=10):
+    """Full-resolution assignment at the end of a test area -- metrics/panoptic_tracker_pointgroup_npm3d.py:555-631.
+    pos_full [N,3] is the whole cloud; votes [N,C] / prediction_count [N] / ins_pre [N] (-1 = none) hold what the cylinders
+    produced (rows without a prediction are zero / -1).  Semantic: class votes of the nearest point that has a
+    prediction (knn_interpolate, k=1), argmax.  Instance: label of the nearest point that has an instance (knn, k=1);
+    -1 where the semantic prediction is a stuff class, where that neighbour is farther than max_dist, and for
+    instances left with fewer than min_points points.  Returns (sem int64 [N], ins int64 [N])."""
+    pos_full = np.asarray(pos_full, np.float32)
+    has_sem = np.asarray(prediction_count) > 0
+    j, _ = nearest(pos_full[has_sem], pos_full)
+    full_pred = np.asarray(votes, np.float32)[has_sem][j]
+    sem = np.argmax(full_pred, 1).astype(np.int64)
+    ins_pre = np.asarray(ins_pre, np.int64)
+    has_ins = ins_pre != -1
+    j, d2 = nearest(pos_full[has_ins], pos_full)
+    ins = ins_pre[has_ins][j].copy()
+    for l in np.asarray(stuff_classes).reshape(-1):
+        ins[sem == l] = -1
+    ins[np.sqrt(d2) > max_dist] = -1
+    for l in np.unique(ins):
+        if l == -1:
+            continue
+        m = ins == l
+        if m.sum() < min_points:
+            ins[m] = -1
+    return sem, ins

@@ -678,6 +678,25 @@ def cylinder_tiles(pos, centres_xy, radius):
     return ClusterCSR(offs, out[:total], nc)
 
 
+def nearest(ref, query, cell, max_dist=0.0):
+    """Exact 1-NN of every query row among the reference rows ([n,2] or [n,3] float32): (idx int64, dist2 float32).
+    idx -1 / dist2 inf where no reference point lies within max_dist (> 0); ties -> smallest reference index."""
+    lib = _lib.load()
+    ref = _need(ref, torch.float32, "ref")
+    query = _need(query, torch.float32, "query")
+    if ref.dim() != 2 or query.dim() != 2 or ref.shape[1] != query.shape[1]:
+        raise ValueError("nearest: ref and query must be [n,dim] with the same dim")
+    nq, dim = query.shape
+    dev = query.device
+    idx = torch.empty(nq, dtype=torch.int64, device=dev)
+    d2 = torch.empty(nq, dtype=torch.float32, device=dev)
+    wsb = lib.pp_nearest_workspace(ref.shape[0])
+    ws = _ws(wsb, dev, tag="nearest")
+    _lib.check(lib.pp_nearest(_ptr(ref), ref.shape[0], _ptr(query), nq, dim, float(cell), float(max_dist), _ptr(idx),
+                              _ptr(d2), _ptr(ws), wsb, _stream()), "pp_nearest")
+    return idx, d2
+
+
 def group_by_key(key, n_groups, ids=None):
     lib = _lib.load()
     key = _need(key, torch.int32, "key")

@@ -266,3 +266,84 @@ def tile_batch_gpu(pos, coords, voxel, centres_xy, radius):
     mean_pc = (mean_pc / sizes.clamp(min=1)[:, None].double()).float()
     x = torch.cat([pc - mean_pc[b], pc[:, 2:3]], 1)
     return {"pos": pc, "coords": ci, "batch": b, "x": x, "origin_id": idx, "tiles": tiles}
+
+
+def grid_cylinder_centres(pos, grid_size, svd_flip="u"):
+    """Centre grid of GridCylinderSampling on the device (torch_points3d/core/data_transform/transforms.py:224-243):
+    PCA of the xy coordinates (mean + 2x2 covariance reduced on the GPU in float64, eigen-decomposition of the 2x2 matrix
+    on the host), bounding box in the PCA frame, nodes every grid_size from min to (max + grid_size) exclusive with x
+    outer / y inner, mapped back to world xy.  svd_flip picks the sign of the axes, which moves the grid when the extent
+    is not a multiple of grid_size: "u" = the reference's pinned sklearn 0.24.2 (the sample with the largest |projection|
+    gets a positive coordinate), "v" = sklearn >= 1.5 (largest |entry| of each axis positive).  float64 [m,2] on
+    pos.device; empty cylinders are still included (see grid_cylinder_tiles)."""
+    if svd_flip not in ("u", "v"):
+        raise ValueError("svd_flip must be 'u' or 'v'")
+    xy = pos[:, :2].double()
+    n = xy.shape[0]
+    if n < 2:
+        raise ValueError("grid_cylinder_centres needs at least two points")
+    mean = xy.mean(0)
+    xc = xy - mean
+    cov = (xc.T @ xc / (n - 1)).cpu().numpy()
+    w, v = np.linalg.eigh(cov)                       # ascending eigenvalues, eigenvectors in columns
+    comps = torch.from_numpy(np.ascontiguousarray(v[:, ::-1].T)).to(xy.device)  # rows = axes, largest variance first
+    red = xc @ comps.T
+    if svd_flip == "u":
+        sel = red.abs().argmax(0)
+        sign = torch.sign(red[sel, torch.arange(2, device=xy.device)])
+    else:
+        sel = comps.abs().argmax(1)
+        sign = torch.sign(comps[torch.arange(2, device=xy.device), sel])
+    sign = torch.where(sign == 0, torch.ones_like(sign), sign)
+    comps = comps * sign[:, None]
+    red = red * sign[None, :]
+    lo, hi = red.min(0)[0].cpu().numpy(), red.max(0)[0].cpu().numpy()
+    gx = np.arange(lo[0], hi[0] + grid_size, grid_size)
+    gy = np.arange(lo[1], hi[1] + grid_size, grid_size)
+    nodes = np.stack([np.repeat(gx, len(gy)), np.tile(gy, len(gx))], 1)
+    return torch.from_numpy(nodes).to(xy.device) @ comps + mean
+
+
+def grid_cylinder_tiles(pos, radius, grid_size=None, labels=None, svd_flip="u", nn_cell=None):
+    """GridCylinderSampling (transforms.py:182-267) for a whole scene on the device: the PCA-aligned centre grid, one
+    vertical cylinder of `radius` per node (CylinderSampling, inclusive radius), nodes without points dropped.
+    Returns (tiles: ops.ClusterCSR with ascending origin ids per kept cylinder -- the reference lists them in KD-tree
+    order --, centres float32 [k,2], centre_label: labels[nearest point in xy] per kept cylinder or None)."""
+    grid_size = float(radius if grid_size is None else grid_size)
+    cen = grid_cylinder_centres(pos, grid_size, svd_flip).float()
+    tiles = ops.cylinder_tiles(pos, cen.contiguous(), radius)
+    keep = torch.nonzero(tiles.sizes() > 0).view(-1)
+    if keep.numel() < tiles.n:
+        tiles = tiles.select(keep)
+        cen = cen[keep]
+    centre_label = None
+    if labels is not None:
+        idx, _ = ops.nearest(pos[:, :2].contiguous(), cen.contiguous(), cell=float(nn_cell or max(grid_size / 4, 1e-3)))
+        centre_label = labels[idx]
+    return tiles, cen, centre_label
+
+
+def back_project(pos_full, votes, prediction_count, ins_pre, stuff_classes, max_dist=1.0, min_points=10, cell=0.25):
+    """Full-resolution assignment at the end of a test area (metrics/panoptic_tracker_pointgroup_npm3d.py:555-631) on the
+    device.  pos_full [N,3] is the whole cloud, votes [N,C] / prediction_count [N] / ins_pre [N] (-1 = none) hold what the
+    cylinders produced.  Semantic: votes of the nearest point that has a prediction (knn_interpolate with k = 1 is a
+    copy), argmax.  Instance: label of the nearest point that has an instance; -1 where the semantic prediction is a
+    stuff class, where that neighbour is farther than max_dist, and for instances left with fewer than min_points
+    points.  `cell` = edge of the search grid (2-4x the sub-sampling voxel).  Returns (sem int64 [N], ins int64 [N])."""
+    pos_full = pos_full.float().contiguous()
+    has_sem = torch.nonzero(prediction_count > 0).view(-1)
+    j, _ = ops.nearest(pos_full[has_sem], pos_full, cell)
+    sem = torch.argmax(votes[has_sem[j]], 1)
+    ins_pre = ins_pre.long()
+    has_ins = torch.nonzero(ins_pre != -1).view(-1)
+    # instance labels only matter within max_dist: bound the search (same result, far fewer rings for far points)
+    j, d2 = ops.nearest(pos_full[has_ins], pos_full, cell, max_dist=float(max_dist) * 1.0001)
+    ins = torch.where(j >= 0, ins_pre[has_ins[j.clamp(min=0)]], torch.full_like(j, -1))
+    stuff = torch.as_tensor(stuff_classes, device=sem.device).view(-1)
+    ins[torch.isin(sem, stuff)] = -1
+    ins[torch.sqrt(d2) > max_dist] = -1
+    if ins.numel():
+        lab, inv, cnt = torch.unique(ins, return_inverse=True, return_counts=True)
+        small = (cnt < min_points) & (lab != -1)
+        ins[small[inv]] = -1
+    return sem, ins

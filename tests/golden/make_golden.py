@@ -302,7 +302,63 @@ def make_final_eval():
     print("final_eval:", {k: cases[k].tolist() for k in cases if k.startswith("log_e0_") and ("mean" in k or "mIoU" in k or "F1" in k)})
 
 
+def make_grid_cylinders():
+    """Runs the reference's OWN GridCylinderSampling + CylinderSampling (torch_points3d/core/data_transform/transforms.py:
+    182-267, 388-441) on a synthetic rotated strip of points.  The module cannot be imported (torch_geometric, numba, ...),
+    so the two class definitions are extracted with `ast` and executed with their real dependencies (sklearn KDTree and
+    PCA, installed here: 1.7.2) and a minimal stand-in for torch_geometric's Data container (attribute bag)."""
+    import ast
+    import itertools
+    from sklearn.decomposition import PCA
+    from sklearn.neighbors import KDTree
+
+    class Data:
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def keys(self):
+            return [k for k in self.__dict__ if not k.startswith("_")]
+
+        def __getitem__(self, k):
+            return getattr(self, k)
+
+    path = os.path.join(REF, "torch_points3d/core/data_transform/transforms.py")
+    tree = ast.parse(open(path).read())
+    classes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("GridCylinderSampling", "CylinderSampling")]
+    ns = {"np": np, "torch": torch, "KDTree": KDTree, "KDTREE_KEY": "kd_tree", "PCA": PCA, "Data": Data,
+          "GridSampling3D_PCA": lambda size: None, "tq": lambda x: x, "itertools": itertools}
+    exec(compile(ast.Module(body=classes, type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(31)
+    n = 6000
+    p = np.stack([rng.uniform(-45, 45, n), rng.uniform(-12, 12, n), rng.normal(0, 1.5, n)], 1)
+    p[: n // 6, 1] += 20  # an L-shaped annex, so some grid nodes have no points
+    p[: n // 6, 0] = rng.uniform(20, 45, n // 6)
+    a = 0.6
+    rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    p[:, :2] = p[:, :2] @ rot.T + [130.0, -40.0]
+    pos = p.astype(np.float32)
+    y = rng.integers(0, 9, n)
+    data = Data(pos=torch.from_numpy(pos.copy()), y=torch.from_numpy(y), origin_id=torch.arange(n))
+    radius, grid = 8.0, 8.0
+    out = ns["GridCylinderSampling"](radius, grid)(data)
+    offsets = np.cumsum([0] + [len(d.origin_id) for d in out]).astype(np.int64)
+    origin = np.concatenate([d.origin_id.numpy() for d in out])
+    centred = np.concatenate([d.pos.numpy() for d in out])
+    centre_label = np.array([int(d.center_label) for d in out])
+    # centre of every kept cylinder: original minus centred xy of its first point (float32 rounding of the subtraction)
+    centres = np.stack([pos[o.origin_id[0], :2].astype(np.float64) - o.pos[0, :2].numpy().astype(np.float64) for o in out])
+    np.savez_compressed(os.path.join(OUT, "grid_cylinder_cases.npz"), pos=pos, y=y, radius=radius, grid_size=grid,
+                        offsets=offsets, origin=origin.astype(np.int32), centred_pos=centred, centre_label=centre_label,
+                        centres=centres)
+    print("grid cylinders:", len(out), "kept cylinders,", len(origin), "memberships")
+
+
 if __name__ == "__main__":
+    if "--grid-only" in sys.argv:
+        make_grid_cylinders()
+        sys.exit(0)
     if "--final-eval-only" in sys.argv:
         make_final_eval()
         sys.exit(0)
@@ -313,6 +369,7 @@ if __name__ == "__main__":
     make_losses()
     make_nms()
     make_final_eval()
+    make_grid_cylinders()
 # tests/golden/ref_written_npm3d_like.ply (+ _values.npz): 50 vertices written by the reference's own
 # torch_points3d/models/panoptic/ply.py:write_ply (fields x, y, z, scalar_class, scalar_label as float32, the way
 # CloudCompare exports NPM3D) -- generated once with the snippet in the commit that added panopticsegforlargescalepointcloud_amd/io.py.

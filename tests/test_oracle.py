@@ -374,3 +374,38 @@ def test_voxelize_and_cylinders_restatements(oracle):
     for c, t in zip(cen, tiles):
         want = np.sort(tree.query_radius(c[None].astype(np.float64), r=1.7)[0])
         assert len(np.setxor1d(t, want)) <= 1      # float32 vs float64 distance exactly at the rim
+
+
+def test_grid_cylinders_match_reference_golden(oracle):
+    """oracle.grid_cylinder_centres + cylinder_tiles + nearest against the output of the reference's OWN
+    GridCylinderSampling / CylinderSampling run here (tests/golden/make_golden.py::make_grid_cylinders): same kept
+    cylinders in the same order, same member sets (the reference lists them in KD-tree order), same centre labels."""
+    z = np.load(os.path.join(GOLD, "grid_cylinder_cases.npz"))
+    pos, radius, grid = z["pos"], float(z["radius"]), float(z["grid_size"])
+    cen = oracle.grid_cylinder_centres(pos, grid)
+    tiles = oracle.cylinder_tiles(pos, cen.astype(np.float32), radius)
+    keep = [i for i, t in enumerate(tiles) if len(t)]
+    off = z["offsets"]
+    assert len(keep) == len(off) - 1 and len(keep) < len(tiles)  # some grid nodes are empty and dropped
+    np.testing.assert_allclose(cen[keep], z["centres"], atol=1e-4)
+    for k, i in enumerate(keep):
+        members = z["origin"][off[k]:off[k + 1]]
+        assert np.array_equal(np.sort(members), tiles[i])
+        # centred positions: pos[members] - centre (xy), z untouched
+        want = z["centred_pos"][off[k]:off[k + 1]]
+        got = pos[members].copy()
+        got[:, :2] -= cen[i].astype(np.float32)
+        np.testing.assert_allclose(got, want, atol=1e-4)
+    j, _ = oracle.nearest(pos[:, :2], cen[keep].astype(np.float32))
+    assert np.array_equal(z["y"][j], z["centre_label"])
+
+
+def test_nearest_bruteforce_conventions(oracle):
+    ref = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0], [5, 5, 5]], np.float32)
+    q = np.array([[0.4, 0, 0], [0.5, 0, 0], [0.9, 0, 0], [9, 9, 9]], np.float32)
+    idx, d2 = oracle.nearest(ref, q)
+    assert idx.tolist() == [0, 0, 1, 3]  # equidistant -> smallest index; duplicates -> first
+    idx, d2 = oracle.nearest(ref, q, max_dist=1.0)
+    assert idx.tolist() == [0, 0, 1, -1] and np.isinf(d2[3])
+    idx, _ = oracle.nearest(ref[:0], q)
+    assert (idx == -1).all()

@@ -66,3 +66,100 @@ def test_tile_batch_on_the_gpu_matches_numpy_collation():
     # the cylinder mean is accumulated in float64 on the GPU and in float32 (pairwise) by NumPy: ~1e-4 m apart
     np.testing.assert_allclose(got["pos"].cpu().numpy(), want["pos"], atol=3e-4)
     np.testing.assert_allclose(got["x"].cpu().numpy(), want["x"], atol=5e-4)
+
+
+def _cloud(rng, n, dim, spread=40.0):
+    """clustered surface-like cloud with a few far outliers"""
+    c = rng.uniform(-spread, spread, size=(max(n // 200, 1), dim))
+    p = c[rng.integers(0, len(c), n)] + rng.normal(size=(n, dim)) * rng.uniform(0.05, 2.0, size=(n, 1))
+    p[: max(n // 500, 1)] += rng.normal(size=(max(n // 500, 1), dim)) * 400
+    return p.astype(np.float32)
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_nearest_matches_bruteforce_bit_exact(dim):
+    """pp_nearest against the brute-force oracle: indices and float32 squared distances identical, including ties
+    (duplicated and lattice points), far outliers, a bounded search and an empty reference set."""
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd import ops
+    rng = np.random.default_rng(5 + dim)
+    dev = torch.device("cuda")
+    for n_ref, n_q, cell in [(3000, 6000, 0.5), (1, 500, 1.0), (5000, 4000, 0.05), (2000, 3000, 7.0), (40, 2000, 0.3)]:
+        ref = _cloud(rng, n_ref, dim)
+        q = np.concatenate([_cloud(rng, n_q // 2, dim), ref[rng.integers(0, n_ref, n_q // 2)] +
+                            rng.normal(size=(n_q // 2, dim)).astype(np.float32) * 0.02])
+        ref[n_ref // 2:n_ref // 2 + 20] = ref[:20]                    # duplicates: smallest index must win
+        for max_dist in (0.0, 1.0):
+            want_i, want_d = oracle.nearest(ref, q, max_dist)
+            got_i, got_d = ops.nearest(torch.from_numpy(ref).to(dev), torch.from_numpy(q).to(dev), cell, max_dist)
+            assert np.array_equal(got_i.cpu().numpy(), want_i)
+            assert np.array_equal(got_d.cpu().numpy(), want_d)
+    # lattice: many exact ties
+    g = np.stack(np.meshgrid(*[np.arange(12)] * dim, indexing="ij"), -1).reshape(-1, dim).astype(np.float32)
+    q = (g[rng.integers(0, len(g), 3000)] + rng.choice([0.0, 0.5], size=(3000, dim))).astype(np.float32)
+    want_i, want_d = oracle.nearest(g, q)
+    got_i, got_d = ops.nearest(torch.from_numpy(g).to(dev), torch.from_numpy(q).to(dev), 1.0)
+    assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_d.cpu().numpy(), want_d)
+    got_i, got_d = ops.nearest(torch.from_numpy(g[:0]).to(dev), torch.from_numpy(q).to(dev), 1.0)
+    assert (got_i == -1).all() and torch.isinf(got_d).all()
+    with pytest.raises(Exception):
+        ops.nearest(torch.from_numpy(g).to(dev) * 1e9, torch.from_numpy(q).to(dev), 1.0)
+
+
+def test_grid_cylinder_tiles_match_reference_golden():
+    """scene.grid_cylinder_tiles (device PCA grid + cylinders + centre labels) against the output of the reference's
+    own GridCylinderSampling (golden fixture, sklearn >= 1.5 sign rule = "v") and, for the pinned-sklearn sign rule
+    ("u"), against the oracle restatement."""
+    import os
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd import scene as sc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_cylinder_cases.npz"))
+    dev = torch.device("cuda")
+    pos, radius, grid = z["pos"], float(z["radius"]), float(z["grid_size"])
+    tiles, cen, lab = sc.grid_cylinder_tiles(torch.from_numpy(pos).to(dev), radius, grid,
+                                             labels=torch.from_numpy(z["y"]).to(dev), svd_flip="v")
+    off = z["offsets"]
+    assert tiles.n == len(off) - 1
+    # the reference's PCA runs in float32 inside sklearn (axes good to ~4e-5 rad => centres good to a few mm over this
+    # 100 m strip); the device path reduces in float64.  Tolerance: 2 cm on 8 m spacing; memberships may differ only for
+    # points within that distance of a cylinder wall.
+    np.testing.assert_allclose(cen.cpu().numpy(), z["centres"], atol=2e-2)
+    got_off, got_pts = tiles.offsets.cpu().numpy(), tiles.points.cpu().numpy()
+    differing = 0
+    for k in range(tiles.n):
+        got = got_pts[got_off[k]:got_off[k + 1]]
+        assert np.all(np.diff(got) > 0)
+        sym = np.setxor1d(got, z["origin"][off[k]:off[k + 1]])
+        differing += len(sym)
+        if len(sym):
+            d = np.linalg.norm(pos[sym, :2] - z["centres"][k], axis=1)
+            assert np.all(np.abs(d - radius) < 3e-2)
+    assert differing <= 0.002 * len(z["origin"])
+    assert (lab.cpu().numpy() != z["centre_label"]).sum() <= 1
+    want = oracle.grid_cylinder_centres(pos, grid, u_based=True)
+    got = sc.grid_cylinder_centres(torch.from_numpy(pos).to(dev), grid, svd_flip="u").cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=2e-2)
+
+
+def test_back_project_matches_oracle():
+    """full-resolution back-projection (nearest predicted point, stuff / distance / size filters) vs the oracle."""
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd import scene as sc
+    rng = np.random.default_rng(8)
+    dev = torch.device("cuda")
+    n = 12000
+    pos = _cloud(rng, n, 3, spread=15.0)
+    sub = rng.random(n) < 0.3                                   # the sub-sampled cloud the cylinders saw
+    votes = np.zeros((n, 9), np.float32)
+    votes[sub] = rng.random((int(sub.sum()), 9)).astype(np.float32)
+    count = sub.astype(np.int64) * rng.integers(1, 4, n)
+    ins = np.full(n, -1, np.int64)
+    has = sub & (rng.random(n) < 0.6)
+    ins[has] = rng.integers(0, 150, int(has.sum()))
+    want_sem, want_ins = oracle.back_project(pos, votes, count, ins, [0, 1, 5])
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got_sem, got_ins = sc.back_project(t(pos), t(votes), t(count), t(ins), [0, 1, 5], cell=0.5)
+    assert np.array_equal(got_sem.cpu().numpy(), want_sem)
+    assert np.array_equal(got_ins.cpu().numpy(), want_ins)
+    assert (want_ins == -1).any() and (want_ins >= 0).any()
