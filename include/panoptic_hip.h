@@ -165,6 +165,14 @@ int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, in
                   const float* shift, int32_t relu, const float* residual,
                   const int32_t* row_order /*optional tile schedule (pp_tile_order); NULL = row order*/, float* out,
                   pp_stream_t stream);
+/* bfloat16 compute variant (BASELINE.json configs[4], "bf16"): same arguments and fp32 tensors in memory; features and
+ * weights are rounded to bfloat16 (nearest even) in registers, products accumulate in fp32 on
+ * v_mfma_f32_16x16x16_bf16 -- torch.autocast(bfloat16) semantics for the convolution.  Needs cin % 16 == 0 per source,
+ * K <= 28 and < 4 GiB per source (PP_ERR_INVALID otherwise; callers keep the fp32 entry for those layers). */
+int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                       const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
+                       const float* scale, const float* shift, int32_t relu, const float* residual,
+                       const int32_t* row_order, float* out, pp_stream_t stream);
 
 /* K3b/K4b  block-compacted rulebook and the convolution on it (the fast path for 3x3x3 kernels with Cin % 16 == 0).
  * The kernel map is regrouped per block of 64 consecutive output rows and per offset into compact lists of
@@ -189,6 +197,10 @@ int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1,
  * in is [n_in,cin] (n_in bounds the gathers: indices in nbr are < n_in), dout is [n_out,cout]. */
 int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
                          const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream);
+/* bfloat16 compute variant: in and dout rounded to bfloat16 in registers, fp32 accumulation and fp32 dw.
+ * Needs a kernel map (nbr != NULL), cout <= 192 and in < 4 GiB. */
+int pp_spconv_bwd_weight_bf16(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                              const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6  batch-norm pieces on [n,C]  replaces: ME.MinkowskiBatchNorm (= BatchNorm1d on F), api_modules.py:40,53,269

@@ -376,3 +376,15 @@ def back_project(pos_full, votes, prediction_count, ins_pre, stuff_classes, max_
         if m.sum() < min_points:
             ins[m] = -1
     return sem, ins
+
+
+def round_bf16(x):
+    """float32 -> nearest bfloat16 (ties to even) -> float32: the operand rounding of the bf16 convolution entries
+    (pp_spconv_fwd_bf16 / pp_spconv_bwd_weight_bf16).  The oracle of those entries is the fp32 restatement applied to
+    inputs rounded this way -- products of two bfloat16 numbers are exact in fp32, so only the summation order differs."""
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = r.astype(np.uint32).view(np.float32).copy()
+    out[~np.isfinite(x)] = x[~np.isfinite(x)]
+    return out.reshape(x.shape)

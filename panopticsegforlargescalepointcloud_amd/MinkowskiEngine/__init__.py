@@ -42,6 +42,27 @@ COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
 # indirection (scattered index loads / output stores, one radix sort per level) costs more than it saves end to end
 # (242 -> 251..257 ms per step for windows of 64..65536 rows, profiles/r01_i_notes.md).
 TILE_WINDOW = int(os.environ.get("PP_TILE_WINDOW", "0"))
+# compute dtype of the sparse convolutions: "fp32" (the reference's; parity runs) or "bf16" (BASELINE.json configs[4]):
+# operands rounded to bfloat16 in registers, fp32 accumulation, fp32 tensors in memory -- what torch.autocast(bfloat16)
+# does to a convolution.  `conv_autocast()` switches it for a region of code.
+_CONV_BF16 = [os.environ.get("PP_CONV_DTYPE", "fp32").lower() == "bf16"]
+
+
+class conv_autocast:
+    """with ME.conv_autocast(): ... -- bfloat16 compute for every sparse convolution launched inside (forward, input
+    and weight gradients of the layers the bf16 kernels take; the 4-channel input layer stays fp32)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _CONV_BF16[0]
+        _CONV_BF16[0] = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _CONV_BF16[0] = self.prev
+        return False
 
 
 def _want_rulebook(conv, x, ts_out, cin, sign):
@@ -316,9 +337,10 @@ class _SparseConvFn(torch.autograd.Function):
         feats = feats.contiguous()
         packed = ops.pack_weight(kernel)
         cout = kernel.shape[-1]
-        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=order_out)
+        bf16 = _CONV_BF16[0]
+        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=order_out, bf16=bf16)
         ctx.save_for_backward(feats, kernel)
-        ctx.nbr, ctx.inv_fn, ctx.K, ctx.order_in = nbr, inv_fn, K, order_in
+        ctx.nbr, ctx.inv_fn, ctx.K, ctx.order_in, ctx.bf16 = nbr, inv_fn, K, order_in, bf16
         return out
 
     @staticmethod
@@ -328,9 +350,10 @@ class _SparseConvFn(torch.autograd.Function):
         din = dw = None
         if ctx.needs_input_grad[0]:
             packed_t = ops.pack_weight(kernel, transpose=True)
-            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in)
+            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in,
+                                 bf16=ctx.bf16)
         if ctx.needs_input_grad[1]:
-            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K).reshape(kernel.shape)
+            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K, bf16=ctx.bf16).reshape(kernel.shape)
         return din, dw, None, None, None, None, None, None
 
 
@@ -609,7 +632,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
                                   relu=relu, residual=res)
     else:
         feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
-                               scale=scale, shift=shift, relu=relu, residual=res, row_order=cm.tile_order(ts_out))
+                               scale=scale, shift=shift, relu=relu, residual=res, row_order=cm.tile_order(ts_out),
+                               bf16=_CONV_BF16[0])
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

@@ -44,12 +44,14 @@ SIGNATURES = {
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
+    "pp_spconv_fwd_bf16": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_rulebook_blocks": (i64, [i64]),
     "pp_rulebook_workspace": (sz, [i64]),
     "pp_rulebook_offsets": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
     "pp_rulebook_fill": (C.c_int, [vp, i64, vp, vp, vp, vp]),
     "pp_spconv_fwd_rb": (C.c_int, [vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp]),
     "pp_spconv_bwd_weight": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
+    "pp_spconv_bwd_weight_bf16": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
     "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),
     "pp_affine_act": (C.c_int, [vp, i64, i32, vp, vp, i32, f32, vp, vp, vp]),
     "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),

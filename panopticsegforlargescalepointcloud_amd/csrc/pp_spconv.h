@@ -3,6 +3,19 @@
 #include "pp_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 floats -> 4 bfloat16 (round to nearest even; two v_cvt_pk_bf16_f32), packed as the A / B operand of
+// v_mfma_f32_16x16x16_bf16: lane (i, q) supplies k = 4q .. 4q+3
+__device__ __forceinline__ s16x4 pp_bf16x4(f32x4 v) {
+  const bf16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
+  const bf16x2 hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+  const u32x2 p = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, p);
+}
 
 struct SpconvArgs {
   const float* in0;
@@ -16,6 +29,7 @@ struct SpconvArgs {
   float* out;
   int64_t n_out;
   int c0, c1, K, cout, NT, relu;
+  int bf16;  // operands rounded to bfloat16 in registers, fp32 accumulation (v3 kernel only)
 };
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
@@ -34,4 +48,4 @@ int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStre
 // pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows
 bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr);
 int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* dout, int cout, const int32_t* nbr,
-                          int K, int64_t n_out, float* dw, hipStream_t s);
+                          int K, int64_t n_out, float* dw, int bf16, hipStream_t s);

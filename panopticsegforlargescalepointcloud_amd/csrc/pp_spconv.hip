@@ -234,11 +234,10 @@ static void launch_fwd(int ntw, dim3 grid, hipStream_t s, const SpconvArgs& a) {
   }
 }
 
-extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
-                             const float* packed_weight,
-                             const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
-                             const float* shift, int32_t relu, const float* residual, const int32_t* row_order,
-                             float* out, pp_stream_t stream) {
+static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                           const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
+                           const float* scale, const float* shift, int32_t relu, const float* residual,
+                           const int32_t* row_order, float* out, int bf16, pp_stream_t stream) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
@@ -249,7 +248,7 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
   SpconvArgs a;
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
   a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
-  a.NT = pp_nt(cout); a.relu = relu;
+  a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16;
   const int max_ntw = mode16 ? 4 : 7;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
@@ -260,9 +259,12 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
     const char* e = getenv("PP_DENSE_VER");
     dense_ver = e ? atoi(e) : 3;
   }
-  if (mode16 && dense_ver >= 3 && K <= 28 && ntw <= 4 && pp_spconv_fwd3_ok(a, n_in)) {
+  if (mode16 && (dense_ver >= 3 || bf16) && K <= 28 && ntw <= 4 && pp_spconv_fwd3_ok(a, n_in)) {
     int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, pp_s(stream));
     if (rc != PP_OK) return rc;
+  } else if (bf16) {
+    pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
+    return PP_ERR_INVALID;
   } else if (mode16 && dense_ver >= 2 && K <= 28 && ntw <= 4) {
     int rc = pp_spconv_fwd2_launch(a, ntw, (unsigned)groups, pp_s(stream));
     if (rc != PP_OK) return rc;
@@ -272,6 +274,21 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
     launch_fwd<false>(ntw, grid, pp_s(stream), a);
   PP_LAUNCH_CHECK();
   return PP_OK;
+}
+
+extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                             const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
+                             const float* scale, const float* shift, int32_t relu, const float* residual,
+                             const int32_t* row_order, float* out, pp_stream_t stream) {
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
+                         row_order, out, 0, stream);
+}
+extern "C" int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                                  const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out,
+                                  int32_t cout, const float* scale, const float* shift, int32_t relu,
+                                  const float* residual, const int32_t* row_order, float* out, pp_stream_t stream) {
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
+                         row_order, out, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,8 +341,9 @@ __global__ __launch_bounds__(256) void k_spconv_bwd_weight(const float* __restri
   }
 }
 
-extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
-                                    const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream) {
+static int spconv_bwd_weight_impl(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                  const int32_t* nbr, int32_t K, int64_t n_out, float* dw, int bf16,
+                                  pp_stream_t stream) {
   PP_REQUIRE(in && dout && dw, "pp_spconv_bwd_weight: null pointer");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_bwd_weight: a kernel map is required unless K == 1");
   PP_REQUIRE(cout <= 192, "pp_spconv_bwd_weight: cout > 192 unsupported");
@@ -333,8 +351,12 @@ extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, 
   PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
   if (n_out == 0) return PP_OK;
   static const int bww_ver = getenv("PP_BWW_VER") ? atoi(getenv("PP_BWW_VER")) : 2;
-  if (bww_ver >= 2 && pp_spconv_bww2_ok(cin, cout, n_in, nbr))
-    return pp_spconv_bww2_launch(in, cin, n_in, dout, cout, nbr, K, n_out, dw, s);
+  if ((bww_ver >= 2 || bf16) && pp_spconv_bww2_ok(cin, cout, n_in, nbr))
+    return pp_spconv_bww2_launch(in, cin, n_in, dout, cout, nbr, K, n_out, dw, bf16, s);
+  if (bf16) {
+    pp_set_error("pp_spconv_bwd_weight_bf16: needs a kernel map, cout <= 192 and inputs < 4 GiB");
+    return PP_ERR_INVALID;
+  }
   dim3 grid(pp_blocks(n_out, 4 * BWW_ROWS_PER_WAVE), (unsigned)K, (unsigned)((cin + 15) / 16));
   int nto = pp_nt(cout);
 #define BWW_CASE(N) \
@@ -347,4 +369,13 @@ extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, 
 #undef BWW_CASE
   PP_LAUNCH_CHECK();
   return PP_OK;
+}
+
+extern "C" int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                    const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream) {
+  return spconv_bwd_weight_impl(in, cin, n_in, dout, cout, nbr, K, n_out, dw, 0, stream);
+}
+extern "C" int pp_spconv_bwd_weight_bf16(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                         const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream) {
+  return spconv_bwd_weight_impl(in, cin, n_in, dout, cout, nbr, K, n_out, dw, 1, stream);
 }

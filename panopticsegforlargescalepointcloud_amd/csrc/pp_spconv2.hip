@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd2(SpconvArgs a) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F3_MISSING 0xFFFFFFFFu
 
-template <int NTW, int T>
+template <int NTW, int T, bool BF16>
 __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[4][F2_MAXK][R];
@@ -314,12 +314,26 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
         VALID = 0;                                                    \
     }                                                                 \
   }
+    // BF16: the same registers, rounded to bfloat16 (k = 4q + t of lane (i, q) is exactly the operand layout of
+    // v_mfma_f32_16x16x16_bf16), so one MFMA replaces the four fp32 ones; fp32 accumulation either way
 #define F3_MFMAS(AX, BX, KC)                                                                              \
-  _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                      \
-    if ((m[tt] >> (KC)) & 1u) {                                                                           \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                       \
-          _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                              \
-              acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
+  if constexpr (BF16) {                                                                                   \
+    s16x4 bh_[NTW];                                                                                       \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) bh_[jt] = pp_bf16x4(BX[jt]);                       \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
+      if ((m[tt] >> (KC)) & 1u) {                                                                         \
+        const s16x4 ah_ = pp_bf16x4(AX[tt]);                                                              \
+        _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                \
+            acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah_, bh_[jt], acc[tt][jt], 0, 0, 0);  \
+      }                                                                                                   \
+    }                                                                                                     \
+  } else {                                                                                                \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
+      if ((m[tt] >> (KC)) & 1u) {                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                     \
+            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                            \
+                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
+      }                                                                                                   \
     }                                                                                                     \
   }
     F3_LOADS(A0, B0);
@@ -370,14 +384,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
   }
 }
 
-template <int T>
+template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 64 * T), groups);
   switch (ntw) {
-    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
     default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
   }
   return PP_OK;
@@ -398,7 +412,11 @@ int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned g
   const int T = t_env ? t_env : 2;
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
-  return T == 4 ? launch3_t<4>(a, ntw, groups, a_bytes, w_bytes, s) : launch3_t<2>(a, ntw, groups, a_bytes, w_bytes, s);
+  if (a.bf16)
+    return T == 4 ? launch3_t<4, true>(a, ntw, groups, a_bytes, w_bytes, s)
+                  : launch3_t<2, true>(a, ntw, groups, a_bytes, w_bytes, s);
+  return T == 4 ? launch3_t<4, false>(a, ntw, groups, a_bytes, w_bytes, s)
+                : launch3_t<2, false>(a, ntw, groups, a_bytes, w_bytes, s);
 }
 
 template <int T>

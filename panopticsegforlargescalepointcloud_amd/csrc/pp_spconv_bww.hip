@@ -15,7 +15,7 @@
 
 typedef unsigned int u32;
 
-template <int MT, int NTO>
+template <int MT, int NTO, bool BF16>
 __global__ __launch_bounds__(256) void k_spconv_bww2(const float* __restrict__ in, int cin, u32 in_bytes,
                                                      const float* __restrict__ dout, int cout,
                                                      const int32_t* __restrict__ nbr, int K, int64_t n_out,
@@ -86,6 +86,19 @@ __global__ __launch_bounds__(256) void k_spconv_bww2(const float* __restrict__ i
           B[m][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)(ro + cofs[jt]), 0, 0));
       }
       asm volatile("" ::: "memory");  // keep every load above the sub-step branches (hipcc would sink them)
+      if constexpr (BF16) {
+        // the 4 sub-steps of a lane are k = 4q .. 4q+3 of one v_mfma_f32_16x16x16_bf16: one MFMA instead of four
+        s16x4 ah[MT], bh[NTO];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = pp_bf16x4((f32x4){A[0][mt], A[1][mt], A[2][mt], A[3][mt]});
+#pragma unroll
+        for (int jt = 0; jt < NTO; ++jt) bh[jt] = pp_bf16x4((f32x4){B[0][jt], B[1][jt], B[2][jt], B[3][jt]});
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int jt = 0; jt < NTO; ++jt)
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[jt], acc[mt][jt], 0, 0, 0);
+      } else
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         if (__ballot(s[m] >= 0) != 0ull) {
@@ -122,13 +135,17 @@ bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr) {
 
 template <int MT, int NTO>
 static void bww2_go(dim3 grid, hipStream_t s, const float* in, int cin, u32 in_bytes, const float* dout, int cout,
-                    const int32_t* nbr, int K, int64_t n_out, int rpb, float* dw) {
-  hipLaunchKernelGGL((k_spconv_bww2<MT, NTO>), grid, dim3(256), 0, s, in, cin, in_bytes, dout, cout, nbr, K, n_out,
-                     rpb, dw);
+                    const int32_t* nbr, int K, int64_t n_out, int rpb, float* dw, int bf16) {
+  if (bf16)
+    hipLaunchKernelGGL((k_spconv_bww2<MT, NTO, true>), grid, dim3(256), 0, s, in, cin, in_bytes, dout, cout, nbr, K,
+                       n_out, rpb, dw);
+  else
+    hipLaunchKernelGGL((k_spconv_bww2<MT, NTO, false>), grid, dim3(256), 0, s, in, cin, in_bytes, dout, cout, nbr, K,
+                       n_out, rpb, dw);
 }
 
 int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* dout, int cout, const int32_t* nbr,
-                          int K, int64_t n_out, float* dw, hipStream_t s) {
+                          int K, int64_t n_out, float* dw, int bf16, hipStream_t s) {
   const int nto = (cout + 15) / 16, ntiles = (cin + 15) / 16;
   int mt = nto <= 2 ? 4 : (nto <= 6 ? 2 : 1);
   while (mt > 1 && ntiles % mt != 0) mt >>= 1;
@@ -138,7 +155,7 @@ int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* d
   dim3 grid((unsigned)((n_out + rpb - 1) / rpb), gy, gz);
   const u32 in_bytes = (u32)((uint64_t)n_in * cin * 4u);
 #define BWW2(M, N) \
-  bww2_go<M, N>(grid, s, in, cin, in_bytes, dout, cout, nbr, K, n_out, rpb, dw); break;
+  bww2_go<M, N>(grid, s, in, cin, in_bytes, dout, cout, nbr, K, n_out, rpb, dw, bf16); break;
   switch (mt * 16 + nto) {
     case 4 * 16 + 1: BWW2(4, 1)
     case 4 * 16 + 2: BWW2(4, 2)

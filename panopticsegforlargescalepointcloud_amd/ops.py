@@ -317,8 +317,13 @@ def pack_weight(weight, transpose=False):
     return packed
 
 
+def bf16_conv_supported(c0, c1, K, nbr_given=True):
+    """layers the bfloat16 entries take (the 4-channel input layer and 1x1 shortcuts without a map stay fp32)"""
+    return c0 % 16 == 0 and c1 % 16 == 0 and (c1 == 0 or c1 == c0) and K <= 28
+
+
 def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
-               row_order=None):
+               row_order=None, bf16=False):
     lib = _lib.load()
     in0 = _need(in0, torch.float32, "in0")
     in1 = _need(in1, torch.float32, "in1")
@@ -336,8 +341,9 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.pp_spconv_fwd(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
-                                 _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out), _stream()), "pp_spconv_fwd")
+    fn = lib.pp_spconv_fwd_bf16 if (bf16 and bf16_conv_supported(c0, c1, K)) else lib.pp_spconv_fwd
+    _lib.check(fn(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
+                  _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out), _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None))
@@ -395,14 +401,15 @@ def spconv_fwd_rb(in0, packed, rb, cout, in1=None, scale=None, shift=None, relu=
     return out
 
 
-def spconv_bwd_weight(inp, dout, nbr, K):
+def spconv_bwd_weight(inp, dout, nbr, K, bf16=False):
     lib = _lib.load()
     inp = _need(inp, torch.float32, "in")
     dout = _need(dout, torch.float32, "dout")
     cin, cout = inp.shape[1], dout.shape[1]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=inp.device)
-    _lib.check(lib.pp_spconv_bwd_weight(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw),
-                                        _stream()), "pp_spconv_bwd_weight")
+    fn = lib.pp_spconv_bwd_weight_bf16 if (bf16 and nbr is not None and cout <= 192) else lib.pp_spconv_bwd_weight
+    _lib.check(fn(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw), _stream()),
+               "pp_spconv_bwd_weight")
     return dw
 
 

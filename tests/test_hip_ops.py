@@ -157,6 +157,48 @@ def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 48), (64, 64), (96, 112), (48, 16)])
+def test_spconv_bf16_entries_match_oracle_on_rounded_operands(ops, oracle, cin, cout):
+    """pp_spconv_fwd_bf16 / pp_spconv_bwd_weight_bf16: operands rounded to bfloat16, fp32 accumulation.  Products of
+    bfloat16 numbers are exact in fp32, so against the fp32 oracle fed with pre-rounded operands only the summation order
+    differs (tolerance 1e-4 relative to the output scale); against the un-rounded fp32 result the error is the bf16
+    rounding (~2^-8 per operand), checked loosely.  Includes the fused epilogue, a second source and a strided map."""
+    rng = np.random.default_rng(70 + cin + cout)
+    fine = surface(rng, n=1600, n_batch=2, extent=36)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    for out_c, in_c, sign in [(fine, fine, 1), (coarse, fine, 1), (fine, coarse, -1)]:
+        nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
+        n_in, n_out = len(in_c), len(out_c)
+        x = rng.normal(size=(n_in, cin)).astype(np.float32)
+        W = (rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        sh = rng.normal(size=cout).astype(np.float32)
+        res = rng.normal(size=(n_out, cout)).astype(np.float32)
+        want = oracle.spconv_fwd(oracle.round_bf16(x), oracle.round_bf16(W), nbr, n_out, scale=sc, shift=sh, relu=True,
+                                 residual=res)
+        got = ops.spconv_fwd(dev(x), ops.pack_weight(dev(W)), dev(nbr), n_out, cout, 27, scale=dev(sc), shift=dev(sh),
+                             relu=True, residual=dev(res), bf16=True).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        full = oracle.spconv_fwd(x, W, nbr, n_out, scale=sc, shift=sh, relu=True, residual=res)
+        assert np.abs(got - full).max() < 0.05 * max(1.0, float(np.abs(full).max()))
+        assert np.abs(got - full).max() > 0  # really a different arithmetic
+        g = rng.normal(size=(n_out, cout)).astype(np.float32)
+        xr, gr = oracle.round_bf16(x).astype(np.float64), oracle.round_bf16(g).astype(np.float64)
+        want_dw = np.zeros((27, cin, cout))
+        for k in range(27):
+            m = nbr[k] >= 0
+            want_dw[k] = xr[nbr[k][m]].T @ gr[m]
+        dw = ops.spconv_bwd_weight(dev(x), dev(g), dev(nbr), 27, bf16=True).cpu().numpy()
+        np.testing.assert_allclose(dw, want_dw, rtol=2e-4, atol=2e-3)
+    if cin % 32 == 0:  # two sources (ME.cat fused)
+        nbr = oracle.kernel_map(fine, fine, 3, 1, 1)
+        x0 = rng.normal(size=(len(fine), cin // 2)).astype(np.float32)
+        x1 = rng.normal(size=(len(fine), cin // 2)).astype(np.float32)
+        want = oracle.spconv_fwd(oracle.round_bf16(x0), oracle.round_bf16(W), nbr, len(fine), in1=oracle.round_bf16(x1))
+        got = ops.spconv_fwd(dev(x0), ops.pack_weight(dev(W)), dev(nbr), len(fine), cout, 27, in1=dev(x1), bf16=True)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * float(np.abs(want).max()))
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 48), (96, 32), (4, 16)])
 def test_spconv_backward_matches_oracle(ops, oracle, cin, cout):
     rng = np.random.default_rng(6)
