@@ -93,6 +93,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("PP_HIP_LIB", LIB_PATH)  # profiling builds (profiles/ablate_conv.sh); never a fallback
     if not os.path.exists(LIB_PATH):
         raise PanopticHipError(
             "libpanoptic_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "

@@ -203,8 +203,13 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd2(SpconvArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F3_MISSING 0xFFFFFFFFu
+// F3_ABLATE (profiling builds only, profiles/ablate_conv.sh): 1 = no step loop (prologue + epilogue), 2 = loads but no
+// MFMAs, 3 = no feature gathers, 4 = no weight loads.  Results are wrong by construction; never defined in the product.
+#ifndef F3_ABLATE
+#define F3_ABLATE 0
+#endif
 
-template <int NTW, int T, bool BF16>
+template <int NTW, int T, bool BF16, int D>
 __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[4][F2_MAXK][R];
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
 #pragma unroll
     for (int jt = 0; jt < NTW; ++jt) acc[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (rem) {
+  if (rem && F3_ABLATE != 1) {
     const int S0 = a.c0 >> 4, S = (a.c0 + a.c1) >> 4;
     const unsigned q16 = (unsigned)q * 16u;
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -294,10 +299,12 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     const float* src_ = sl < S0 ? a.in0 + sl * 16 : a.in1 + (sl - S0) * 16;                                    \
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)a_bytes, 0x00020000); \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                           \
-        AX[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)vo[tt], 0, 0));      \
+        AX[tt] = F3_ABLATE == 3 ? (f32x4){1.f, 2.f, 3.f, (float)vo[tt]}                                         \
+                                : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)vo[tt], 0, 0)); \
     const unsigned wso_ = (unsigned)(kl * S + sl) * w_step + w_jt0;                                            \
     _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                         \
-        BX[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * 1024u), (int)wso_, 0)); \
+        BX[jt] = F3_ABLATE == 4 ? (f32x4){1.f, 2.f, 3.f, (float)wso_}                                           \
+                                : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * 1024u), (int)wso_, 0)); \
   }
     // advance the load side; VALID = false when no step is left (the state then still names a valid step)
 #define F3_ADVANCE(VALID)                                             \
@@ -317,7 +324,10 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     // BF16: the same registers, rounded to bfloat16 (k = 4q + t of lane (i, q) is exactly the operand layout of
     // v_mfma_f32_16x16x16_bf16), so one MFMA replaces the four fp32 ones; fp32 accumulation either way
 #define F3_MFMAS(AX, BX, KC)                                                                              \
-  if constexpr (BF16) {                                                                                   \
+  if constexpr (F3_ABLATE == 2) {                                                                         \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) asm volatile("" ::"v"(AX[tt]));                      \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) asm volatile("" ::"v"(BX[jt]));                    \
+  } else if constexpr (BF16) {                                                                                   \
     s16x4 bh_[NTW];                                                                                       \
     _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) bh_[jt] = pp_bf16x4(BX[jt]);                       \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
@@ -336,23 +346,52 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
       }                                                                                                   \
     }                                                                                                     \
   }
-    F3_LOADS(A0, B0);
-    int kc = kl;
     int more;  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
-    F3_ADVANCE(more);
     // The loads are unconditional: after the last step the load side simply re-reads a valid step.  (A branch around
     // them makes hipcc merge the two paths' outstanding-load counts and wait for the NEW loads before the MFMAs.)
-    for (;;) {
-      F3_LOADS(A1, B1);
-      F3_MFMAS(A0, B0, kc);
-      if (!more) break;
-      kc = kl;
-      F3_ADVANCE(more);
+    if constexpr (D == 1) {
       F3_LOADS(A0, B0);
-      F3_MFMAS(A1, B1, kc);
-      if (!more) break;
-      kc = kl;
+      int kc = kl;
       F3_ADVANCE(more);
+      for (;;) {
+        F3_LOADS(A1, B1);
+        F3_MFMAS(A0, B0, kc);
+        if (!more) break;
+        kc = kl;
+        F3_ADVANCE(more);
+        F3_LOADS(A0, B0);
+        F3_MFMAS(A1, B1, kc);
+        if (!more) break;
+        kc = kl;
+        F3_ADVANCE(more);
+      }
+    } else {
+      // two steps in flight (three register sets): narrow layers have too few MFMAs per step to cover a gather
+      int nsteps = __builtin_popcount(rem) * S;
+      f32x4 A2[T], B2[NTW];
+      F3_LOADS(A0, B0);
+      int k0 = kl, k1, k2;
+      F3_ADVANCE(more);
+      F3_LOADS(A1, B1);
+      k1 = kl;
+      F3_ADVANCE(more);
+      for (;;) {
+        F3_LOADS(A2, B2);
+        k2 = kl;
+        F3_ADVANCE(more);
+        F3_MFMAS(A0, B0, k0);
+        if (--nsteps == 0) break;
+        F3_LOADS(A0, B0);
+        k0 = kl;
+        F3_ADVANCE(more);
+        F3_MFMAS(A1, B1, k1);
+        if (--nsteps == 0) break;
+        F3_LOADS(A1, B1);
+        k1 = kl;
+        F3_ADVANCE(more);
+        F3_MFMAS(A2, B2, k2);
+        if (--nsteps == 0) break;
+      }
     }
 #undef F3_LOADS
 #undef F3_ADVANCE
@@ -387,11 +426,22 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 64 * T), groups);
-  switch (ntw) {
-    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+  static int depth_env = -1;  // PP_DENSE_DEPTH: steps in flight (1 or 2); default 2 for <= PP_DENSE_DEPTH_NTW column tiles
+  static int depth_ntw = 2;
+  if (depth_env < 0) {
+    depth_env = getenv("PP_DENSE_DEPTH") ? atoi(getenv("PP_DENSE_DEPTH")) : 2;
+    if (getenv("PP_DENSE_DEPTH_NTW")) depth_ntw = atoi(getenv("PP_DENSE_DEPTH_NTW"));
+  }
+  const bool deep = depth_env >= 2 && ntw <= depth_ntw;
+  switch (ntw + (deep ? 10 : 0)) {
+    case 11: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 12: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 13: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 14: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
     default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
   }
   return PP_OK;
