@@ -173,10 +173,13 @@ def allgather_varlen(t, group=None):
 
 def exchange_tile_results(local, group=None):
     """local: dict tile_id -> (origin_ids int64 [n], labels int32 [n]) on this rank (tensors on one device).
-    Returns the same dict for ALL tiles on every rank."""
+    Returns the same dict for ALL tiles on every rank.  Two collectives per scene: a small one with the per-tile row
+    counts and ONE all-gather of a padded int32 [rows, 2] buffer (origin id, label: 8 B per point -- scenes have fewer
+    than 2^31 points; 64-bit ids fall back to an int64 buffer)."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dict(local)
+    world = dist.get_world_size(group)
     ids = sorted(local)
     dev = local[ids[0]][0].device if ids else torch.device("cpu")
     if dist.get_backend(group) == "gloo":  # CPU collectives (tests / single-GPU dry runs)
@@ -184,15 +187,32 @@ def exchange_tile_results(local, group=None):
         dev = torch.device("cpu")
     meta = torch.tensor([[t, local[t][0].shape[0]] for t in ids], dtype=torch.int64, device=dev).reshape(-1, 2)
     origin = torch.cat([local[t][0] for t in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
-    labels = torch.cat([local[t][1].to(torch.int64) for t in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
-    payload = torch.stack([origin, labels], 1)  # one buffer -> one collective
-    metas = allgather_varlen(meta, group)
-    payloads = allgather_varlen(payload, group)
+    labels = torch.cat([local[t][1] for t in ids]) if ids else torch.zeros(0, dtype=torch.int32, device=dev)
+    # header: [rows, largest origin id, tiles] of this rank, then the (tile, rows) pairs
+    head = torch.tensor([origin.shape[0], int(origin.max().item()) if origin.numel() else 0, len(ids)],
+                        dtype=torch.int64, device=dev)
+    heads = torch.empty((world, 3), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads.view(-1), head, group=group)
+    heads = heads.tolist()
+    max_rows = max(max(h[0] for h in heads), 1)
+    max_tiles = max(max(h[2] for h in heads), 1)
+    wide = max(h[1] for h in heads) >= 2 ** 31
+    dt = torch.int64 if wide else torch.int32
+    # one buffer per rank: max_tiles (tile, rows) pairs followed by max_rows (origin, label) pairs
+    send = torch.zeros((max_tiles + max_rows, 2), dtype=dt, device=dev)
+    send[: len(ids)] = meta.to(dt)
+    send[max_tiles: max_tiles + origin.shape[0], 0] = origin.to(dt)
+    send[max_tiles: max_tiles + origin.shape[0], 1] = labels.to(dt)
+    recv = torch.empty((world,) + tuple(send.shape), dtype=dt, device=dev)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    metas = recv[:, :max_tiles].tolist()
+    all_origin = recv[:, max_tiles:, 0].long()   # one conversion for the scene, per-tile results are views
+    all_labels = recv[:, max_tiles:, 1].to(torch.int32)
     out = {}
-    for m, p in zip(metas, payloads):
+    for r in range(world):
         pos = 0
-        for t, n in m.tolist():
-            out[t] = (p[pos: pos + n, 0], p[pos: pos + n, 1].to(torch.int32))
+        for t, n in metas[r][: heads[r][2]]:
+            out[int(t)] = (all_origin[r, pos: pos + n], all_labels[r, pos: pos + n])
             pos += n
     return out
 
