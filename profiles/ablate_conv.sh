@@ -3,6 +3,7 @@
 # no step loop / no MFMAs / no feature gathers / no weight loads) into profiles/abl/ and times one layer shape with each.
 #   build here (no GPU needed):  bash profiles/ablate_conv.sh build
 #   on the GPU box:              bash profiles/ablate_conv.sh run <n_tiles> <ts> <cin> <cout>
+# (profiles/abl/ is listed in .gitignore and .gpurunignore: drop it from .gpurunignore to ship the builds to the box)
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/panopticsegforlargescalepointcloud_amd/csrc
