@@ -169,6 +169,12 @@ int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, in
  * weights are rounded to bfloat16 (nearest even) in registers, products accumulate in fp32 on
  * v_mfma_f32_16x16x16_bf16 -- torch.autocast(bfloat16) semantics for the convolution.  Needs cin % 16 == 0 per source,
  * K <= 28 and < 4 GiB per source (PP_ERR_INVALID otherwise; callers keep the fp32 entry for those layers). */
+/* Optional scratch for small launches (fewer waves than SIMD slots): with a buffer registered here pp_spconv_fwd[_bf16]
+ * splits the kernel offsets of such a launch over up to 8 waves per row tile and adds the partial sums in a fixed order
+ * (results stay reproducible; they differ from the unsplit sum only by fp32 summation order).  The buffer belongs to
+ * the caller, must outlive the launches and serves ONE stream at a time; NULL un-registers.  Needs
+ * split * n_out * cout * 4 bytes, otherwise the launch runs unsplit. */
+int pp_spconv_set_scratch(void* scratch, size_t bytes);
 int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                        const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                        const float* scale, const float* shift, int32_t relu, const float* residual,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
+    "pp_spconv_set_scratch": (C.c_int, [vp, sz]),
     "pp_spconv_fwd_bf16": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_rulebook_blocks": (i64, [i64]),
     "pp_rulebook_workspace": (sz, [i64]),

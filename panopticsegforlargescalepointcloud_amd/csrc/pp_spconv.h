@@ -30,6 +30,10 @@ struct SpconvArgs {
   int64_t n_out;
   int c0, c1, K, cout, NT, relu;
   int bf16;  // operands rounded to bfloat16 in registers, fp32 accumulation (v3 kernel only)
+  // split-K (v3 kernel only): blockIdx.z owns the kernel offsets [z*K/split, (z+1)*K/split) and writes raw partial sums
+  // to part[z][row][col]; k_spconv_split_reduce adds them in a fixed order and applies the epilogue
+  int split;
+  float* part;
 };
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
@@ -44,6 +48,7 @@ __device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
 bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in);
 int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
 int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s);
+int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s);
 
 // pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows
 bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr);

@@ -234,6 +234,15 @@ static void launch_fwd(int ntw, dim3 grid, hipStream_t s, const SpconvArgs& a) {
   }
 }
 
+// caller-provided scratch for the split-K path of small launches (pp_spconv_set_scratch)
+static float* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+extern "C" int pp_spconv_set_scratch(void* scratch, size_t bytes) {
+  g_scratch = (float*)scratch;
+  g_scratch_bytes = scratch ? bytes : 0;
+  return PP_OK;
+}
+
 static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                            const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                            const float* scale, const float* shift, int32_t relu, const float* residual,
@@ -248,7 +257,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   SpconvArgs a;
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
   a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
-  a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16;
+  a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   const int max_ntw = mode16 ? 4 : 7;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
@@ -260,8 +269,22 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     dense_ver = e ? atoi(e) : 3;
   }
   if (mode16 && (dense_ver >= 3 || bf16) && K <= 28 && ntw <= 4 && pp_spconv_fwd3_ok(a, n_in)) {
+    // small launches (fewer waves than SIMD slots) are bound by the latency of one wave's walk over the 27 offsets:
+    // split the offsets over up to 8 waves and add the partials in a fixed order (deterministic)
+    static const int split_env = getenv("PP_DENSE_SPLIT") ? atoi(getenv("PP_DENSE_SPLIT")) : -1;
+    const int64_t waves = ((n_out + 31) / 32) * groups;
+    if (K >= 8 && g_scratch && split_env != 1 && waves < 1536) {
+      int sk = 2;
+      while (sk < 8 && waves * sk < 2048) sk *= 2;
+      if (split_env > 1) sk = split_env;
+      if ((size_t)sk * (size_t)n_out * (size_t)cout * sizeof(float) <= g_scratch_bytes) {
+        a.split = sk;
+        a.part = g_scratch;
+      }
+    }
     int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, pp_s(stream));
     if (rc != PP_OK) return rc;
+    if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
   } else if (bf16) {
     pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
     return PP_ERR_INVALID;

@@ -208,16 +208,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef F3_ABLATE
 #define F3_ABLATE 0
 #endif
+// waves per workgroup of k_spconv_fwd3 (waves never synchronise; the workgroup is only the dispatch granule)
+#ifndef F3_WPB
+#define F3_WPB 4
+#endif
 
 template <int NTW, int T, bool BF16, int D>
-__global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
+__global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
-  __shared__ unsigned s_off[4][F2_MAXK][R];
+  __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const unsigned bid = pp_xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t row_base = ((int64_t)bid * 4 + wave) * R;
+  const int64_t row_base = ((int64_t)bid * F3_WPB + wave) * R;
   if (row_base >= a.n_out) return;  // wave-uniform; waves never synchronise
   const int jt0 = blockIdx.y * NTW;
   unsigned(*off)[R] = s_off[wave];
@@ -264,9 +268,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
     }
   }
   unsigned rem = 0;
+  unsigned kmask = 0xFFFFFFFFu;
+  if (a.split > 1) {
+    const int k0 = (int)blockIdx.z * a.K / a.split, k1 = ((int)blockIdx.z + 1) * a.K / a.split;
+    kmask = (k1 >= 32 ? 0xFFFFFFFFu : (1u << k1) - 1u) & ~((1u << k0) - 1u);
+  }
 #pragma unroll
   for (int tt = 0; tt < T; ++tt) {
-    m[tt] = __builtin_amdgcn_readfirstlane(m[tt]);
+    m[tt] = __builtin_amdgcn_readfirstlane(m[tt]) & kmask;
     rem |= m[tt];
   }
 
@@ -398,6 +407,26 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
 #undef F3_MFMAS
   }
 
+  if (a.split > 1) {  // raw partial sums; the epilogue runs in k_spconv_split_reduce
+    float* __restrict__ part = a.part + (int64_t)blockIdx.z * a.n_out * a.cout;
+#pragma unroll
+    for (int jt = 0; jt < NTW; ++jt) {
+      const int col = (jt0 + jt) * 16 + i;
+      if (jt0 + jt < a.NT && col < a.cout) {
+#pragma unroll
+        for (int rt = 0; rt < T; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t slot = row_base + rt * 16 + q * 4 + r;
+            if (slot < a.n_out) {
+              const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
+              part[row * a.cout + col] = acc[rt][jt][r];
+            }
+          }
+      }
+    }
+    return;
+  }
   // epilogue: lane (col = i, row group = q) holds rows 4q+r of each 16-row tile
 #pragma unroll
   for (int jt = 0; jt < NTW; ++jt) {
@@ -425,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a
 
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
-  dim3 grid(pp_blocks(a.n_out, 64 * T), groups);
+  dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
   static int depth_env = -1;  // PP_DENSE_DEPTH: steps in flight (1 or 2); default 2 for <= PP_DENSE_DEPTH_NTW column tiles
   static int depth_ntw = 2;
   if (depth_env < 0) {
@@ -434,16 +463,36 @@ static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_b
   }
   const bool deep = depth_env >= 2 && ntw <= depth_ntw;
   switch (ntw + (deep ? 10 : 0)) {
-    case 11: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 12: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 13: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 14: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 2>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
-    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1>), grid, dim3(256), 0, s, a, a_bytes, w_bytes); break;
+    case 11: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 12: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 13: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 14: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
     default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
   }
+  return PP_OK;
+}
+
+// sum of the split-K partials in a fixed order + the epilogue of the convolution (deterministic, one pass)
+__global__ __launch_bounds__(256) void k_spconv_split_reduce(SpconvArgs a) {
+  const int64_t total = a.n_out * a.cout;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int col = (int)(e % a.cout);
+  float v = a.part[e];
+  for (int z = 1; z < a.split; ++z) v += a.part[(int64_t)z * total + e];
+  v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
+  if (a.relu) v = fmaxf(v, 0.f);
+  if (a.residual) v += a.residual[e];
+  a.out[e] = v;
+}
+
+int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_spconv_split_reduce, dim3(pp_blocks(a.n_out * a.cout, 256)), dim3(256), 0, s, a);
+  PP_LAUNCH_CHECK();
   return PP_OK;
 }
 

@@ -4,6 +4,7 @@ PyTorch is plumbing here (allocation, streams); every op below is one or a few l
 gfx950 kernels in csrc/.  All tensors must live on a HIP device; there is no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -317,6 +318,19 @@ def pack_weight(weight, transpose=False):
     return packed
 
 
+_CONV_SCRATCH = {"device": None, "buf": None}
+CONV_SCRATCH_BYTES = int(os.environ.get("PP_CONV_SCRATCH_MB", "64")) << 20
+
+
+def _conv_scratch(lib, device):
+    """registers the split-K scratch of small convolution launches (pp_spconv_set_scratch) once per device; the buffer
+    is owned here and serves the stream the convolutions are launched on"""
+    if _CONV_SCRATCH["device"] != device:
+        buf = torch.empty(CONV_SCRATCH_BYTES, dtype=torch.uint8, device=device) if CONV_SCRATCH_BYTES > 0 else None
+        _lib.check(lib.pp_spconv_set_scratch(_ptr(buf), CONV_SCRATCH_BYTES if buf is not None else 0), "pp_spconv_set_scratch")
+        _CONV_SCRATCH["device"], _CONV_SCRATCH["buf"] = device, buf
+
+
 def bf16_conv_supported(c0, c1, K, nbr_given=True):
     """layers the bfloat16 entries take (the 4-channel input layer and 1x1 shortcuts without a map stay fp32)"""
     return c0 % 16 == 0 and c1 % 16 == 0 and (c1 == 0 or c1 == c0) and K <= 28
@@ -342,6 +356,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     fn = lib.pp_spconv_fwd_bf16 if (bf16 and bf16_conv_supported(c0, c1, K)) else lib.pp_spconv_fwd
+    _conv_scratch(lib, in0.device)
     _lib.check(fn(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
                   _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out), _stream()), "pp_spconv_fwd")
     if prof is not None:

@@ -157,6 +157,37 @@ def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,n", [(96, 96, 900), (112, 112, 300), (64, 80, 4000), (16, 16, 40), (160, 64, 2500)])
+def test_spconv_split_k_small_launches(ops, oracle, cin, cout, n):
+    """small launches take the split-K path (offsets spread over several waves, partials added in a fixed order by
+    k_spconv_split_reduce with the fused epilogue): same result as the oracle, bit-identical run to run, and the
+    registered scratch being too small falls back to the unsplit kernel."""
+    rng = np.random.default_rng(90 + cin + n)
+    coords = surface(rng, n=n, n_batch=2, extent=24)
+    n = len(coords)
+    nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(n, cout)).astype(np.float32)
+    want = oracle.spconv_fwd(x, W, nbr, n, scale=sc, shift=sh, relu=True, residual=res)
+    run = lambda: ops.spconv_fwd(dev(x), ops.pack_weight(dev(W)), dev(nbr), n, cout, 27, scale=dev(sc), shift=dev(sh),
+                                 relu=True, residual=dev(res))
+    got = run()
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert torch.equal(got, run())
+    lib = ops._lib.load()
+    try:
+        assert lib.pp_spconv_set_scratch(None, 0) == 0
+        unsplit = run()
+    finally:
+        ops._CONV_SCRATCH["device"] = None  # re-register on the next call
+    np.testing.assert_allclose(unsplit.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    if cin * 27 > 500:
+        assert not torch.equal(unsplit, got)  # a different summation order: the split path really ran
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 48), (64, 64), (96, 112), (48, 16)])
 def test_spconv_bf16_entries_match_oracle_on_rounded_operands(ops, oracle, cin, cout):
     """pp_spconv_fwd_bf16 / pp_spconv_bwd_weight_bf16: operands rounded to bfloat16, fp32 accumulation.  Products of
