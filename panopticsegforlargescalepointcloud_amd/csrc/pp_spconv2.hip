@@ -374,6 +374,29 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         kc = kl;
         F3_ADVANCE(more);
       }
+    } else if constexpr (D == 3) {
+      // as D == 1, but the load side advances (LDS read of the next offsets) BEFORE the MFMAs of the current step, so
+      // that read is covered by them instead of sitting between two steps
+      int k0, k1, e0, e1, nx;
+      F3_LOADS(A0, B0);
+      k0 = kl;
+      F3_ADVANCE(nx);
+      for (;;) {
+        F3_LOADS(A1, B1);
+        k1 = kl;
+        e1 = nx;
+        F3_ADVANCE(more);
+        nx = e1 ? more : 0;
+        F3_MFMAS(A0, B0, k0);
+        if (!e1) break;
+        F3_LOADS(A0, B0);
+        k0 = kl;
+        e0 = nx;
+        F3_ADVANCE(more);
+        nx = e0 ? more : 0;
+        F3_MFMAS(A1, B1, k1);
+        if (!e0) break;
+      }
     } else {
       // two steps in flight (three register sets): narrow layers have too few MFMAs per step to cover a gather
       int nsteps = __builtin_popcount(rem) * S;
@@ -455,14 +478,21 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
-  static int depth_env = -1;  // PP_DENSE_DEPTH: steps in flight (1 or 2); default 2 for <= PP_DENSE_DEPTH_NTW column tiles
+  // PP_DENSE_DEPTH: loop variant for launches with <= PP_DENSE_DEPTH_NTW (default 2) column tiles per wave:
+  // 1 = one step in flight, 2 = two steps in flight, 3 (default) = one step in flight with the load side advanced
+  // before the MFMAs (16->16 at 2.5 M rows: 374 / 375 / 343 us); wider launches always use 1
   static int depth_ntw = 2;
   if (depth_env < 0) {
-    depth_env = getenv("PP_DENSE_DEPTH") ? atoi(getenv("PP_DENSE_DEPTH")) : 2;
+    depth_env = getenv("PP_DENSE_DEPTH") ? atoi(getenv("PP_DENSE_DEPTH")) : 3;
     if (getenv("PP_DENSE_DEPTH_NTW")) depth_ntw = atoi(getenv("PP_DENSE_DEPTH_NTW"));
   }
-  const bool deep = depth_env >= 2 && ntw <= depth_ntw;
-  switch (ntw + (deep ? 10 : 0)) {
+  const bool deep = depth_env == 2 && ntw <= depth_ntw;
+  const bool early = depth_env == 3 && ntw <= depth_ntw;
+  switch (ntw + (deep ? 10 : 0) + (early ? 20 : 0)) {
+    case 21: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 22: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 23: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+    case 24: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
     case 11: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
     case 12: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
     case 13: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
