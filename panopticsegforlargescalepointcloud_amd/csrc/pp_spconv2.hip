@@ -481,6 +481,7 @@ static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_b
   // PP_DENSE_DEPTH: loop variant for launches with <= PP_DENSE_DEPTH_NTW (default 2) column tiles per wave:
   // 1 = one step in flight, 2 = two steps in flight, 3 (default) = one step in flight with the load side advanced
   // before the MFMAs (16->16 at 2.5 M rows: 374 / 375 / 343 us); wider launches always use 1
+  static int depth_env = -1;
   static int depth_ntw = 2;
   if (depth_env < 0) {
     depth_env = getenv("PP_DENSE_DEPTH") ? atoi(getenv("PP_DENSE_DEPTH")) : 3;
