@@ -359,6 +359,16 @@ int pp_proposal_intersections(const int32_t* prop_offsets, const int64_t* prop_p
                               pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row gather                      replaces: features[perm] / features[inverse] around ME.SparseTensor (.F in caller order,
+ *                                 applications/minkowski.py:193) and backbone_features[cluster] in _compute_score,
+ *                                 PointGroup3heads.py:400-410
+ * out[i] = src[index[i]] for float32 rows of c (multiple of 4) channels; index int64 in [0, n_src).  Out-of-range
+ * indices are counted in *err_flag (device int32, zeroed by the caller) and their rows left untouched.
+ * ---------------------------------------------------------------------------------------------- */
+int pp_gather_rows(const float* src, int64_t n_src, int32_t c, const int64_t* index, int64_t n, float* out,
+                   int32_t* err_flag, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * f2  exact 1-nearest neighbour     replaces: torch_geometric knn(x=ref, y=query, k=1) / knn_interpolate(k=1) of the
  *                                  full-resolution back-projection, metrics/panoptic_tracker_pointgroup_npm3d.py:564-566,
  *                                  593-618; KD-tree query of the cylinder centre label, data_transform/transforms.py:239-240

@@ -99,11 +99,11 @@ class _PermuteRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, perm, inv):
         ctx.inv = inv
-        return x[perm]
+        return ops.gather_rows(x, perm)
 
     @staticmethod
     def backward(ctx, dy):
-        return dy[ctx.inv], None, None
+        return ops.gather_rows(dy.contiguous(), ctx.inv), None, None
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -112,7 +112,7 @@ class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, index):
         ctx.index, ctx.n = index, x.shape[0]
-        return x[index]
+        return ops.gather_rows(x, index)
 
     @staticmethod
     def backward(ctx, dy):
@@ -120,7 +120,7 @@ class _GatherRowsFn(torch.autograd.Function):
 
 
 def _permute_rows(x, perm, inv):
-    return _PermuteRowsFn.apply(x, perm, inv) if x.requires_grad else x[perm]
+    return _PermuteRowsFn.apply(x, perm, inv) if x.requires_grad else ops.gather_rows(x, perm)
 
 
 class CoordinateManager:
@@ -261,7 +261,7 @@ class GatheredRows:
 
     def materialise(self, perm=None):
         index = self.index if perm is None else self.index[perm]
-        return _GatherRowsFn.apply(self.base, index) if self.base.requires_grad else self.base[index]
+        return _GatherRowsFn.apply(self.base, index) if self.base.requires_grad else ops.gather_rows(self.base, index)
 
 
 class SparseTensor:

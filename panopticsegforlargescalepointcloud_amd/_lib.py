@@ -78,6 +78,7 @@ SIGNATURES = {
     "pp_instance_iou": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
     "pp_proposal_intersections_workspace": (sz, [i64, i64]),
     "pp_proposal_intersections": (C.c_int, [vp, vp, i32, i64, vp, vp, sz, vp]),
+    "pp_gather_rows": (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp]),
     "pp_nearest_workspace": (sz, [i64]),
     "pp_nearest": (C.c_int, [vp, i64, vp, i64, i32, f32, f32, vp, vp, vp, sz, vp]),
 }

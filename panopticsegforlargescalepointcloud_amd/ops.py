@@ -700,6 +700,37 @@ def cylinder_tiles(pos, centres_xy, radius):
     return ClusterCSR(offs, out[:total], nc)
 
 
+_GATHER_ERR = {}
+
+
+def gather_rows(src, index):
+    """src[index] for [n,c] float32 rows with c % 4 == 0 and an int64 index (other layouts: torch indexing).  Indices
+    are trusted the way torch trusts them on the device: an out-of-range index is counted in a device flag that
+    `gather_rows_check()` turns into an exception (no synchronisation on the hot path)."""
+    if (src.dtype != torch.float32 or src.dim() != 2 or src.shape[1] % 4 or index.dtype != torch.int64
+            or index.dim() != 1 or not src.is_contiguous()):
+        return src[index]
+    lib = _lib.load()
+    index = _need(index, torch.int64, "index")
+    dev = src.device
+    flag = _GATHER_ERR.get(dev)
+    if flag is None:
+        flag = _GATHER_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty((index.shape[0], src.shape[1]), dtype=torch.float32, device=dev)
+    _lib.check(lib.pp_gather_rows(_ptr(src), src.shape[0], src.shape[1], _ptr(index), index.shape[0], _ptr(out),
+                                  _ptr(flag), _stream()), "pp_gather_rows")
+    return out
+
+
+def gather_rows_check():
+    """raises if any gather_rows call since the last check saw an out-of-range index (one synchronisation)"""
+    for dev, flag in _GATHER_ERR.items():
+        bad = int(flag.item())
+        if bad:
+            flag.zero_()
+            raise _lib.PanopticHipError("gather_rows: %d indices out of range" % bad)
+
+
 def nearest(ref, query, cell, max_dist=0.0):
     """Exact 1-NN of every query row among the reference rows ([n,2] or [n,3] float32): (idx int64, dist2 float32).
     idx -1 / dist2 inf where no reference point lies within max_dist (> 0); ties -> smallest reference index."""

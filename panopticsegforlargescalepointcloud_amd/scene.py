@@ -258,6 +258,7 @@ class TileRunner:
                                          t0=t0)
         t0 = self._tick("(group+score total marker)", time.perf_counter()) if False else (time.perf_counter() if self.stage_timing else 0.0)
         labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)
+        ops.gather_rows_check()  # row gathers trust their indices on the device; one flag read per batch
         self._tick("nms+paint", t0)
         return labels, res, counts
 

@@ -529,6 +529,24 @@ def test_segment_reduce_run_structured_index(ops):
             np.testing.assert_allclose(got.cpu().numpy(), want / cnt, rtol=1e-5, atol=1e-4)
 
 
+def test_gather_rows_matches_indexing(ops):
+    rng = np.random.default_rng(21)
+    for n_src, n, c in [(1000, 5000, 4), (70_000, 200_000, 16), (3000, 10, 112), (5, 0, 8), (4000, 4000, 64)]:
+        src = dev(rng.normal(size=(n_src, c)).astype(np.float32))
+        idx = dev(rng.integers(0, n_src, size=n))
+        assert torch.equal(ops.gather_rows(src, idx), src[idx])
+    # layouts the kernel does not take fall back to torch indexing (same result)
+    src = dev(rng.normal(size=(100, 6)).astype(np.float32))
+    idx = dev(rng.integers(0, 100, size=50))
+    assert torch.equal(ops.gather_rows(src, idx), src[idx])
+    ops.gather_rows_check()
+    src = dev(rng.normal(size=(100, 8)).astype(np.float32))
+    ops.gather_rows(src, dev(np.array([1, 100, -1, 5])))
+    with pytest.raises(Exception):
+        ops.gather_rows_check()
+    ops.gather_rows_check()  # the flag is cleared by the failed check
+
+
 def test_instance_iou_and_intersections_match_goldens(ops, oracle):
     z = np.load(os.path.join(GOLD, "loss_cases.npz"))
     offs = z["cluster_offsets"]
