@@ -153,7 +153,9 @@ int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t bloc
  * out[o] = epilogue( sum_k  [in0 | in1][nbr[k][o]] . W_k )
  * epilogue(v) = relu?( v * scale + shift ) + residual      (scale/shift/residual may be NULL)
  * nbr == NULL with K == 1: identity map (1x1 convolution, n_out rows in == rows out).
- * transpose_w: 0 -> packed[k] = W_k (Cin x Cout);  1 -> packed[k] = W_k^T (used for input gradients).
+ * transpose_w: bit 0 -> packed[k] = W_k^T (input gradients) instead of W_k (Cin x Cout); bit 1 -> offsets reversed,
+ * packed[k] = W_{K-1-k}: on a same-level map nbr_mirrored[k] == nbr[K-1-k], so transposed stride-1 convolutions and
+ * the input gradients of stride-1 convolutions reuse the forward map instead of a flipped copy of it.
  * n_in bounds the gathers: the fast kernel reads rows through a buffer descriptor of n_in * c0 * 4 bytes (missing
  * neighbours come back as hardware-checked zeros); inputs of 4 GiB or more per source take the slower kernel.
  * ---------------------------------------------------------------------------------------------- */

@@ -333,14 +333,17 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------------------
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, order_out=None, order_in=None):
+    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, order_out=None, order_in=None, same_level=False, kflip=False):
+        """same_level: nbr is the (+1) map of a stride-1 3x3x3 layer; its mirrored twin is nbr[K-1-k], so the transposed
+        layer (kflip) and every input gradient reuse nbr with the offsets of the packed weights reversed."""
         feats = feats.contiguous()
-        packed = ops.pack_weight(kernel)
+        packed = ops.pack_weight(kernel, kflip=kflip)
         cout = kernel.shape[-1]
         bf16 = _CONV_BF16[0]
         out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=order_out, bf16=bf16)
         ctx.save_for_backward(feats, kernel)
         ctx.nbr, ctx.inv_fn, ctx.K, ctx.order_in, ctx.bf16 = nbr, inv_fn, K, order_in, bf16
+        ctx.same_level, ctx.kflip = same_level, kflip
         return out
 
     @staticmethod
@@ -349,12 +352,20 @@ class _SparseConvFn(torch.autograd.Function):
         dout = dout.contiguous()
         din = dw = None
         if ctx.needs_input_grad[0]:
-            packed_t = ops.pack_weight(kernel, transpose=True)
-            din = ops.spconv_fwd(dout, packed_t, ctx.inv_fn(), feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in,
+            if ctx.same_level:
+                packed_t = ops.pack_weight(kernel, transpose=True, kflip=not ctx.kflip)
+                inv = ctx.nbr
+            else:
+                packed_t = ops.pack_weight(kernel, transpose=True)
+                inv = ctx.inv_fn()
+            din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in,
                                  bf16=ctx.bf16)
         if ctx.needs_input_grad[1]:
-            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K, bf16=ctx.bf16).reshape(kernel.shape)
-        return din, dw, None, None, None, None, None, None
+            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K, bf16=ctx.bf16)
+            if ctx.kflip:
+                dw = dw.flip(0)
+            dw = dw.reshape(kernel.shape)
+        return din, dw, None, None, None, None, None, None, None, None
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
@@ -443,11 +454,17 @@ class _ConvBase(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-stdv, stdv)
 
+    @property
+    def mirrored(self):
+        """transposed 3x3x3 convolution with stride 1: same-level map with mirrored offsets = the forward map with the
+        offsets of the weights reversed (no flipped copy of the map)"""
+        return self.TRANSPOSED and self.stride == 1 and self.kernel_volume > 1
+
     def packed(self):
         k = self.kernel
         tag = (k._version, k.data_ptr(), k.device)
         if self._packed is None or self._packed[0] != tag:
-            self._packed = (tag, ops.pack_weight(k))
+            self._packed = (tag, ops.pack_weight(k, kflip=self.mirrored))
         return self._packed[1]
 
     def out_stride_and_map(self, x):
@@ -464,6 +481,8 @@ class _ConvBase(nn.Module):
         else:
             ts_out = cm.ensure_stride(ts_in, self.stride)
         ks = self.kernel_size
+        if self.mirrored:
+            sign = 1  # with packed(kflip) / _SparseConvFn(kflip=True)
         nbr = cm.kernel_map(ts_in, ts_out, ks, sign)
         return ts_out, nbr, (lambda: cm.kernel_map(ts_out, ts_in, ks, -sign))
 
@@ -471,8 +490,9 @@ class _ConvBase(nn.Module):
         ts_out, nbr, inv_fn = self.out_stride_and_map(x)
         cm = x.coordinate_manager
         n_out = cm.level(ts_out).n
+        same_level = self.stride == 1 and self.kernel_volume > 1
         feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume, cm.tile_order(ts_out),
-                                    cm.tile_order(x.tensor_stride))
+                                    cm.tile_order(x.tensor_stride), same_level, self.mirrored)
         if self.bias is not None:
             feats = feats + self.bias
         return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=ts_out)
@@ -625,8 +645,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
     c0 = x.feats.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
     if (nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0
-            and _want_rulebook(conv, x, ts_out, c0 + c1, -1 if conv.TRANSPOSED else 1)):
-        sign = -1 if conv.TRANSPOSED else 1
+            and _want_rulebook(conv, x, ts_out, c0 + c1, -1 if (conv.TRANSPOSED and not conv.mirrored) else 1)):
+        sign = -1 if (conv.TRANSPOSED and not conv.mirrored) else 1  # mirrored layers: forward map + reversed weights
         rb = cm.rulebook(x.tensor_stride, ts_out, conv.kernel_size, sign)
         feats = ops.spconv_fwd_rb(x.feats, conv.packed(), rb, conv.out_channels, in1=in1, scale=scale, shift=shift,
                                   relu=relu, residual=res)

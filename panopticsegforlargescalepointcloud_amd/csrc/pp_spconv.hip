@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
   }
   float v = 0.f;
   if (ci < cin && co < cout) {
-    // source layout: not transposed [K][cin][cout]; transposed: the ME tensor is [K][cout][cin]
-    v = transpose_w ? w[((int64_t)k * cout + co) * cin + ci] : w[((int64_t)k * cin + ci) * cout + co];
+    // source layout: not transposed [K][cin][cout]; transposed (bit 0): the ME tensor is [K][cout][cin];
+    // bit 1: offsets in reverse order (packed[k] = W_{K-1-k}: the mirrored map of a same-level convolution)
+    const int64_t ks = (transpose_w & 2) ? K - 1 - k : k;
+    v = (transpose_w & 1) ? w[(ks * cout + co) * cin + ci] : w[(ks * cin + ci) * cout + co];
   }
   packed[e] = v;
 }

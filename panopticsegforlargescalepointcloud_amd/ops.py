@@ -304,8 +304,9 @@ def morton_order(coords, unit=1, block_bits=0, want_sorted=False):
 
 
 # ------------------------------------------------------------------------------------------ convolution
-def pack_weight(weight, transpose=False):
-    """ME-layout kernel [K,Cin,Cout] (or [Cin,Cout]) -> MFMA fragment order.  transpose=True packs W_k^T."""
+def pack_weight(weight, transpose=False, kflip=False):
+    """ME-layout kernel [K,Cin,Cout] (or [Cin,Cout]) -> MFMA fragment order.  transpose=True packs W_k^T; kflip=True
+    packs the offsets in reverse order (mirrored same-level map without flipping the map)."""
     lib = _lib.load()
     w = _need(weight.detach(), torch.float32, "weight")
     if w.dim() == 2:
@@ -314,7 +315,8 @@ def pack_weight(weight, transpose=False):
     if transpose:
         cin, cout = cout, cin
     packed = torch.empty(lib.pp_packed_weight_floats(K, cin, cout), dtype=torch.float32, device=w.device)
-    _lib.check(lib.pp_pack_weight(_ptr(w), K, cin, cout, int(transpose), _ptr(packed), _stream()), "pp_pack_weight")
+    _lib.check(lib.pp_pack_weight(_ptr(w), K, cin, cout, int(bool(transpose)) | (2 if kflip else 0), _ptr(packed),
+                                  _stream()), "pp_pack_weight")
     return packed
 
 
