@@ -632,6 +632,50 @@ __global__ __launch_bounds__(256) void k_seg_accum_lds(const float* __restrict__
     if (shc[t]) atomicAdd(&cnt[t], shc[t]);
 }
 
+// many segments: a thread owns one column of SEG_RUN consecutive rows and keeps a running value while the segment id
+// does not change, so (nearly) sorted ids -- per-proposal maxima of the scorer, whose rows are ordered by proposal --
+// cost one atomic per run instead of one per element.  Unsorted ids stay correct, just with shorter runs.
+#define SEG_RUN 16
+__global__ __launch_bounds__(256) void k_seg_accum_runs(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                                        int64_t n, int c, int64_t n_seg, int reduce, float* out,
+                                                        int* out_ord, int32_t* cnt, int32_t* err) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t chunk = e / c;
+  const int j = (int)(e - chunk * c);
+  const int64_t r0 = chunk * SEG_RUN;
+  if (r0 >= n) return;
+  const int64_t r1 = r0 + SEG_RUN < n ? r0 + SEG_RUN : n;
+  int64_t cur = -1;
+  float acc = 0.f;
+  int run = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const int64_t sg = index[r];
+    if (sg != cur) {
+      if (run) {
+        if (reduce == 2) atomicMax(&out_ord[cur * c + j], f2ord(acc)); else atomicAdd(&out[cur * c + j], acc);
+        if (j == 0) atomicAdd(&cnt[cur], run);
+      }
+      run = 0;
+      cur = sg;
+      if (sg < 0 || sg >= n_seg) {
+        cur = -1;
+        if (j == 0) atomicAdd(err, 1);
+        continue;
+      }
+    } else if (cur < 0) {
+      if (j == 0) atomicAdd(err, 1);
+      continue;
+    }
+    const float v = src[r * c + j];
+    acc = run == 0 ? v : (reduce == 2 ? fmaxf(acc, v) : acc + v);
+    ++run;
+  }
+  if (run) {
+    if (reduce == 2) atomicMax(&out_ord[cur * c + j], f2ord(acc)); else atomicAdd(&out[cur * c + j], acc);
+    if (j == 0) atomicAdd(&cnt[cur], run);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_seg_finish(float* out, int* out_ord, const int32_t* __restrict__ cnt,
                                                     int64_t total, int c, int reduce) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -678,6 +722,10 @@ extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t
     hipLaunchKernelGGL(k_seg_accum_lds, dim3(pp_blocks(n * c, 256 * SEG_LDS_ELEMS_PER_THREAD)), dim3(256),
                        sizeof(int) * (size_t)(n_seg * (c + 1)), s, src, index, n * c, c, (int)n_seg, reduce, out,
                        (int*)out, cnt, cnt + n_seg);
+  } else if (n > 0 && c >= 4) {
+    const int64_t threads = ((n + SEG_RUN - 1) / SEG_RUN) * c;
+    hipLaunchKernelGGL(k_seg_accum_runs, dim3(pp_blocks(threads, 256)), dim3(256), 0, s, src, index, n, c, n_seg, reduce,
+                       out, (int*)out, cnt, cnt + n_seg);
   } else if (n > 0) {
     hipLaunchKernelGGL(k_seg_count, dim3(pp_blocks(n, 256)), dim3(256), 0, s, index, n, n_seg, cnt, cnt + n_seg);
     hipLaunchKernelGGL(k_seg_accum, dim3(pp_blocks(n * c, 256)), dim3(256), 0, s, src, index, n * c, c, n_seg, reduce,

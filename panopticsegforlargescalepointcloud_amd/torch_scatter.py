@@ -10,7 +10,9 @@ class _ScatterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, index, n_seg, reduce):
         src2 = src.reshape(src.shape[0], -1).contiguous()
-        if reduce == "max":
+        if reduce == "max" and not ctx.needs_input_grad[0]:
+            out = ops.segment_reduce(src2, index, n_seg, "max")  # inference: no arg-max pass
+        elif reduce == "max":
             out, arg = ops.segment_reduce(src2, index, n_seg, "max", want_arg=True)
             ctx.save_for_backward(arg)
         else:

@@ -488,7 +488,8 @@ def test_group_by_key_and_segment_reduce(ops, oracle):
             assert np.array_equal(arg.cpu().numpy(), warg)
 
 
-@pytest.mark.parametrize("n,c,n_seg", [(200_000, 5, 40), (30_000, 16, 3000), (5000, 1, 7), (70_000, 1, 12000)])
+@pytest.mark.parametrize("n,c,n_seg", [(200_000, 5, 40), (30_000, 16, 3000), (5000, 1, 7), (70_000, 1, 12000),
+                                       (100_003, 16, 5000), (9001, 4, 2000)])
 def test_segment_reduce_few_and_many_segments(ops, oracle, n, c, n_seg):
     """both accumulation paths (block-private LDS for few segments, global atomics otherwise), empty segments and the
     arg-max convention; sums differ from the oracle only by float32 summation order."""
@@ -496,12 +497,15 @@ def test_segment_reduce_few_and_many_segments(ops, oracle, n, c, n_seg):
     src = rng.normal(size=(n, c)).astype(np.float32)
     index = rng.integers(0, n_seg, size=n)
     index[index == 3] = 4
-    for red in ["sum", "mean", "max"]:
-        want, warg = oracle.segment_reduce(src, index, n_seg, red)
-        got, arg = ops.segment_reduce(dev(src), dev(index), n_seg, red, want_arg=True)
-        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-3 if red == "sum" else 2e-4)
-        if red == "max":
-            assert np.array_equal(arg.cpu().numpy(), warg)
+    for order in ("random", "sorted"):  # sorted ids: the run-merging kernel takes one atomic per run
+        if order == "sorted":
+            index = np.sort(index)
+        for red in ["sum", "mean", "max"]:
+            want, warg = oracle.segment_reduce(src, index, n_seg, red)
+            got, arg = ops.segment_reduce(dev(src), dev(index), n_seg, red, want_arg=True)
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-3 if red == "sum" else 2e-4)
+            if red == "max":
+                assert np.array_equal(arg.cpu().numpy(), warg)
     with pytest.raises(Exception):
         index[17] = n_seg
         ops.segment_reduce(dev(src), dev(index), n_seg, "sum")
