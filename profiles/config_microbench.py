@@ -1,0 +1,69 @@
+"""End-to-end throughput on the other single-GPU configurations of BASELINE.json (the bench metric is configs[3]):
+  C2  NPM3D-like full scene, ~2 M points, 5 cm voxels        (bench.py --points 2000000 --grid 4)
+  C3  FOR-instance-like forest tile set, ~1 M points, 10 cm voxels, r = 8 m cylinders, two classes, offset + embedding
+      dual clustering (cluster_type of the published setting), same timed region as bench.py.
+usage (GPU box): python profiles/config_microbench.py"""
+import copy
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from panopticsegforlargescalepointcloud_amd import panoptic, synthetic as syn  # noqa: E402
+from panopticsegforlargescalepointcloud_amd.scene import TileRunner  # noqa: E402
+
+
+def c2():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--points", "2000000", "--grid", "4", "--steps", "5",
+                          "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    d = json.loads(out)
+    print("C2  %s: %.1f ms/step, %.1f M points/s" % (d["config"]["workload"][:90], d["ms_per_step"], d["value"] / 1e6))
+
+
+def c3(n_points=1_000_000, voxel=0.10, grid=10, steps=5):
+    dev = torch.device("cuda", 0)
+
+    class DS:
+        feature_dimension = 4
+        num_classes = syn.FOR_NUM_CLASSES
+        stuff_classes = torch.tensor(syn.FOR_STUFF)
+    _, cfg, _ = bench.build_model(dev, voxel)
+    cfg = copy.deepcopy(cfg)
+    torch.manual_seed(11)
+    model = panoptic.PointGroup3heads(cfg, "dummy", DS, None)
+    with torch.no_grad():
+        model.ScorerHead[0].bias.fill_(1.0)
+    model = model.to(dev).eval()
+    scene = syn.forest_scene(n_points, voxel, 2022)
+    tiles, radius = syn.cylinder_tiles(scene, grid)
+    ids = list(range(len(tiles)))
+    b = syn.tile_batch(scene, tiles, ids)
+    ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(6), offset_sigma=0.1)
+    dev_b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    override = tuple(torch.from_numpy(a).to(dev) for a in ov)
+    runner = TileRunner(model, dev)
+    for _ in range(2):
+        labels, res, counts = runner.run(dev_b, len(ids), override=override)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        labels, res, counts = runner.run(dev_b, len(ids), override=override)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = len(b["pos"])
+    print("C3  forest: %d cylinders (r = %.1f m), %d voxels fed (%d scene voxels, %d trees), cluster_type %s: %.1f ms/step, "
+          "%.1f M points/s, %d proposals -> %d instances" % (len(ids), radius, n, len(scene.pos), scene.n_inst, cfg.cluster_type,
+                                                               1e3 * dt, n / dt / 1e6, res.clusters_csr.n, sum(counts)))
+
+
+if __name__ == "__main__":
+    if "--c3-only" not in sys.argv:
+        c2()
+    c3()
