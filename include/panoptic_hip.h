@@ -337,6 +337,12 @@ size_t pp_segment_reduce_workspace(int64_t n_seg);
 int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
                       int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
                       pp_stream_t stream);
+/* Same, for index values the caller has validated already (e.g. the inverse ids of a unique(), or an index a checked
+ * call has just accepted -- the backward of a gather): rows with an out-of-range id are skipped silently and the call
+ * does not synchronise the stream. */
+int pp_segment_reduce_unchecked(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
+                                int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
+                                pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K10 instance IoU                replaces: torch_points_kernels.instance_iou,

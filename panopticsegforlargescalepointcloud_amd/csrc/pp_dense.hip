@@ -700,9 +700,9 @@ __global__ __launch_bounds__(256) void k_seg_argmax(const float* __restrict__ sr
 
 extern "C" size_t pp_segment_reduce_workspace(int64_t n_seg) { return pp_align(sizeof(int32_t) * (size_t)(n_seg + 2)); }
 
-extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
-                                 int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
-                                 pp_stream_t stream) {
+static int segment_reduce_impl(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
+                               int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
+                               bool check, pp_stream_t stream) {
   PP_REQUIRE(out && (n == 0 || (src && index)), "pp_segment_reduce: null pointer");
   PP_REQUIRE(reduce >= 0 && reduce <= 2, "pp_segment_reduce: reduce must be 0 (sum), 1 (mean) or 2 (max)");
   hipStream_t s = pp_s(stream);
@@ -740,6 +740,7 @@ extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t
                          (unsigned long long*)arg);
   }
   PP_LAUNCH_CHECK();
+  if (!check) return PP_OK;
   int32_t bad = 0;
   PP_HIP(hipMemcpyAsync(&bad, cnt + n_seg, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   PP_HIP(hipStreamSynchronize(s));
@@ -748,4 +749,15 @@ extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t
     return PP_ERR_INVALID;
   }
   return PP_OK;
+}
+
+extern "C" int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
+                                 int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
+                                 pp_stream_t stream) {
+  return segment_reduce_impl(src, index, n, c, n_seg, reduce, out, arg, workspace, workspace_bytes, true, stream);
+}
+extern "C" int pp_segment_reduce_unchecked(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
+                                           int32_t reduce, float* out, int64_t* arg, void* workspace,
+                                           size_t workspace_bytes, pp_stream_t stream) {
+  return segment_reduce_impl(src, index, n, c, n_seg, reduce, out, arg, workspace, workspace_bytes, false, stream);
 }

@@ -768,7 +768,8 @@ def group_by_key(key, n_groups, ids=None):
     return offs, out, total
 
 
-def segment_reduce(src, index, n_seg, reduce, want_arg=False):
+def segment_reduce(src, index, n_seg, reduce, want_arg=False, check=True):
+    """check=False: the ids are known to be in range (no validation, no stream synchronisation)"""
     lib = _lib.load()
     src = _need(src, torch.float32, "src")
     index = _need(index, torch.int64, "index")
@@ -778,8 +779,9 @@ def segment_reduce(src, index, n_seg, reduce, want_arg=False):
     arg = torch.empty((n_seg, c), dtype=torch.int64, device=dev) if want_arg else None
     wsb = lib.pp_segment_reduce_workspace(n_seg)
     ws = _ws(wsb, dev)
-    _lib.check(lib.pp_segment_reduce(_ptr(src), _ptr(index), n, c, int(n_seg), _REDUCE[reduce], _ptr(out), _ptr(arg),
-                                     _ptr(ws), wsb, _stream()), "pp_segment_reduce")
+    fn = lib.pp_segment_reduce if check else lib.pp_segment_reduce_unchecked
+    _lib.check(fn(_ptr(src), _ptr(index), n, c, int(n_seg), _REDUCE[reduce], _ptr(out), _ptr(arg), _ptr(ws), wsb, _stream()),
+               "pp_segment_reduce")
     return (out, arg) if want_arg else out
 
 

@@ -6,7 +6,7 @@ implementation by tests/golden/loss_cases.npz."""
 import torch
 
 from ..torch_points_kernels import instance_iou, instance_iou_csr
-from ..torch_scatter import scatter
+from ..torch_scatter import gather, scatter
 
 
 def offset_loss(pred_offsets, gt_offsets, total_instance_points):
@@ -53,7 +53,7 @@ def discriminative_loss_single(prediction, correct_label, feature_dim, delta_v=0
     if k == 0:
         return zero, zero, zero, zero
     mu = scatter(pred, unique_id, dim=0, reduce="sum") / (counts.reshape(-1, 1) + 1e-8)
-    distance = torch.norm(pred - mu[unique_id], p=1, dim=1)
+    distance = torch.norm(pred - gather(mu, unique_id), p=1, dim=1)
     distance = torch.square(torch.clip(distance - delta_v, min=0.0))
     l_var = scatter(distance, unique_id, dim=0, reduce="sum") / (counts + 1e-8)
     l_var = torch.sum(l_var) / float(k)
@@ -73,7 +73,7 @@ def discriminative_loss(embedding_logits, instance_labels, batch, feature_dim):
     parts = []
     for s in torch.unique(batch):
         m = batch == s
-        parts.append(discriminative_loss_single(embedding_logits[m], instance_labels[m], feature_dim))
+        parts.append(discriminative_loss_single(gather(embedding_logits, m), instance_labels[m], feature_dim))
     loss, var, dist, reg = (torch.stack([p[i] for p in parts]) for i in range(4))
     return {"ins_loss": torch.mean(loss), "ins_var_loss": torch.mean(var), "ins_dist_loss": torch.mean(dist),
             "ins_reg_loss": torch.mean(reg)}

@@ -20,7 +20,7 @@ from .. import ops
 from ..applications import Data, Minkowski
 from ..modules import MLP, Seq, fused_head
 from ..torch_points_kernels import region_grow_csr
-from ..torch_scatter import scatter
+from ..torch_scatter import gather, scatter
 from ..utils import meanshift_cluster
 from .losses import discriminative_loss, instance_iou_loss, instance_ious, offset_loss
 from .structures import PanopticLabels, PanopticResults
@@ -256,11 +256,11 @@ class PointGroup3heads(nn.Module):
         self.loss = self.opt.loss_weights.semantic * self.semantic_loss
         mask = inp.instance_mask
         if out.offset_logits is not None:
-            for name, loss in offset_loss(out.offset_logits[mask], inp.vote_label[mask], torch.sum(mask)).items():
+            for name, loss in offset_loss(gather(out.offset_logits, mask), inp.vote_label[mask], torch.sum(mask)).items():
                 setattr(self, name, loss)
                 self.loss = self.loss + self.opt.loss_weights[name] * loss
         if out.embed_logits is not None:
-            for name, loss in discriminative_loss(out.embed_logits[mask], inp.instance_labels[mask], inp.batch[mask],
+            for name, loss in discriminative_loss(gather(out.embed_logits, mask), inp.instance_labels[mask], inp.batch[mask],
                                                   self.opt.embed_dim).items():
                 setattr(self, name, loss)
                 if name == "ins_loss":

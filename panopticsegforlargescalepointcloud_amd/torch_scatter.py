@@ -55,3 +55,30 @@ def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
     s = src.float().unsqueeze(1) if squeeze else src.float()
     y = _ScatterFn.apply(s, index, n_seg, reduce)
     return y.squeeze(1) if squeeze else y
+
+
+class _GatherFn(torch.autograd.Function):
+    """src[index] along dim 0 (the dual of scatter-sum): the gradient is a segment sum over the rows that took the same
+    source row -- torch's own backward of advanced indexing sorts the index and was the slowest kernel of the loss."""
+
+    @staticmethod
+    def forward(ctx, src, index):
+        ctx.index, ctx.shape = index, src.shape
+        src2 = src.reshape(src.shape[0], -1)
+        return ops.gather_rows(src2.contiguous(), index).reshape((index.shape[0],) + tuple(src.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, dout):
+        d2 = dout.reshape(dout.shape[0], -1).contiguous().float()
+        # the forward gather has already dereferenced every id, so they are in range
+        dsrc = ops.segment_reduce(d2, ctx.index, ctx.shape[0], "sum", check=False)
+        return dsrc.reshape(ctx.shape), None
+
+
+def gather(src, index):
+    """src[index] (index: int64 ids or a boolean row mask) with a segment-sum backward."""
+    if index.dtype == torch.bool:
+        index = torch.nonzero(index).view(-1)
+    if not src.requires_grad:
+        return src[index]
+    return _GatherFn.apply(src, index.long())
