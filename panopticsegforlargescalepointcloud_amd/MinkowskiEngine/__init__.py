@@ -490,6 +490,12 @@ class _ConvBase(nn.Module):
         ts_out, nbr, inv_fn = self.out_stride_and_map(x)
         cm = x.coordinate_manager
         n_out = cm.level(ts_out).n
+        if not torch.is_grad_enabled():  # inference: cached packed weights, no autograd bookkeeping
+            feats = ops.spconv_fwd(x.feats.contiguous(), self.packed(), nbr, n_out, self.out_channels, self.kernel_volume,
+                                   row_order=cm.tile_order(ts_out), bf16=_CONV_BF16[0])
+            if self.bias is not None:
+                feats = feats + self.bias
+            return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)
         same_level = self.stride == 1 and self.kernel_volume > 1
         feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume, cm.tile_order(ts_out),
                                     cm.tile_order(x.tensor_stride), same_level, self.mirrored)
