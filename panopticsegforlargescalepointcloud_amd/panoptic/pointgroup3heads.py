@@ -10,6 +10,8 @@ as CSR (ops.ClusterCSR) instead of Python lists until the caller asks for lists;
 the batch at once on the GPU instead of one sklearn process per cylinder; the scorer batch is assembled with one
 gather instead of a Python loop over proposals; eval-mode layers run as fused launches.
 """
+import os
+import threading
 from collections import OrderedDict
 
 import torch
@@ -27,6 +29,7 @@ from .structures import PanopticLabels, PanopticResults
 
 IGNORE_LABEL = -1  # torch_points3d/datasets/segmentation/__init__.py
 MAX_SCORER_BATCH = 60000  # proposals per ScorerUnet launch (batch index must fit the 16-bit key field)
+OVERLAP_CLUSTERING = os.environ.get("PP_CLUSTER_OVERLAP", "1") != "0"  # mean shift on a side stream next to region growing
 
 
 class PointGroup3heads(nn.Module):
@@ -53,6 +56,7 @@ class PointGroup3heads(nn.Module):
                               .append(nn.ReLU()).append(nn.Linear(self.ScorerUnet.output_nc, 1)))
         self.use_score_net = option.get("use_score_net", True)
         self.dedupe_proposals = True  # eval-only optimisation with identical results, see _compute_score
+        self._side_streams = {}        # device -> HIP stream of the overlapped mean shift (see _embed_clusters_async)
         self.cal_iou_based_on_mask = option.get("cal_iou_based_on_mask", False)
         self.cal_iou_based_on_mask_start_epoch = option.get("cal_iou_based_on_mask_start_epoch", 200)
 
@@ -188,17 +192,51 @@ class PointGroup3heads(nn.Module):
         if getattr(self, "_timer", None) is not None:
             self._t0 = self._timer(name, self._t0)
 
+    def _embed_clusters_async(self, pred, emb):
+        """Mean shift on the embeddings does not depend on region growing: in inference it runs on a side stream from a
+        worker thread (both stages are chains of small launches separated by host synchronisations on data-dependent
+        sizes, so one hides in the other's gaps).  Returns a callable that joins and yields the ClusterCSR."""
+        if (not OVERLAP_CLUSTERING or torch.is_grad_enabled() or getattr(self, "_timer", None) is not None
+                or not pred.is_cuda):
+            return None
+        main = torch.cuda.current_stream(pred.device)
+        side = self._side_streams.get(pred.device)
+        if side is None:
+            side = self._side_streams[pred.device] = torch.cuda.Stream(device=pred.device)
+        side.wait_stream(main)
+        box = {}
+
+        def work():
+            try:
+                with torch.cuda.device(pred.device), torch.cuda.stream(side), torch.no_grad():
+                    box["csr"] = self._embed_clusters(pred, emb)
+            except BaseException as e:  # re-raised by the caller's join
+                box["err"] = e
+
+        th = threading.Thread(target=work, name="pp-meanshift")
+        th.start()
+
+        def join():
+            th.join()
+            main.wait_stream(side)
+            if "err" in box:
+                raise box["err"]
+            return box["csr"]
+        return join
+
     def _cluster5(self, pred, off, emb):
+        pending = self._embed_clusters_async(pred, emb)
         votes = self._grow(self.raw_pos + off, pred, 200)
         self._lap("region_grow")
-        embed = self._embed_clusters(pred, emb)
+        embed = pending() if pending is not None else self._embed_clusters(pred, emb)
         self._lap("meanshift")
         return ops.ClusterCSR.concat([votes, embed]), self._types([(votes, 0), (embed, 1)], pred.device)
 
     def _cluster6(self, pred, off, emb):
+        pending = self._embed_clusters_async(pred, emb)
         pos = self._grow(self.raw_pos, pred, None)
         votes = self._grow(self.raw_pos + off, pred, 200)
-        embed = self._embed_clusters(pred, emb)
+        embed = pending() if pending is not None else self._embed_clusters(pred, emb)
         return (ops.ClusterCSR.concat([pos, votes, embed]),
                 self._types([(pos, 0), (votes, 1), (embed, 2)], pred.device))
 
