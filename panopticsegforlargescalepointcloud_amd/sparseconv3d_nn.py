@@ -1,0 +1,57 @@
+"""The second drop-in seam of the reference: the backend surface that
+`torch_points3d/modules/SparseConv3d/nn/__init__.py:21-52` switches between ("torchsparse" / "minkowski") and that
+`torch_points3d/modules/SparseConv3d/modules.py:6-162` and `applications/sparseconv3d.py:120-141` consume as `snn.*`:
+
+    cat, Conv3d, Conv3dTranspose, ReLU, SparseTensor, BatchNorm
+
+Same names, constructor arguments and defaults as the reference's Minkowski flavour (`nn/minkowski.py`), built on the
+MI355X MinkowskiEngine-compatible layer of this package.  To plug it in, register the module under the backend name the
+reference imports:  sys.modules["torch_points3d.modules.SparseConv3d.nn.minkowski"] = this module  (or simply point
+sys.modules["MinkowskiEngine"] at `panopticsegforlargescalepointcloud_amd.MinkowskiEngine` and keep the reference file).
+"""
+import torch
+
+from . import MinkowskiEngine as ME
+
+__all__ = ["cat", "Conv3d", "Conv3dTranspose", "ReLU", "SparseTensor", "BatchNorm"]
+
+
+class Conv3d(ME.MinkowskiConvolution):
+    """3-D sparse convolution; `dimension` is fixed to 3 like in the reference backend."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=dilation, bias=bias,
+                         dimension=3)
+
+
+class Conv3dTranspose(ME.MinkowskiConvolutionTranspose):
+    """3-D transposed sparse convolution onto the cached finer coordinate map."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=dilation, bias=bias,
+                         dimension=3)
+
+
+class BatchNorm(ME.MinkowskiBatchNorm):
+    """BatchNorm1d over the features; the consumer reads `.bn.weight / .bn.bias` (weight initialisation)."""
+
+    def __repr__(self):
+        return repr(self.bn)
+
+
+class ReLU(ME.MinkowskiReLU):
+    def __init__(self, inplace=False):
+        super().__init__(inplace=False)  # the sparse tensor is never modified in place, whatever the caller asks for
+
+
+def cat(*tensors):
+    return ME.cat(*tensors)
+
+
+def SparseTensor(feats, coordinates, batch, device=torch.device("cpu")):
+    """features [N,C], integer voxel coordinates [N,3] and the batch index [N] or [N,1] -> ME.SparseTensor with
+    coordinates (batch, x, y, z).  The tensor must end up on a HIP device: there is no CPU execution path."""
+    if batch.dim() == 1:
+        batch = batch.unsqueeze(-1)
+    coords = torch.cat([batch.int(), coordinates.int()], dim=-1)
+    return ME.SparseTensor(features=feats, coordinates=coords, device=device)

@@ -279,3 +279,23 @@ def test_gt_layout_histogram_matches_oracle():
         assert off.dtype == torch.int32 and sizes.dtype == torch.int32
         np.testing.assert_array_equal(off.numpy(), want_off)
         np.testing.assert_array_equal(sizes.numpy(), want_sizes)
+
+
+def test_sparseconv3d_backend_surface():
+    """the SparseConv3d.nn seam (reference modules/SparseConv3d/nn/__init__.py:21): the six names, their constructor
+    defaults and what the consumer touches (`.bn.weight`, `.kernel` shapes) -- no GPU needed to build the modules."""
+    import inspect
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, sparseconv3d_nn as snn
+    assert set(snn.__all__) == {"cat", "Conv3d", "Conv3dTranspose", "ReLU", "SparseTensor", "BatchNorm"}
+    for cls, base in [(snn.Conv3d, ME.MinkowskiConvolution), (snn.Conv3dTranspose, ME.MinkowskiConvolutionTranspose)]:
+        sig = inspect.signature(cls.__init__).parameters
+        assert [p for p in sig][1:] == ["in_channels", "out_channels", "kernel_size", "stride", "dilation", "bias"]
+        assert (sig["kernel_size"].default, sig["stride"].default, sig["dilation"].default, sig["bias"].default) == (3, 1, 1, False)
+        m = cls(8, 16)
+        assert isinstance(m, base) and tuple(m.kernel.shape) == (27, 8, 16) and m.bias is None
+        assert tuple(cls(8, 16, kernel_size=1).kernel.shape) == (8, 16)
+    bn = snn.BatchNorm(16)
+    assert isinstance(bn, ME.MinkowskiBatchNorm) and bn.bn.weight.shape == (16,) and "BatchNorm1d" in repr(bn)
+    assert isinstance(snn.ReLU(inplace=True), ME.MinkowskiReLU)
+    with pytest.raises(Exception):  # no CPU execution path: the tensor has to live on a HIP device
+        snn.SparseTensor(torch.zeros(4, 3), torch.zeros(4, 3, dtype=torch.int32), torch.zeros(4, dtype=torch.int64))

@@ -213,3 +213,44 @@ def test_bf16_conv_autocast_training_step_close_to_fp32():
     assert abs(l16 - l32) < 0.03 * abs(l32) and l16 != l32
     cos = float(torch.dot(g16, g32) / (g16.norm() * g32.norm()))
     assert 0.95 < cos < 1.0, cos  # measured 0.975: ~80 stacked convolutions with 2^-8 operand rounding each
+
+
+def test_sparseconv3d_backend_block_matches_oracle():
+    """a ResBlock-like stack written against the SparseConv3d.nn seam (snn.Conv3d / BatchNorm / ReLU / cat /
+    Conv3dTranspose / SparseTensor, reference modules/SparseConv3d/modules.py:20-45,159) vs the oracle's convolutions."""
+    from oracle import oracle
+    from panopticsegforlargescalepointcloud_amd import sparseconv3d_nn as snn
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(17)
+    coords = bf.surface_coords(rng)                       # [N,4] (batch, x, y, z), unique
+    n = len(coords)
+    x = rng.normal(size=(n, 16)).astype(np.float32)
+    torch.manual_seed(5)
+    conv1, conv2 = snn.Conv3d(16, 32).to(dev), snn.Conv3d(32, 32, kernel_size=3, stride=2).to(dev)
+    up = snn.Conv3dTranspose(32, 16, kernel_size=3, stride=2).to(dev)
+    bn, relu = snn.BatchNorm(32).to(dev).eval(), snn.ReLU()
+    with torch.no_grad():
+        bn.bn.running_mean.normal_()
+        bn.bn.running_var.uniform_(0.5, 2.0)
+        st = snn.SparseTensor(torch.from_numpy(x), torch.from_numpy(coords[:, 1:]), torch.from_numpy(coords[:, 0]), device=dev)
+        y1 = relu(bn(conv1(st)))
+        y2 = conv2(y1)
+        y3 = snn.cat(up(y2), st)
+        got1, got2, got3 = y1.F.cpu().numpy(), y2.F.cpu().numpy(), y3.F.cpu().numpy()
+        coarse_got = y2.C.cpu().numpy()
+    scale = (bn.bn.weight / torch.sqrt(bn.bn.running_var + bn.bn.eps)).detach().cpu().numpy()
+    shift = (bn.bn.bias - bn.bn.running_mean * torch.from_numpy(scale).to(dev)).detach().cpu().numpy()
+    nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
+    want1 = oracle.spconv_fwd(x, conv1.kernel.detach().cpu().numpy(), nbr, n, scale=scale, shift=shift, relu=True)
+    np.testing.assert_allclose(got1, want1, rtol=1e-4, atol=1e-4)
+    coarse, _ = oracle.stride_coords(coords, 2)
+    # the coarse level's row order is internal: compare as sets of (coordinate, feature row)
+    down = oracle.kernel_map(coarse, coords, 3, 1, 1)
+    want2 = oracle.spconv_fwd(want1, conv2.kernel.detach().cpu().numpy(), down, len(coarse))
+    key = lambda c: np.lexsort(c.T[::-1])
+    og, ow = key(coarse_got), key(coarse)
+    assert np.array_equal(coarse_got[og], coarse[ow])
+    np.testing.assert_allclose(got2[og], want2[ow], rtol=1e-4, atol=1e-4)
+    upm = oracle.kernel_map(coords, coarse, 3, 1, -1)
+    want3 = np.concatenate([oracle.spconv_fwd(want2, up.kernel.detach().cpu().numpy(), upm, n), x], 1)
+    np.testing.assert_allclose(got3, want3, rtol=1e-4, atol=2e-4)
