@@ -15,6 +15,7 @@ or                  sys.modules["MinkowskiEngine"] = panopticsegforlargescalepoi
 """
 import math
 import os
+import threading
 
 import torch
 from torch import nn
@@ -46,6 +47,17 @@ TILE_WINDOW = int(os.environ.get("PP_TILE_WINDOW", "0"))
 # operands rounded to bfloat16 in registers, fp32 accumulation, fp32 tensors in memory -- what torch.autocast(bfloat16)
 # does to a convolution.  `conv_autocast()` switches it for a region of code.
 _CONV_BF16 = [os.environ.get("PP_CONV_DTYPE", "fp32").lower() == "bf16"]
+# inference: coarser levels and their kernel maps are built on a side stream by a worker thread that replays the
+# requests of the model's previous forward, while the main stream already runs the convolutions of the finer levels
+MAP_PREFETCH = os.environ.get("PP_MAP_PREFETCH", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 class conv_autocast:
@@ -160,6 +172,53 @@ class CoordinateManager:
         self.tile_orders = {}
         self.rulebooks = {}
         self.densities = {}
+        # prefetch support: one lock around level / map construction, an event per built item (the builder's stream
+        # may not be the consumer's), an optional log of the requests (the plan replayed by the next forward)
+        self._lock = threading.RLock()
+        self._ready = {}
+        self._log = None
+        self._worker = None
+        self._worker_err = None
+
+    def _built(self, key):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ready[key] = ev
+
+    def _use(self, key):
+        ev = self._ready.get(key)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def prefetch(self, plan):
+        """replay `plan` (the request log of an earlier forward of the same model) on the side stream"""
+        dev = self.orig_coords.device
+        side = _side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
+        def work():
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(side), torch.no_grad():
+                    for item in plan:
+                        if item[0] == "stride":
+                            self.ensure_stride(item[1], item[2])
+                        else:
+                            self.kernel_map(*item[1])
+            except BaseException as e:  # surfaced by join_prefetch
+                self._worker_err = e
+
+        self._worker = threading.Thread(target=work, name="pp-map-prefetch")
+        self._worker.start()
+
+    def join_prefetch(self):
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+            dev = self.orig_coords.device
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+            if self._worker_err is not None:
+                err, self._worker_err = self._worker_err, None
+                raise err
 
     def rulebook(self, ts_from, ts_to, ksize, sign):
         key = (ts_from, ts_to, ksize, sign)
@@ -180,6 +239,7 @@ class CoordinateManager:
         return d
 
     def level(self, ts):
+        self._use(("level", ts))
         return self.levels[ts]
 
     def tile_order(self, ts):
@@ -193,12 +253,24 @@ class CoordinateManager:
         return feats if self.inv_perm is None else _permute_rows(feats, self.inv_perm, self.perm)
 
     def ensure_stride(self, ts_in, stride):
+        if self._log is not None:
+            self._log.append(("stride", ts_in, stride))
+        ts_out = ts_in * stride
+        if ts_out not in self.levels:  # (lock-free when the level exists: the worker may hold the lock for a while)
+            with self._lock:
+                self._ensure_stride_locked(ts_in, stride)
+        self._use(("level", ts_out))
+        return ts_out
+
+    def _ensure_stride_locked(self, ts_in, stride):
         ts_out = ts_in * stride
         if ts_out not in self.levels:
+            self._use(("level", ts_in))
             src = self.levels[ts_in]
             if self.sorted and stride == 2 and ORDER_BLOCK_BITS == 4 and src.index is not None and COARSEN_FROM_INDEX:
                 # the coarse level is a bit permutation of the fine level's occupancy bitmaps: no hash, no sort
                 index, out = ops.block_index_coarsen(src.index, src.n)
+                self._built(("level", ts_out))  # event first: lock-free readers find the item only with its event
                 self.levels[ts_out] = _Level(out, index=index)
                 return ts_out
             out, table, _ = ops.stride_coords(src.coords, ts_out)
@@ -207,8 +279,10 @@ class CoordinateManager:
                 if out.shape[0] > 1:
                     out = ops.morton_order(out, ts_out, ORDER_BLOCK_BITS, want_sorted=True)[1]
                 index, _ = ops.block_index_build(out, ts_out, ORDER_BLOCK_BITS)
+                self._built(("level", ts_out))
                 self.levels[ts_out] = _Level(out, index=index)
             else:
+                self._built(("level", ts_out))
                 self.levels[ts_out] = _Level(out, table=table)
         return ts_out
 
@@ -218,11 +292,26 @@ class CoordinateManager:
                 raise NotImplementedError("1x1x1 convolutions with stride > 1 are not used by the reference path")
             return None
         key = (ts_from, ts_to, ksize, sign)
+        if self._log is not None:
+            self._log.append(("map", key))
         m = self.maps.get(key)
         if m is None:
+            with self._lock:
+                m = self._kernel_map_locked(key)
+        self._use(key)
+        return m
+
+    def _kernel_map_locked(self, key):
+        ts_from, ts_to, ksize, sign = key
+        m = self.maps.get(key)
+        if m is None:
+            self._use(("level", ts_from))
+            self._use(("level", ts_to))
             if ts_to not in self.levels:
                 raise ValueError("transposed convolution onto tensor stride %d: that coordinate map was never created" % ts_to)
             rev = self.maps.get((ts_to, ts_from, ksize, -sign))
+            if rev is not None:
+                self._use((ts_to, ts_from, ksize, -sign))
             if rev is not None and ts_from == ts_to:
                 m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
                 if hasattr(rev, "pp_pairs"):
@@ -239,6 +328,7 @@ class CoordinateManager:
                         del m.pp_mask
                 else:
                     m = ops.kernel_map(self.levels[ts_to].coords, src.table, ksize, min(ts_from, ts_to), sign)
+            self._built(key)
             self.maps[key] = m
         return m
 

@@ -181,14 +181,27 @@ class MinkowskiUnet(BaseMinkowski):
         gather) -- enough for order-independent consumers such as the per-proposal max of the scorer."""
         self._set_input(data)
         data = self.input
-        stack_down = []
-        for i in range(len(self.down_modules) - 1):
-            data = self.down_modules[i](data)
-            stack_down.append(data)
-        data = self.down_modules[-1](data)
-        stack_down.append(None)
-        for i in range(len(self.up_modules)):
-            data = self.up_modules[i](data, stack_down.pop())
+        cm = data.coordinate_manager
+        prefetch = (ME.MAP_PREFETCH and not torch.is_grad_enabled() and ME.CONV_MODE in ("auto", "dense")
+                    and ME.TILE_WINDOW == 0)
+        plan = getattr(self, "_map_plan", None)
+        if prefetch and plan is None:
+            cm._log = []            # first inference pass of this model: record the level / map requests ...
+        elif prefetch:
+            cm.prefetch(plan)       # ... later passes replay them ahead of the convolutions on the side stream
+        try:
+            stack_down = []
+            for i in range(len(self.down_modules) - 1):
+                data = self.down_modules[i](data)
+                stack_down.append(data)
+            data = self.down_modules[-1](data)
+            stack_down.append(None)
+            for i in range(len(self.up_modules)):
+                data = self.up_modules[i](data, stack_down.pop())
+        finally:
+            cm.join_prefetch()
+            if cm._log is not None:
+                self._map_plan, cm._log = cm._log, None
         if internal_order:
             out = Data(x=data.feats, pos=None, batch=data.coordinate_manager.level(1).coords[:, 0])
         else:
