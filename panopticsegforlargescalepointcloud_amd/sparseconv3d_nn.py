@@ -16,32 +16,27 @@ from . import MinkowskiEngine as ME
 __all__ = ["cat", "Conv3d", "Conv3dTranspose", "ReLU", "SparseTensor", "BatchNorm"]
 
 
-class Conv3d(ME.MinkowskiConvolution):
-    """3-D sparse convolution; `dimension` is fixed to 3 like in the reference backend."""
+def _conv_flavour(name, base, doc):
+    """3-D flavour of a MinkowskiEngine convolution class: the backend surface drops `dimension` / `kernel_generator`
+    and defaults to a 3x3x3 kernel."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, bias=False):
-        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=dilation, bias=bias,
-                         dimension=3)
+        base.__init__(self, in_channels, out_channels, kernel_size, stride, dilation, bias, dimension=3)
+
+    return type(name, (base,), {"__init__": __init__, "__doc__": doc, "__module__": __name__})
 
 
-class Conv3dTranspose(ME.MinkowskiConvolutionTranspose):
-    """3-D transposed sparse convolution onto the cached finer coordinate map."""
-
-    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, bias=False):
-        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=dilation, bias=bias,
-                         dimension=3)
-
-
-class BatchNorm(ME.MinkowskiBatchNorm):
-    """BatchNorm1d over the features; the consumer reads `.bn.weight / .bn.bias` (weight initialisation)."""
-
-    def __repr__(self):
-        return repr(self.bn)
+Conv3d = _conv_flavour("Conv3d", ME.MinkowskiConvolution, "3-D sparse convolution (stride s creates / reuses the level at s x the tensor stride).")
+Conv3dTranspose = _conv_flavour("Conv3dTranspose", ME.MinkowskiConvolutionTranspose,
+                                "3-D transposed sparse convolution onto the cached finer coordinate map.")
+# BatchNorm1d over the features; the consumer reads `.bn.weight / .bn.bias` when it initialises the weights
+BatchNorm = type("BatchNorm", (ME.MinkowskiBatchNorm,), {"__repr__": lambda self: repr(self.bn), "__module__": __name__})
 
 
 class ReLU(ME.MinkowskiReLU):
     def __init__(self, inplace=False):
-        super().__init__(inplace=False)  # the sparse tensor is never modified in place, whatever the caller asks for
+        del inplace  # a sparse tensor's features are never modified in place, whatever the caller asks for
+        super().__init__()
 
 
 def cat(*tensors):
