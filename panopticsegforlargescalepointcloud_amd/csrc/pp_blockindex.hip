@@ -327,13 +327,20 @@ extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t
 // ---- kernel map through the index ------------------------------------------------------------------------------------
 // One thread per output row.  The keys of its 27 neighbours are ORs of 9 per-axis terms; the block found for the
 // previous neighbour is kept in registers (a row's neighbours touch <= 8 blocks, usually 1-3).
+// CUBE (block_bits <= 4: a block is a 16^3 cube of the level's lattice): along one axis the three neighbour positions
+// fall into at most two blocks, so the 27 probes touch at most 2 x 2 x 2 blocks.  Those are looked up first; then the
+// bitmap words and prefixes of ALL 27 probes are loaded unconditionally (index 0 for absent ones) before any of them is
+// used.  By PMC the one-probe-at-a-time form spent 88 % of its wave cycles in s_waitcnt on a chain of 4-5 dependent
+// loads per probe (2.9 us per probe); here a row pays the lookup chain once and one batch of 54 independent loads.
+template <bool CUBE>
 __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ out_coords, int64_t n_out, BlockIndex I,
                                                        int unit_shift, int block_bits, int dstep,
                                                        int32_t* __restrict__ nbr, unsigned long long* n_pairs,
                                                        uint32_t* __restrict__ mask_out) {
-  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride over the rows: the pair count is ONE atomic per wave at the very end (an atomic per wave and row chunk
+  // on the same address serialises in L2: 154 k of them cost most of the 2 ms a 9.8 M-row map used to take)
   int found = 0;
-  if (o < n_out) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (int64_t)gridDim.x * blockDim.x) {
     const int4 c = out_coords[o];
     uint64_t ax[3][3];
     bool ok[3][3];
@@ -349,9 +356,84 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
       }
     const uint64_t kb = (uint64_t)(uint16_t)c.x << 48;
     const bool bok = (unsigned)c.x < 65536u;
+    uint32_t fmask = 0;
+    if constexpr (CUBE) {
+      uint64_t pa[3], pb[3];  // the (at most two) block parts of the key per axis, defined by the valid positions
+      bool alt[3];
+      int sel[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        pa[a] = pb[a] = 0;
+        alt[a] = false;
+        bool have = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const uint64_t part = ax[a][d] >> 12;
+          sel[a][d] = 0;
+          if (!ok[a][d]) continue;
+          if (!have) {
+            pa[a] = pb[a] = part;
+            have = true;
+          } else if (part != pa[a]) {
+            pb[a] = part;
+            alt[a] = true;
+            sel[a][d] = 1;
+          }
+        }
+      }
+      int lb[8], ls[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        lb[t] = -1;
+        ls[t] = 0;
+        if (bok && (!(t & 1) || alt[0]) && (!(t & 2) || alt[1]) && (!(t & 4) || alt[2])) {
+          const uint64_t blk = (kb >> 12) | ((t & 1) ? pb[0] : pa[0]) | ((t & 2) ? pb[1] : pa[1]) | ((t & 4) ? pb[2] : pa[2]);
+          lb[t] = bi_find_block(I, blk);
+          ls[t] = lb[t] >= 0 ? I.start[lb[t]] : 0;
+        }
+      }
+      uint64_t word[27];
+      uint32_t pre[27], meta[27];  // meta: bit 0..5 = bit index, bit 8 = probe valid; the block start goes to st[]
+      int st[27];
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        int zb[4], zs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          zb[t] = sel[2][dz] ? lb[4 + t] : lb[t];
+          zs[t] = sel[2][dz] ? ls[4 + t] : ls[t];
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yb0 = sel[1][dy] ? zb[2] : zb[0], yb1 = sel[1][dy] ? zb[3] : zb[1];
+          const int ys0 = sel[1][dy] ? zs[2] : zs[0], ys1 = sel[1][dy] ? zs[3] : zs[1];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int k = dx + 3 * dy + 9 * dz;
+            const int blk_i = sel[0][dx] ? yb1 : yb0;
+            const bool valid = blk_i >= 0 && ok[0][dx] && ok[1][dy] && ok[2][dz];
+            const uint32_t code = (uint32_t)((ax[0][dx] | ax[1][dy] | ax[2][dz]) & 4095ull);
+            const uint32_t w = valid ? (uint32_t)blk_i * BI_WORDS + (code >> 6) : 0u;  // word 0 always exists
+            word[k] = I.bits[w];
+            pre[k] = I.pre[w];
+            meta[k] = (code & 63u) | (valid ? 256u : 0u);
+            st[k] = sel[0][dx] ? ys1 : ys0;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int bit = (int)(meta[k] & 63u);
+        int32_t r = -1;
+        if ((meta[k] & 256u) && ((word[k] >> bit) & 1ull))
+          r = st[k] + (int)pre[k] + __popcll(word[k] & ((1ull << bit) - 1ull));
+        found += r >= 0 ? 1 : 0;
+        fmask |= (r >= 0 ? 1u : 0u) << k;
+        nbr[(int64_t)k * n_out + o] = r;
+      }
+    } else {
     uint64_t last_blk = ~0ull;
     int last_b = -1, last_start = 0;
-    uint32_t fmask = 0;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
       const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
@@ -376,6 +458,7 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
       fmask |= (r >= 0 ? 1u : 0u) << k;
       nbr[(int64_t)k * n_out + o] = r;
     }
+    }
     if (mask_out) mask_out[o] = fmask;
   }
   if (n_pairs) {
@@ -383,6 +466,8 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
     if ((threadIdx.x & 63) == 0 && found) atomicAdd(n_pairs, (unsigned long long)found);
   }
 }
+
+static inline unsigned kmb_grid(int64_t n_out) { return (unsigned)std::min<int64_t>(pp_blocks(n_out, 256), 256 * 16); }
 
 extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals,
                                 int64_t cap, const int32_t* start, const uint64_t* bits, const uint16_t* pre,
@@ -398,8 +483,13 @@ extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const 
   int unit_shift = 0;
   while ((1 << unit_shift) < unit_src) ++unit_shift;
   BlockIndex I{bkeys, bvals, cap, start, bits, pre};
-  hipLaunchKernelGGL(k_kernel_map_bi, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, (const int4*)out_coords, n_out, I,
-                     unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
+  static const bool cube_ok = !(getenv("PP_KMAP_CUBE") && atoi(getenv("PP_KMAP_CUBE")) == 0);
+  if (block_bits <= 4 && cube_ok)
+    hipLaunchKernelGGL(k_kernel_map_bi<true>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
+                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
+  else
+    hipLaunchKernelGGL(k_kernel_map_bi<false>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
+                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

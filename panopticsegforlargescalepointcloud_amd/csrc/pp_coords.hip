@@ -156,9 +156,10 @@ __global__ __launch_bounds__(256) void k_kernel_map(const int4* __restrict__ out
                                                     const uint64_t* __restrict__ keys,
                                                     const int32_t* __restrict__ vals, int64_t cap, int step,
                                                     int32_t* __restrict__ nbr, unsigned long long* n_pairs) {
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride rows: the pair count costs one atomic per wave of the (bounded) grid, not one per 64 rows -- atomics on
+  // one address serialise in L2 (see k_kernel_map_bi)
   int found = 0;
-  if (o < n_out) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (int64_t)gridDim.x * blockDim.x) {
   int4 c = out_coords[o];
   constexpr int K = KS * KS * KS;
 #pragma unroll
@@ -193,7 +194,7 @@ extern "C" int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uin
   hipStream_t s = pp_s(stream);
   if (n_pairs) PP_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int64_t), s));
   if (n_out == 0) return PP_OK;
-  unsigned nb = pp_blocks(n_out, 256);
+  unsigned nb = (unsigned)std::min<int64_t>(pp_blocks(n_out, 256), 256 * 16);
   if (ksize == 3)
     hipLaunchKernelGGL(k_kernel_map<3>, dim3(nb), dim3(256), 0, s, (const int4*)out_coords, n_out, keys, vals, cap,
                        sign * step, nbr, (unsigned long long*)n_pairs);
