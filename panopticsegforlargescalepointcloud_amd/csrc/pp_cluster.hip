@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
 // ascending index order -- broadcast LDS reads, no global traffic -- appending hits until it has nsample of them:
 // exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
 #define BQC_CAP 1536
+#ifndef BQC_ROUND
+#define BQC_ROUND 8  // candidates per round of the query walk (by PMC the kernel waits on LDS 3/4 of the time)
+#endif
 __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                           const uint64_t* __restrict__ keys,
                                                           const int32_t* __restrict__ cell_start,
@@ -305,18 +308,18 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
       }
       int cnt = 0;
       int j = 0;
-      for (; j + 4 <= total && cnt < nsample; j += 4) {  // four candidates per round: one LDS latency instead of four
-        float4 pc[4];
-        bool hit[4];
+      for (; j + BQC_ROUND <= total && cnt < nsample; j += BQC_ROUND) {  // several candidates per round: one LDS latency
+        float4 pc[BQC_ROUND];
+        bool hit[BQC_ROUND];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pc[u] = cand[j + u];
+        for (int u = 0; u < BQC_ROUND; ++u) pc[u] = cand[j + u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BQC_ROUND; ++u) {
           const float dx = q.x - pc[u].x, dy = q.y - pc[u].y, dz = q.z - pc[u].z;
           hit[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BQC_ROUND; ++u)
           if (hit[u] && cnt < nsample) list[(int64_t)(cnt++) * M + qq] = __float_as_int(pc[u].w);
       }
       for (; j < total && cnt < nsample; ++j) {
