@@ -349,8 +349,8 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
   } else {                                                                                                \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
       if ((m[tt] >> (KC)) & 1u) {                                                                         \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                     \
-            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                            \
+        _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                 \
                 acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
       }                                                                                                   \
     }                                                                                                     \
