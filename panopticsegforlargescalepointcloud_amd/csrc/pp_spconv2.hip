@@ -229,9 +229,11 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 
   // ---- prologue: neighbour rows -> byte offsets in LDS, per-tile occupancy masks -> SGPRs
   unsigned m[T];
-#pragma unroll
-  for (int tt = 0; tt < T; ++tt) m[tt] = 0;
   {
+    // lanes (kh, rr): rr = row slot of the wave, kh = which half of the offsets (KPL = 2 halves when a wave has 32 rows).
+    // Offsets are split in contiguous halves (k = kk + NL * kh), every lane keeps one presence bit per kk, a 4-step
+    // OR over the 16 lanes of a row tile and T * KPL readlanes give the per-tile masks -- the earlier form decoded
+    // every ballot with ~6 scalar instructions per (offset, tile), a quarter of the wave's non-MFMA issue slots
     constexpr int KPL = 64 / R >= 1 ? 64 / R : 1;
     constexpr int NL = (F2_MAXK + KPL - 1) / KPL;
     const int rr = lane % R, kh = lane / R;
@@ -245,26 +247,32 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     if (a.nbr) {
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
-        const int k = KPL * kk + kh;
+        const int k = kk + NL * kh;
         const int kc = k < a.K ? k : a.K - 1;
         v[kk] = a.nbr[(int64_t)kc * a.n_out + rowc];
       }
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk)
-        if (!rv || KPL * kk + kh >= a.K) v[kk] = -1;
+        if (!rv || kk + NL * kh >= a.K) v[kk] = -1;
     } else {
 #pragma unroll
-      for (int kk = 0; kk < NL; ++kk) v[kk] = (rv && KPL * kk + kh < a.K) ? (int)row : -1;
+      for (int kk = 0; kk < NL; ++kk) v[kk] = (rv && kk + NL * kh < a.K) ? (int)row : -1;
     }
+    unsigned ml = 0;
 #pragma unroll
     for (int kk = 0; kk < NL; ++kk) {
-      if (KPL * kk + kh < F2_MAXK) off[KPL * kk + kh][rr] = v[kk] >= 0 ? (unsigned)v[kk] * row_bytes : F3_MISSING;
-      const unsigned long long b = __ballot(v[kk] >= 0);
+      const int k = kk + NL * kh;
+      if (k < F2_MAXK) off[k][rr] = v[kk] >= 0 ? (unsigned)v[kk] * row_bytes : F3_MISSING;
+      ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ml |= (unsigned)__shfl_xor((int)ml, o);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      m[tt] = 0;
 #pragma unroll
       for (int h = 0; h < KPL; ++h)
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt)
-          m[tt] |= (((b >> (h * R + tt * 16)) & 0xFFFFull) ? 1u : 0u) << (KPL * kk + h);
+        m[tt] |= (unsigned)__builtin_amdgcn_readlane((int)ml, h * R + tt * 16) << (NL * h);
     }
   }
   unsigned rem = 0;
@@ -539,7 +547,14 @@ int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned g
     const char* e = getenv("PP_DENSE_T");
     t_env = e ? atoi(e) : 0;
   }
-  const int T = t_env ? t_env : 2;
+  // rows per wave: 64 (T = 4) on launches with <= PP_DENSE_T4_NTW (default 2) column tiles per wave -- narrow layers are
+  // bound by per-step work, which 64 rows halve per row (end to end 186.9 -> 183.7 ms) -- and 32 (T = 2) on wider ones,
+  // where the extra accumulators cost occupancy (48->48: 660 vs 690 us), and on launches below PP_DENSE_T4_ROWS (2 M)
+  // rows, where halving the number of waves costs more (one rank's share at 8 GPUs: 34.1 vs 34.6 ms); PP_DENSE_T forces
+  // one value
+  static const int t4_ntw = getenv("PP_DENSE_T4_NTW") ? atoi(getenv("PP_DENSE_T4_NTW")) : 2;
+  static const int64_t t4_rows = getenv("PP_DENSE_T4_ROWS") ? atoll(getenv("PP_DENSE_T4_ROWS")) : 2000000;
+  const int T = t_env ? t_env : (ntw <= t4_ntw && a.n_out >= t4_rows ? 4 : 2);
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   if (a.bf16)
