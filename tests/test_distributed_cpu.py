@@ -78,6 +78,38 @@ def test_exchange_and_assembly_world2():
         assert ins_bytes == ref_ins.tobytes() and mx == ref_mx and cnt == int(ref_cnt.sum())
 
 
+def _worker_edge(rank, world, port, q):
+    """one rank without tiles, origin ids beyond 2^31 (the exchange switches to an int64 buffer)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results
+    big = 2 ** 31 + 5
+    allr = {3: (torch.arange(big, big + 40, dtype=torch.int64), torch.arange(40, dtype=torch.int32) % 7 - 1)}
+    local = dict(allr) if rank == 0 else {}
+    full = exchange_tile_results(local)
+    ok = sorted(full) == [3] and torch.equal(full[3][0], allr[3][0]) and torch.equal(full[3][1], allr[3][1])
+    ok = ok and full[3][0].dtype == torch.int64 and full[3][1].dtype == torch.int32
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_empty_rank_and_wide_ids_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in got), got
+
+
 def test_exchange_single_process_is_identity():
     from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results
     r = _tile_results(3, 4000)
