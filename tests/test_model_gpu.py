@@ -254,3 +254,33 @@ def test_sparseconv3d_backend_block_matches_oracle():
     upm = oracle.kernel_map(coords, coarse, 3, 1, -1)
     want3 = np.concatenate([oracle.spconv_fwd(want2, up.kernel.detach().cpu().numpy(), upm, n), x], 1)
     np.testing.assert_allclose(got3, want3, rtol=1e-4, atol=2e-4)
+
+
+def test_side_stream_overlap_does_not_change_results(setup):
+    """the worker-thread / side-stream stages (mean shift next to region growing, level + kernel-map prefetch) only
+    reorder work: labels, proposals, scores and logits are bit-identical with both switched off, and stay identical over
+    repeated passes (the prefetch plan is recorded on a model's first pass and replayed afterwards)."""
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME
+    from panopticsegforlargescalepointcloud_amd.panoptic import pointgroup3heads as pg
+    s = setup
+    dev = torch.device("cuda")
+    ov = tuple(torch.from_numpy(a).to(dev) for a in s["override"])
+
+    def run():
+        labels, res, counts = s["runner"].run(s["b"], len(s["ids"]), override=ov)
+        torch.cuda.synchronize()
+        return (labels.clone(), res.clusters_csr.offsets.clone(), res.clusters_csr.points.clone(),
+                res.cluster_scores.clone(), res.semantic_logits.clone(), list(counts))
+
+    saved = (ME.MAP_PREFETCH, pg.OVERLAP_CLUSTERING)
+    try:
+        ME.MAP_PREFETCH, pg.OVERLAP_CLUSTERING = True, True
+        on = [run() for _ in range(3)]          # pass 1 may record the plan, passes 2-3 replay it
+        ME.MAP_PREFETCH, pg.OVERLAP_CLUSTERING = False, False
+        off = run()
+    finally:
+        ME.MAP_PREFETCH, pg.OVERLAP_CLUSTERING = saved
+    for got in on:
+        for a, b in zip(got[:5], off[:5]):
+            assert torch.equal(a, b)
+        assert got[5] == off[5]
