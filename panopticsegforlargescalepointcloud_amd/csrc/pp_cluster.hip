@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
 // staged in LDS once, sorted by local index (bitonic), and every query of the cell (one lane each) walks them in
 // ascending index order -- broadcast LDS reads, no global traffic -- appending hits until it has nsample of them:
 // exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
-#define BQC_CAP 1536
+#ifndef BQC_CAP
+#define BQC_CAP 1536  // measured optimum: 768 / 1024 / 1536 / 2048 / 2560 -> region growing 29.6 / 25.8 / 19.3 / 23.6 / 35.6 ms
+#endif
 #ifndef BQC_ROUND
 #define BQC_ROUND 8  // candidates per round of the query walk (by PMC the kernel waits on LDS 3/4 of the time)
 #endif
