@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
                                                           const int32_t* __restrict__ cell_p0,
                                                           const int32_t* __restrict__ n_cells, int32_t* __restrict__ list,
                                                           int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count) {
-  __shared__ float4 raw[BQC_CAP];   // candidates as loaded: 27 runs, each ascending in local index (.w)
-  __shared__ float4 cand[BQC_CAP];  // merged: ascending in local index
+  __shared__ int rawkey[BQC_CAP];   // local indices of the candidates as loaded: 27 runs, each ascending
+  __shared__ float4 cand[BQC_CAP];  // merged candidates: ascending in local index (.w)
   __shared__ int nb_start[27], nb_cnt[27], nb_off[28];
   __shared__ int n_bad;
   const int tid = threadIdx.x;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
           if (nb_off[mid] <= f) lo = mid; else hi = mid;
         }
         const int src = nb_start[lo] + (f - nb_off[lo]);
-        raw[f] = spos[src];
+        rawkey[f] = __float_as_int(spos[src].w);  // keys only: 6 KB instead of 24 KB of LDS (5 workgroups per CU, not 3)
         bad += sbc[src] != bc0 ? 1 : 0;  // another (batch, class) behind an aliased cell key
       }
       if (bad) atomicAdd(&n_bad, bad);
@@ -284,17 +284,17 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
         const int mid = (lo + hi) >> 1;
         if (nb_off[mid] <= f) lo = mid; else hi = mid;
       }
-      const float4 me = raw[f];
-      const int key = __float_as_int(me.w);
+      const float4 me = spos[nb_start[lo] + (f - nb_off[lo])];  // re-read from L2: the staging pass has just touched it
+      const int key = rawkey[f];
       int pos = f - nb_off[lo];
       for (int k = 0; k < 27; ++k) {
         const int n = nb_cnt[k];
         if (k == lo || n == 0) continue;
-        const float4* run = raw + nb_off[k];
+        const int* run = rawkey + nb_off[k];
         int a0 = 0, a1 = n;  // first element of the run with index > key
         while (a0 < a1) {
           const int mid = (a0 + a1) >> 1;
-          if (__float_as_int(run[mid].w) < key) a0 = mid + 1; else a1 = mid;
+          if (run[mid] < key) a0 = mid + 1; else a1 = mid;
         }
         pos += a0;
       }
