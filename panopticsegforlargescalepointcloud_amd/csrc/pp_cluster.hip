@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ s
 // exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
 #ifndef BQC_CAP
 #define BQC_CAP 1536  // measured optimum: 768 / 1024 / 1536 / 2048 / 2560 -> region growing 29.6 / 25.8 / 19.3 / 23.6 / 35.6 ms
+                      // (16.4 / 19.2 / 19.1 ms for 1536 / 2048 / 2560 once only the keys are staged in LDS)
 #endif
 #ifndef BQC_ROUND
 #define BQC_ROUND 8  // candidates per round of the query walk (by PMC the kernel waits on LDS 3/4 of the time)
