@@ -385,9 +385,24 @@ __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict_
   if (ch) changed[0] = 1;
 }
 
+// histogram add with one atomic per run of equal keys inside a wave (cell-sorted points carry long runs of the same
+// cluster id; one atomic per element on a few hot addresses serialises in L2)
+__device__ __forceinline__ void rg_hist_add_runs(int32_t* hist, int k, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const int kk = valid ? k : -1;
+  const int prev = __shfl_up(kk, 1);
+  const bool lead = lane == 0 || prev != kk;
+  const unsigned long long lm = __ballot(lead);
+  if (lead && kk >= 0) {
+    const unsigned long long higher = lane < 63 ? (lm >> (lane + 1)) : 0ull;
+    const int next = higher ? lane + 1 + __builtin_ctzll(higher) : 64;
+    atomicAdd(&hist[kk], next - lane);  // lanes past the end of the data carry kk = -1 and start their own run
+  }
+}
+
 __global__ __launch_bounds__(256) void k_rg_sizes(const int32_t* __restrict__ L, int64_t M, int32_t* size) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < M) atomicAdd(&size[L[v]], 1);
+  rg_hist_add_runs(size, v < M ? L[v] : -1, v < M);
 }
 __global__ __launch_bounds__(256) void k_rg_rootkeys(const int32_t* __restrict__ L, const int32_t* __restrict__ size,
                                                      const int32_t* __restrict__ bc, int64_t M, int min_size,
@@ -435,14 +450,16 @@ static inline int bits_for(int64_t v) {
 __global__ __launch_bounds__(256) void k_gbk_keys(const int32_t* __restrict__ key, int64_t n, int n_groups,
                                                   uint32_t* ukey, int32_t* hist, int32_t* err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int32_t k = key[i];
-  if (k >= n_groups) {
-    atomicAdd(err, 1);
-    k = -1;
+  int32_t k = -1;
+  if (i < n) {
+    k = key[i];
+    if (k >= n_groups) {
+      atomicAdd(err, 1);
+      k = -1;
+    }
+    ukey[i] = k < 0 ? (uint32_t)n_groups : (uint32_t)k;
   }
-  ukey[i] = k < 0 ? (uint32_t)n_groups : (uint32_t)k;
-  if (k >= 0) atomicAdd(&hist[k], 1);
+  rg_hist_add_runs(hist, k, k >= 0);
 }
 __global__ __launch_bounds__(256) void k_gbk_emit(const int32_t* __restrict__ sorted_idx, const int64_t* __restrict__ ids,
                                                   const int32_t* __restrict__ total, int64_t n, int64_t* out) {
