@@ -320,11 +320,12 @@ int pp_cylinder_pairs(const float* pos /*[n,3]*/, int64_t n, const float* centre
 
 /* Group points by a small integer key into CSR form (stable: ascending point order inside a group).
  * key[i] in [0,n_groups) or -1 (dropped).  ids[i] (int64) is what gets written (NULL -> i).
- * offsets [n_groups+1], out [n] capacity, total[0] = #kept.  Used to turn labels into the
+ * offsets [n_groups+1], out [n] capacity, total[0] = #kept.  Keys >= n_groups are dropped too, but they are a caller
+ * error: n_out_of_range[0] (device, nullable) receives their number.  Used to turn labels into the
  * List[LongTensor] the reference APIs return (meanshift_cluster.py:102-111). */
 size_t pp_group_by_key_workspace(int64_t n);
 int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n, int32_t n_groups, int32_t* offsets,
-                    int64_t* out, int32_t* total, void* workspace, size_t workspace_bytes,
+                    int64_t* out, int32_t* total, int32_t* n_out_of_range, void* workspace, size_t workspace_bytes,
                     pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -72,7 +72,7 @@ SIGNATURES = {
     "pp_cylinder_pairs_workspace": (sz, [i64]),
     "pp_cylinder_pairs": (C.c_int, [vp, i64, vp, i32, f32, vp, vp, i64, vp, vp, sz, vp]),
     "pp_group_by_key_workspace": (sz, [i64]),
-    "pp_group_by_key": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_group_by_key": (C.c_int, [vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "pp_segment_reduce_workspace": (sz, [i64]),
     "pp_segment_reduce": (C.c_int, [vp, vp, i64, i32, i64, i32, vp, vp, vp, sz, vp]),
     "pp_segment_reduce_unchecked": (C.c_int, [vp, vp, i64, i32, i64, i32, vp, vp, vp, sz, vp]),

@@ -105,19 +105,17 @@ class UnwrappedUnetBasedModel(nn.Module):
 
     @staticmethod
     def _fetch_arguments_from_list(opt, index):
-        args = {}
-        for o, v in opt.items():
-            name = str(o)
-            if is_list(v) and len(v) > 0:
-                if name[-1] == "s" and name not in SPECIAL_NAMES:
-                    name = name[:-1]
-                v_index = v[index]
-                if is_list(v_index):
-                    v_index = list(v_index)
-                args[name] = v_index
-            else:
-                args[name] = list(v) if is_list(v) else v
-        return args
+        """Constructor arguments of layer `index` from a down_conv / up_conv section: list-valued options are indexed
+        per layer and lose a plural "s" (`down_conv_nn` style names in SPECIAL_NAMES keep theirs), scalars are shared by
+        all layers (unet.py:456-474)."""
+        def per_layer(key, value):
+            if not (is_list(value) and len(value) > 0):
+                return key, (list(value) if is_list(value) else value)
+            item = value[index]
+            singular = key[:-1] if key.endswith("s") and key not in SPECIAL_NAMES else key
+            return singular, (list(item) if is_list(item) else item)
+
+        return dict(per_layer(str(k), v) for k, v in opt.items())
 
 
 class BaseMinkowski(UnwrappedUnetBasedModel):
@@ -147,12 +145,15 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
         return next(self.parameters()).device
 
     def weight_initialization(self):
-        for m in self.modules():
-            if isinstance(m, ME.MinkowskiConvolution):
-                ME.utils.kaiming_normal_(m.kernel, mode="fan_out", nonlinearity="relu")
-            if isinstance(m, ME.MinkowskiBatchNorm):
-                nn.init.constant_(m.bn.weight, 1)
-                nn.init.constant_(m.bn.bias, 0)
+        """kaiming-normal (fan_out, relu) on the kernels of MinkowskiConvolution layers -- NOT the transposed ones, which
+        keep ME's default uniform init, exactly as applications/minkowski.py:104-111 tests the class -- and BN (1, 0)."""
+        convs = [m for m in self.modules() if isinstance(m, ME.MinkowskiConvolution)]
+        norms = [m for m in self.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
+        for conv in convs:
+            ME.utils.kaiming_normal_(conv.kernel, mode="fan_out", nonlinearity="relu")
+        for bn in norms:
+            nn.init.ones_(bn.bn.weight)
+            nn.init.zeros_(bn.bn.bias)
 
     def _set_input(self, data):
         dev = self.device

@@ -78,8 +78,10 @@ def resolve(obj, constants):
         if resolve(obj[k], constants) and isinstance(obj[k], str):
             try:
                 val = eval(obj[k], dict(constants))
-                # omegaconf refuses non-primitive values (e.g. the builtin `max` for aggr: "max"): keep the string
-                if isinstance(val, (int, float, bool, list, tuple, str)):
+                # omegaconf refuses non-primitive values (e.g. the builtin `max` for aggr: "max"): keep the string.
+                # None IS assigned ("scorer_type: None" in area4_ablation_14/19.yaml must become Python None,
+                # model_definition_resolver.py:44-48)
+                if val is None or isinstance(val, (int, float, bool, list, tuple, str)):
                     obj[k] = val
             except NameError:
                 pass

@@ -475,8 +475,8 @@ extern "C" size_t pp_group_by_key_workspace(int64_t n) {
 }
 
 extern "C" int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n, int32_t n_groups, int32_t* offsets,
-                               int64_t* out, int32_t* total, void* workspace, size_t workspace_bytes,
-                               pp_stream_t stream) {
+                               int64_t* out, int32_t* total, int32_t* n_out_of_range, void* workspace,
+                               size_t workspace_bytes, pp_stream_t stream) {
   PP_REQUIRE(offsets && total && n_groups >= 0, "pp_group_by_key: bad arguments");
   PP_REQUIRE(n_groups <= n + 1 || n_groups < (1 << 30), "pp_group_by_key: n_groups too large");
   if (workspace_bytes < pp_group_by_key_workspace(std::max<int64_t>(n, n_groups))) return PP_ERR_WORKSPACE;
@@ -615,7 +615,8 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks(M)), dim3(256), 0, s, pushed, 0x7FFFFFFF, M);
   PP_LAUNCH_CHECK();
   // fixpoint
-  for (int round = 0; round < 4096; ++round) {
+  bool converged = false;
+  for (int round = 0; round < 4096 && !converged; ++round) {
     PP_HIP(hipMemsetAsync(misc + 2, 0, sizeof(int32_t), s));
     for (int it = 0; it < 4; ++it)
       hipLaunchKernelGGL(k_rg_propagate, dim3(mb), dim3(256), 0, s, list, deg, spos, L, pushed, M, misc + 2);
@@ -626,7 +627,11 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
       pp_set_error("pp_region_grow: %d batch ids outside [0,2^23)", h[0]);
       return PP_ERR_RANGE;
     }
-    if (!h[1]) break;
+    converged = !h[1];
+  }
+  if (!converged) {  // never continue on labels that are not the fixpoint: the clusters would be silently wrong
+    pp_set_error("pp_region_grow: label propagation did not converge in 4096 x 4 rounds (%lld selected points)", (long long)M);
+    return PP_ERR_INVALID;
   }
   // clusters: valid roots ordered by (class, root index)
   PP_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)M, s));
@@ -646,7 +651,8 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   PP_HIP(hipStreamSynchronize(s));
   const int32_t nC = h[0];
   PP_HIP(hipMemcpyAsync(counts, misc + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  rc = pp_group_by_key(pc_local, sel64, M, nC, cluster_offsets, cluster_points, counts + 1, ar.cur(), ar.left(), stream);
+  rc = pp_group_by_key(pc_local, sel64, M, nC, cluster_offsets, cluster_points, counts + 1, nullptr, ar.cur(), ar.left(),
+                        stream);
   return rc;
 }
 

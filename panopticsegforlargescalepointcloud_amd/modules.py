@@ -17,13 +17,11 @@ from . import ops
 
 
 class Seq(nn.Sequential):
-    def __init__(self):
-        super().__init__()
-        self._num_modules = 0
+    """nn.Sequential with a chaining `append`: children are named "0", "1", ... in insertion order, which fixes the
+    state_dict keys of SURVEY.md App. A (base_modules.py:156-164)."""
 
     def append(self, module):
-        self.add_module(str(self._num_modules), module)
-        self._num_modules += 1
+        self.add_module(str(len(self)), module)
         return self
 
 

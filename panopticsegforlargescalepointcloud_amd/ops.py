@@ -699,6 +699,7 @@ def cylinder_tiles(pos, centres_xy, radius):
     _lib.check(lib.pp_cylinder_pairs(_ptr(pos), n, _ptr(cen), nc, float(radius), _ptr(pp), _ptr(pc), total, _ptr(n_pairs), _ptr(ws),
                                      wsb, _stream()), "pp_cylinder_pairs")
     offs, out, tot = group_by_key(pc[:total].contiguous(), nc, ids=pp[:total].contiguous())
+    group_by_key_check(tot)
     return ClusterCSR(offs, out[:total], nc)
 
 
@@ -760,12 +761,21 @@ def group_by_key(key, n_groups, ids=None):
     ids = _need(ids, torch.int64, "ids")
     offs = torch.empty(n_groups + 1, dtype=torch.int32, device=dev)
     out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    total = torch.zeros(2, dtype=torch.int32, device=dev)  # [kept, keys >= n_groups (caller error, see group_by_key_check)]
     wsb = lib.pp_group_by_key_workspace(max(n, n_groups))
     ws = _ws(wsb, dev)
-    _lib.check(lib.pp_group_by_key(_ptr(key), _ptr(ids), n, int(n_groups), _ptr(offs), _ptr(out), _ptr(total), _ptr(ws),
-                                   wsb, _stream()), "pp_group_by_key")
+    _lib.check(lib.pp_group_by_key(_ptr(key), _ptr(ids), n, int(n_groups), _ptr(offs), _ptr(out), _ptr(total),
+                                   _ptr(total[1:]), _ptr(ws), wsb, _stream()), "pp_group_by_key")
     return offs, out, total
+
+
+def group_by_key_check(total):
+    """`total` as returned by group_by_key, read on the host (one synchronisation, callers that need the count anyway):
+    -> number of grouped entries; raises if any key was >= n_groups."""
+    kept, bad = total.tolist()
+    if bad:
+        raise _lib.PanopticHipError("group_by_key: %d keys outside [0, n_groups)" % bad)
+    return kept
 
 
 def segment_reduce(src, index, n_seg, reduce, want_arg=False, check=True):

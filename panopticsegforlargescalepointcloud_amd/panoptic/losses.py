@@ -10,16 +10,16 @@ from ..torch_scatter import gather, scatter
 
 
 def offset_loss(pred_offsets, gt_offsets, total_instance_points):
-    pt_diff = pred_offsets - gt_offsets
-    pt_dist = torch.sum(torch.abs(pt_diff), dim=-1)
-    offset_norm_loss = torch.sum(pt_dist) / (total_instance_points + 1e-6)
-    gt_norm = torch.norm(gt_offsets, p=2, dim=1)
-    gt_unit = gt_offsets / (gt_norm.unsqueeze(-1) + 1e-8)
-    pred_norm = torch.norm(pred_offsets, p=2, dim=1)
-    pred_unit = pred_offsets / (pred_norm.unsqueeze(-1) + 1e-8)
-    direction_diff = -(gt_unit * pred_unit).sum(-1)
-    offset_dir_loss = torch.sum(direction_diff) / (total_instance_points + 1e-6)
-    return {"offset_norm_loss": offset_norm_loss, "offset_dir_loss": offset_dir_loss}
+    """L1 regression + direction (negative cosine) terms over the instance points, both normalised by the number of
+    instance points (panoptic_losses.py:7-23)."""
+    denom = total_instance_points + 1e-6
+    l1 = (pred_offsets - gt_offsets).abs().sum(-1)
+
+    def unit(v):
+        return v / (v.norm(p=2, dim=1, keepdim=True) + 1e-8)
+
+    cosine = (unit(gt_offsets) * unit(pred_offsets)).sum(-1)
+    return {"offset_norm_loss": l1.sum() / denom, "offset_dir_loss": (-cosine).sum() / denom}
 
 
 def instance_ious(predicted_clusters, cluster_scores, instance_labels, batch, mask_scores_sigmoid=None,
@@ -33,15 +33,16 @@ def instance_ious(predicted_clusters, cluster_scores, instance_labels, batch, ma
 
 def instance_iou_loss(ious, predicted_clusters, cluster_scores, instance_labels, batch, min_iou_threshold=0.25,
                       max_iou_threshold=0.75):
-    assert len(predicted_clusters) == cluster_scores.shape[0]
-    ious = ious.max(1)[0]
-    lower_mask = ious < min_iou_threshold
-    higher_mask = ious > max_iou_threshold
-    middle_mask = torch.logical_and(torch.logical_not(lower_mask), torch.logical_not(higher_mask))
-    shat = torch.zeros_like(ious)
-    shat[higher_mask] = 1
-    shat[middle_mask] = (ious[middle_mask] - min_iou_threshold) / (max_iou_threshold - min_iou_threshold)
-    return torch.nn.functional.binary_cross_entropy(cluster_scores, shat)
+    """BCE of the proposal scores against a soft target: 0 below min_iou, 1 above max_iou, linear in between, from the
+    best IoU of each proposal with any ground-truth instance (panoptic_losses.py:92-114)."""
+    n_prop = predicted_clusters.n if hasattr(predicted_clusters, "n") else len(predicted_clusters)
+    assert n_prop == cluster_scores.shape[0]
+    best = ious.max(1)[0]
+    ramp = (best - min_iou_threshold) / (max_iou_threshold - min_iou_threshold)
+    # strict comparisons as in the reference: exactly min_iou -> ramp value 0, exactly max_iou -> ramp value 1
+    target = torch.where(best > max_iou_threshold, torch.ones_like(best),
+                         torch.where(best < min_iou_threshold, torch.zeros_like(best), ramp))
+    return torch.nn.functional.binary_cross_entropy(cluster_scores, target)
 
 
 def discriminative_loss_single(prediction, correct_label, feature_dim, delta_v=0.5, delta_d=1.5, param_var=1.0,

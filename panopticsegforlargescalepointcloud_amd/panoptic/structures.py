@@ -12,16 +12,18 @@ from .. import ops
 
 
 def non_max_suppression(ious, scores, threshold):
-    ixs = scores.argsort()[::-1]
-    pick = []
-    while len(ixs) > 0:
-        i = ixs[0]
-        pick.append(i)
-        iou = ious[i, ixs[1:]]
-        remove_ixs = np.where(iou > threshold)[0] + 1
-        ixs = np.delete(ixs, remove_ixs)
-        ixs = np.delete(ixs, 0)
-    return pick
+    """Greedy NMS over a dense IoU matrix (host form of structure_3heads.py:6-16, kept for callers that hold the dense
+    matrix; the model path uses the device kernels behind ops.nms_paint).  Visits proposals by descending score
+    (`argsort()[::-1]`, i.e. the reference's tie order) and drops everything a kept proposal overlaps by > threshold."""
+    order = np.argsort(scores)[::-1]
+    alive = np.ones(len(order), dtype=bool)
+    kept = []
+    for i in order:
+        if alive[i]:
+            kept.append(i)
+            alive &= ~(ious[i] > threshold)
+            alive[i] = False
+    return kept
 
 
 class PanopticResults(NamedTuple):

@@ -52,7 +52,7 @@ def cluster_csr(x, label_batch, local_ind, min_points_exclusive):
     key = torch.where(labels >= 0, labels + base[sample_of_point].to(torch.int32), labels)
     n_groups = int(ncl.sum().item())
     goffs, out, total = ops.group_by_key(key.contiguous(), n_groups, ids=local_ind.contiguous())
-    return ops.ClusterCSR(goffs, out[: int(total.item())], n_groups)
+    return ops.ClusterCSR(goffs, out[: ops.group_by_key_check(total)], n_groups)
 
 
 def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, type):

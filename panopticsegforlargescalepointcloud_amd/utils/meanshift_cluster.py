@@ -46,9 +46,9 @@ def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_po
     sizes = goffs[1:] - goffs[:-1]
     keep = sizes > 0
     if bool(keep.all()):
-        return ops.ClusterCSR(goffs, out[: int(total.item())], n_groups)
+        return ops.ClusterCSR(goffs, out[: ops.group_by_key_check(total)], n_groups)
     new_offs = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), torch.cumsum(sizes[keep], 0).to(torch.int32)])
-    return ops.ClusterCSR(new_offs, out[: int(total.item())], int(keep.sum().item()))
+    return ops.ClusterCSR(new_offs, out[: ops.group_by_key_check(total)], int(keep.sum().item()))
 
 
 def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, type, bandwidth):

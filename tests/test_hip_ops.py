@@ -476,7 +476,11 @@ def test_group_by_key_and_segment_reduce(ops, oracle):
     woffs, wout = oracle.group_by_key(key, 50, ids)
     offs, out, total = ops.group_by_key(dev(key), 50, dev(ids))
     assert np.array_equal(offs.cpu().numpy(), woffs)
-    assert np.array_equal(out[: int(total)].cpu().numpy(), wout)
+    assert np.array_equal(out[: ops.group_by_key_check(total)].cpu().numpy(), wout)
+    bad = key.copy()
+    bad[3] = 50  # a key >= n_groups is a caller error and must be reported, not dropped silently
+    with pytest.raises(Exception, match="outside"):
+        ops.group_by_key_check(ops.group_by_key(dev(bad), 50, dev(ids))[2])
     src = rng.normal(size=(10000, 16)).astype(np.float32)
     index = rng.integers(0, 300, size=10000)
     index[index == 5] = 6

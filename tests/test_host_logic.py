@@ -51,6 +51,50 @@ def test_model_from_reference_yaml_schema(path):
     assert abs(float(k.std()) - (2.0 / (27 * 64)) ** 0.5) < 2e-3
 
 
+REF_DIR = "/root/reference/conf/models/panoptic"
+# (file, class name, heads, cluster_type, scorer_type, use_score_net) -- SURVEY.md App. B, README.md:185
+SETTINGS = [("area4_ablation_19.yaml", "PointGroupEmbed", ("Semantic", "Embed"), 7, None, False),
+            ("area4_ablation_14.yaml", "PointGroup", ("Semantic", "Offset"), 1, None, False),
+            ("area4_ablation_15.yaml", "PointGroup", ("Semantic", "Offset"), 2, "unet", True),
+            ("area4_ablation_3heads_5.yaml", "PointGroup3heads", ("Semantic", "Offset", "Embed"), 5, "unet", True),
+            ("area4_ablation_3heads_6.yaml", "PointGroup3heads", ("Semantic", "Offset", "Embed"), 6, "unet", True)]
+
+
+def _check_setting(cfg, cls_name, heads, cluster_type, scorer_type, use_score_net):
+    from panopticsegforlargescalepointcloud_amd.panoptic import instantiate_model
+    torch.manual_seed(0)
+    m = instantiate_model(cfg, DS)
+    assert type(m).__name__ == cls_name and m.HEADS == heads
+    assert cfg.cluster_type == cluster_type and cfg.use_score_net is use_score_net
+    # "scorer_type: None" must resolve to Python None (model_definition_resolver.py:44-48), else _compute_score would
+    # look for a scorer called "None" instead of using the semantic-certainty score
+    assert cfg.scorer_type == scorer_type and m._scorer_type == scorer_type
+    assert cluster_type in m._cluster_fns()
+    sd = m.state_dict()
+    conv = sum(v.numel() for k, v in sd.items() if k.startswith("Backbone.") and k.endswith(".kernel"))
+    assert conv == 10403520
+    for h in ("Offset", "Embed"):
+        assert any(k.startswith(h + ".") for k in sd) == (h in heads)
+    assert abs(cfg.cluster_radius_search - 1.5 * 0.05) < 1e-9 and cfg.prepare_epoch == 30
+
+
+@pytest.mark.parametrize("fname,cls_name,heads,cluster_type,scorer_type,use_score_net", SETTINGS)
+def test_all_published_reference_yamls_load(fname, cls_name, heads, cluster_type, scorer_type, use_score_net):
+    from panopticsegforlargescalepointcloud_amd.config import load_model_config
+    path = os.path.join(REF_DIR, fname)
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present on this box")
+    cfg = load_model_config(path, "PointGroup-PAPER", data={"grid_size": 0.05})
+    _check_setting(cfg, cls_name, heads, cluster_type, scorer_type, use_score_net)
+
+
+@pytest.mark.parametrize("name,spec", list(zip(["setting-I", "setting-II", "setting-III", "setting-IV", "setting-V"], SETTINGS)))
+def test_build_owned_settings_yaml(name, spec):
+    from panopticsegforlargescalepointcloud_amd.config import load_model_config
+    cfg = load_model_config(os.path.join(ROOT, "conf", "panoptic_settings.yaml"), name, data={"grid_size": 0.05})
+    _check_setting(cfg, *spec[1:])
+
+
 def test_config_resolver_keeps_non_expressions():
     from panopticsegforlargescalepointcloud_amd.config import resolve
     cfg = {"a": "2*in_feat", "b": "max", "c": "ResNetDown", "d": ["FEAT", "in_feat"], "e": "1.5 * 0.05"}
