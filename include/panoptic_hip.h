@@ -84,9 +84,10 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
 
 /* Derived maps (no hash probes).  pp_kernel_map_transpose: out_map[k][in_map[k][o]] = o, i.e. the map of the
  * transposed strided convolution (coarse -> fine, ME's "swapped" kernel map, api_modules.py:288-311) from the
- * strided convolution's map; out_map is int32 [K][n_in], filled with -1 first. */
-int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
-                            pp_stream_t stream);
+ * strided convolution's map; out_map is int32 [K][n_in], filled with -1 first.  in_order (nullable): in_map is
+ * slot-ordered (pp_map_permute) and slot o stands for row in_order[o]. */
+int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, const int32_t* in_order,
+                            int32_t* out_map, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K1b/K3c  block index of a level + kernel maps through it (what the coordinate manager uses; the
@@ -124,13 +125,25 @@ int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* b
                      int64_t* n_pairs /*device, may be NULL*/, uint32_t* mask_out /*[n_out] occupied offsets, may be NULL*/,
                      pp_stream_t stream);
 
-/* Tile schedule of a level: order[p] = p-th row to process.  Inside windows of `window` consecutive rows the rows are
- * grouped by coordinate parity, then by their same-level neighbour mask (mask_out of pp_kernel_map_bi), so that the
- * 16 rows of an MFMA tile occupy (nearly) the same kernel offsets.  pp_spconv_fwd takes it as row_order; outputs are
- * identical with and without it. */
-size_t pp_tile_order_workspace(int64_t n);
-int pp_tile_order(const int32_t* coords, const uint32_t* mask, int64_t n, int32_t unit, int32_t window, int32_t* order,
-                  void* workspace, size_t workspace_bytes, pp_stream_t stream);
+/* Tile scheduling at map-build time (csrc/pp_maporder.hip).  The convolution executes a kernel offset for a 16-row
+ * MFMA tile as soon as one of its rows has that neighbour, so every map gets a SLOT ORDER in which the rows of a tile
+ * want the same offsets: inside windows of pp_map_window() consecutive rows, rows are sorted by (batch element, neighbour
+ * mask with the rarest offset classes most significant, row).
+ *   pp_map_mask      mask[o] = bit k set <=> nbr[k][o] >= 0            (pp_kernel_map_bi also emits it as mask_out)
+ *   pp_map_order     order[s] = row taking slot s; coords (nullable, [n,4]) supplies the batch element
+ *   pp_map_permute   out[k][s] = T(nbr[k][order[s]]), T(v) = v < 0 ? -1 : (translate ? translate[v] : v); order NULL = identity;
+ *                    window = the pp_map_window() `order` was built with (LDS-staged form) or 0 (any order)
+ *   pp_level_permute coords_out[s] = coords[order[s]], inverse[order[s]] = s   (renumbering of a level: same-level maps
+ *                    are stored in the level's own row order, so their convolutions need no indirection)
+ * Cross-level maps stay slot-major and pp_spconv_fwd takes `order` as row_order.  Results never depend on the order. */
+int32_t pp_map_window(void);
+int pp_map_set_window(int32_t window /*1024 | 2048 | 4096 | 8192 (default)*/);
+int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, pp_stream_t stream);
+int pp_map_order(const uint32_t* mask, const int32_t* coords, int64_t n, int32_t* order, pp_stream_t stream);
+int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
+                   int32_t window, int32_t* out, pp_stream_t stream);
+int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,
+                     pp_stream_t stream);
 
 /* Internal row order of a coordinate level, batch-major: perm[p] = input row holding the p-th smallest key.
  * unit = tensor stride of the level (coordinates are multiples of it).
@@ -165,12 +178,22 @@ int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin,
 int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in /*rows of in0 (and in1)*/,
                   const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
                   const float* shift, int32_t relu, const float* residual,
-                  const int32_t* row_order /*optional tile schedule (pp_tile_order); NULL = row order*/, float* out,
+                  const int32_t* row_order /*slot order of a cross-level map (pp_map_order): nbr is slot-major and slot s writes
+                                              row row_order[s]; NULL = slot s is row s*/, float* out,
                   pp_stream_t stream);
 /* bfloat16 compute variant (BASELINE.json configs[4], "bf16"): same arguments and fp32 tensors in memory; features and
  * weights are rounded to bfloat16 (nearest even) in registers, products accumulate in fp32 on
  * v_mfma_f32_16x16x16_bf16 -- torch.autocast(bfloat16) semantics for the convolution.  Needs cin % 16 == 0 per source,
  * K <= 28 and < 4 GiB per source (PP_ERR_INVALID otherwise; callers keep the fp32 entry for those layers). */
+/* Explicit variants of the pipelined kernel (parity tests, A/B measurements): rows_per_wave in {0, 32, 64} (16-row MFMA
+ * tiles per wave x 16), pipeline in {0, 1, 3} (1: loads of step n+1 issued before the MFMAs of step n; 3: additionally
+ * the LDS read of the step after that), split_k in {0, 1, 2, 4, 8} (kernel offsets split over that many waves, partial
+ * sums added in a fixed order; needs pp_spconv_set_scratch); 0 = the per-shape choice pp_spconv_fwd makes.  bf16 != 0
+ * selects the bfloat16 compute variant.  PP_ERR_INVALID for shapes the pipelined kernel does not take. */
+int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
+                     const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale, const float* shift,
+                     int32_t relu, const float* residual, const int32_t* row_order, float* out, int32_t bf16,
+                     int32_t rows_per_wave, int32_t pipeline, int32_t split_k, pp_stream_t stream);
 /* Optional scratch for small launches (fewer waves than SIMD slots): with a buffer registered here pp_spconv_fwd[_bf16]
  * splits the kernel offsets of such a launch over up to 8 waves per row tile and adds the partial sums in a fixed order
  * (results stay reproducible; they differ from the unsplit sum only by fp32 summation order).  The buffer belongs to
@@ -181,23 +204,6 @@ int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c
                        const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                        const float* scale, const float* shift, int32_t relu, const float* residual,
                        const int32_t* row_order, float* out, pp_stream_t stream);
-
-/* K3b/K4b  block-compacted rulebook and the convolution on it (the fast path for 3x3x3 kernels with Cin % 16 == 0).
- * The kernel map is regrouped per block of 64 consecutive output rows and per offset into compact lists of
- * (input row, local output row) pairs padded to 16, so MFMA tiles hold only ACTIVE pairs (ME's "kernel map" in
- * in/out-pair form, regrouped for an output-stationary kernel; same reference call sites as K3/K4).
- *   rb_off int32 [blocks*28 + 1] (entry offsets per block and offset; total[0] = #entries), rb_in / rb_out int32 [total].
- * pp_spconv_fwd_rb has pp_spconv_fwd's contract (same packed weights, epilogue, fused second source). */
-int64_t pp_rulebook_blocks(int64_t n_out);
-size_t pp_rulebook_workspace(int64_t n_out);
-int pp_rulebook_offsets(const int32_t* nbr /*[27,n_out]*/, int64_t n_out, int32_t* rb_off, int32_t* total,
-                        void* workspace, size_t workspace_bytes, pp_stream_t stream);
-int pp_rulebook_fill(const int32_t* nbr, int64_t n_out, const int32_t* rb_off, int32_t* rb_in, int32_t* rb_out,
-                     pp_stream_t stream);
-int pp_spconv_fwd_rb(const float* in0, int32_t c0, const float* in1, int32_t c1, const float* packed_weight,
-                     const int32_t* rb_off, const int32_t* rb_in, const int32_t* rb_out, int64_t n_out, int32_t cout,
-                     const float* scale, const float* shift, int32_t relu, const float* residual, float* out,
-                     pp_stream_t stream);
 
 /* K5  weight gradient             replaces: ME ConvolutionBackward (dW part), reached from
  *                                 loss.backward(), torch_points3d/models/panoptic/PointGroup3heads.py:636-639
@@ -366,6 +372,37 @@ size_t pp_proposal_intersections_workspace(int64_t total_points, int64_t n_point
 int pp_proposal_intersections(const int32_t* prop_offsets, const int64_t* prop_points, int32_t n_prop,
                               int64_t n_points, int32_t* inter, void* workspace, size_t workspace_bytes,
                               pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K14b proposal overlaps, NMS and painting on the device (csrc/pp_nms.hip)
+ *                                 replaces: PanopticResults.get_instances + non_max_suppression,
+ *                                 models/panoptic/structure_3heads.py:6-71, and get_cur_ins_pre_label,
+ *                                 metrics/panoptic_tracker_pointgroup_npm3d.py:326-337
+ * pp_proposal_pairs: every pair (a < b) of proposals sharing at least one point, with |a n b|, from the point -> proposal
+ *   incidence (sparse form of mask @ mask^T).  total_entries = prop_offsets[n_prop].  pair_* have room for
+ *   pp_proposal_pairs_capacity(n_prop) triples; n_pairs (device int32) receives their number, in no particular order.
+ *   prop_of_entry int32 [total_entries] = proposal of every CSR entry.  info int32[4] (device): [0] points belonging to
+ *   more than 8 proposals, [1] pair-table overflow, [2] point ids outside [0, n_points), [3] (pp_nms_paint) proposals
+ *   whose batch element is outside [0, n_groups) -- all must be 0.
+ * pp_nms_paint: per batch element (batch[first point of the proposal]; NULL = one group) greedy NMS by descending score
+ *   over the pairs with IoU > nms_threshold (float32), then size > min_cluster_points and score > min_score; the kept
+ *   proposals are ranked by ascending score and painted: labels[p] = largest rank covering p, -1 = none (ids restart at 0
+ *   per batch element).  counts[g] = instances of group g, rank[q] = rank or -1.  scores NULL (no ScoreNet): every proposal
+ *   is an instance, ranked in proposal order.  Equal scores: visited in descending proposal id (numpy's argsort()[::-1]
+ *   on small arrays); the reference's introsort leaves larger tie groups implementation-defined.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t pp_proposal_pairs_capacity(int32_t n_prop);
+size_t pp_proposal_pairs_workspace(int64_t total_entries, int64_t n_points, int32_t n_prop);
+int pp_proposal_pairs(const int32_t* prop_offsets, const int64_t* prop_points, int32_t n_prop, int64_t total_entries,
+                      int64_t n_points, int32_t* prop_of_entry, int32_t* pair_a, int32_t* pair_b, int32_t* pair_inter,
+                      int32_t* n_pairs, int32_t* info, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+size_t pp_nms_paint_workspace(int32_t n_prop, int32_t n_groups, int64_t pair_capacity);
+int pp_nms_paint(const int32_t* prop_offsets, const int64_t* prop_points, int32_t n_prop, int64_t total_entries,
+                 int64_t n_points, const int32_t* prop_of_entry, const int32_t* pair_a, const int32_t* pair_b,
+                 const int32_t* pair_inter, const int32_t* n_pairs, int64_t pair_capacity, const int64_t* batch,
+                 int32_t n_groups, const float* scores, float nms_threshold, int32_t min_cluster_points, float min_score,
+                 int32_t* labels, int32_t* counts, int32_t* rank, int32_t* info, void* workspace, size_t workspace_bytes,
+                 pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row gather                      replaces: features[perm] / features[inverse] around ME.SparseTensor (.F in caller order,

@@ -36,6 +36,9 @@ class Maps:
         return self.maps[key]
 
 
+CONV_STATS = {"flops": 0.0, "seconds": 0.0}  # accumulated by every convolution call (bench.py cpu_baseline reads it)
+
+
 def _fold(sd, p):
     w, b = _np(sd[p + ".bn.weight"]), _np(sd[p + ".bn.bias"])
     m, v = _np(sd[p + ".bn.running_mean"]), _np(sd[p + ".bn.running_var"])
@@ -53,7 +56,12 @@ def _conv_bn(sd, pconv, pbn, maps, x, ts_in, stride, transposed, relu, residual=
         nbr = maps.map(ts_in, ts_out, sign)
     n_out = len(maps.levels[ts_out])
     scale, shift = _fold(sd, pbn)
+    t0 = time.perf_counter()
     y = O.spconv_fwd(x, W, nbr, n_out, in1=in1, scale=scale, shift=shift, relu=relu, residual=residual)
+    # bookkeeping for the CPU baseline's GFLOP/s (2 flops per pair, input and output channel)
+    pairs = n_out if nbr is None else int((nbr >= 0).sum())
+    CONV_STATS["flops"] += 2.0 * pairs * W.shape[-2] * W.shape[-1]
+    CONV_STATS["seconds"] += time.perf_counter() - t0
     return y, ts_out
 
 
@@ -100,7 +108,11 @@ def _head(sd, p, x, log_softmax=False):
 
 
 def nms(ious, scores, threshold):
-    ixs = scores.argsort()[::-1]
+    """non_max_suppression of structure_3heads.py:6-16.  The reference orders with `scores.argsort()[::-1]` (numpy
+    introsort: the order of EQUAL scores is implementation-defined beyond 16 elements); the tie rule is pinned here to the
+    stable sort reversed -- descending score, equal scores by descending index -- which is what numpy's insertion-sort
+    path gives, and what csrc/pp_nms.hip implements."""
+    ixs = np.argsort(scores, kind="stable")[::-1]
     pick = []
     while len(ixs) > 0:
         i = ixs[0]

@@ -24,25 +24,18 @@ from .. import ops
 from . import utils  # noqa: F401
 
 
-# Kernel choice for 3x3x3 convolutions with Cin % 16 == 0 (PP_CONV = auto | dense | rb):
-#   dense : output-stationary dense-offset kernel (csrc/pp_spconv2.hip, v3) with per-16-row-tile offset skipping;
-#   rb    : block-compacted rulebook kernel (csrc/pp_spconv_rb.hip).
-# auto = dense everywhere.  The rulebook kernel won on sparse maps only until the dense kernel lost its vector-ALU
-# overhead and the rows became parity-grouped (transposed stride-2 maps: useful MFMA work 0.14 -> 0.4-0.74); measured
-# end to end in profiles/r01_h_*.  PP_RB_DENSITY > 0 re-enables the rulebook below that map density (A/B runs).
-CONV_MODE = os.environ.get("PP_CONV", "auto")
-USE_RULEBOOK = CONV_MODE != "dense"
-RB_DENSITY = float(os.environ.get("PP_RB_DENSITY", "0.0"))
 # internal row order of every coordinate level: parity-grouped blocks of 2^ORDER_BLOCK_BITS voxels (0 = plain Z-order,
 # -1 = caller order with row-level hash tables)
 ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
 # build coarser levels from the finer level's block index (PP_COARSEN=0: hash + sort path, for A/B runs)
 COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
-# tile schedule window (rows): processing order of a level's rows = (window, parity, same-level neighbour mask); 0 = off.
-# OFF by default: it raises the useful share of executed MFMA tiles (0.31 -> 0.43 at the finest level) but the extra
-# indirection (scattered index loads / output stores, one radix sort per level) costs more than it saves end to end
-# (242 -> 251..257 ms per step for windows of 64..65536 rows, profiles/r01_i_notes.md).
-TILE_WINDOW = int(os.environ.get("PP_TILE_WINDOW", "0"))
+# tile scheduling at map-build time (csrc/pp_maporder.hip): every kernel map gets a slot order in which the 16 rows of
+# an MFMA tile want the same offsets; a level's physical row order is the slot order of its same-level map, cross-level
+# maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
+MAP_ORDER = os.environ.get("PP_MAP_ORDER", "1") != "0"
+MAP_ORDER_MIN_ROWS = int(os.environ.get("PP_MAP_ORDER_MIN_ROWS", "50000"))  # smaller levels gain nothing from it
+if os.environ.get("PP_MAP_WINDOW"):  # rows per sort window (1024 | 2048 | 4096 | 8192), A/B runs
+    ops._lib.check(ops._lib.load().pp_map_set_window(int(os.environ["PP_MAP_WINDOW"])), "pp_map_set_window")
 # compute dtype of the sparse convolutions: "fp32" (the reference's; parity runs) or "bf16" (BASELINE.json configs[4]):
 # operands rounded to bfloat16 in registers, fp32 accumulation, fp32 tensors in memory -- what torch.autocast(bfloat16)
 # does to a convolution.  `conv_autocast()` switches it for a region of code.
@@ -77,31 +70,33 @@ class conv_autocast:
         return False
 
 
-def _want_rulebook(conv, x, ts_out, cin, sign):
-    if CONV_MODE == "rb":
-        return True
-    if CONV_MODE == "dense":
-        return False
-    if RB_DENSITY <= 0.0:
-        return False
-    if conv.TRANSPOSED and ts_out != x.tensor_stride:
-        return True
-    return cin >= 32 and x.coordinate_manager.map_density(x.tensor_stride, ts_out, conv.kernel_size, sign) < RB_DENSITY
-
-
 # ------------------------------------------------------------------------------------------------
 # coordinate manager
 # ------------------------------------------------------------------------------------------------
 class _Level:
-    """coords int32 [n,4] in internal row order; `index` (ops.BlockIndex) when the rows are order-key sorted, else a
-    row-level hash `table` (PP_ORDER_BLOCK=-1: caller order, hash probing -- the first design, kept for A/B runs)."""
-    __slots__ = ("coords", "table", "index", "n")
+    """One coordinate level.  `coords` int32 [n,4] in the level's PHYSICAL row order (the order of every feature matrix
+    of this level).  `index` (ops.BlockIndex) is built over the block / Z-order the rows are created in; `phys_of`
+    (int32 [n], None = identity) maps a row of that order to its physical row -- with map ordering on, the physical
+    order is the slot order of the level's same-level kernel map, kept in `same_map`.  `table`: row-level hash
+    (PP_ORDER_BLOCK=-1: caller order, hash probing -- the first design, kept for A/B runs)."""
+    __slots__ = ("coords", "table", "index", "n", "phys_of", "same_map")
 
-    def __init__(self, coords, table=None, index=None):
+    def __init__(self, coords, table=None, index=None, phys_of=None, same_map=None):
         self.coords = coords
         self.table = table
         self.index = index
         self.n = coords.shape[0]
+        self.phys_of = phys_of
+        self.same_map = same_map
+
+
+def _order_level(coords_m, index, ts):
+    """physical order of a level from its same-level map: (coords_p, order, phys_of, same_map in physical ids)"""
+    nbr_m = ops.kernel_map_bi(coords_m, index, 3, ts, 1, want_mask=True)
+    order = ops.map_order(nbr_m.pp_mask, coords_m)
+    coords_p, phys_of = ops.level_permute(coords_m, order)
+    same = ops.map_permute(nbr_m, order, translate=phys_of)
+    return coords_p, order, phys_of, same
 
 
 class _PermuteRowsFn(torch.autograd.Function):
@@ -157,10 +152,15 @@ class CoordinateManager:
         if self.sorted:
             if coords.shape[0] > 1:
                 self.perm, coords = ops.morton_order(coords, 1, ORDER_BLOCK_BITS, want_sorted=True)
-                self.inv_perm = torch.empty_like(self.perm)
-                self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
             index, ndup = ops.block_index_build(coords, 1, ORDER_BLOCK_BITS)
             level = _Level(coords, index=index)
+            if MAP_ORDER and ndup == 0 and coords.shape[0] >= MAP_ORDER_MIN_ROWS:
+                coords_p, order, phys_of, same = _order_level(coords, index, 1)
+                level = _Level(coords_p, index=index, phys_of=phys_of, same_map=same)
+                self.perm = self.perm[order.long()]
+            if self.perm is not None:
+                self.inv_perm = torch.empty_like(self.perm)
+                self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
         else:
             table, ndup = ops.hash_build(coords)
             level = _Level(coords, table=table)
@@ -169,9 +169,8 @@ class CoordinateManager:
                              "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
         self.levels = {1: level}
         self.maps = {}
-        self.tile_orders = {}
-        self.rulebooks = {}
-        self.densities = {}
+        if level.same_map is not None:
+            self.maps[(1, 1, 3, 1)] = level.same_map
         # prefetch support: one lock around level / map construction, an event per built item (the builder's stream
         # may not be the consumer's), an optional log of the requests (the plan replayed by the next forward)
         self._lock = threading.RLock()
@@ -220,31 +219,9 @@ class CoordinateManager:
                 err, self._worker_err = self._worker_err, None
                 raise err
 
-    def rulebook(self, ts_from, ts_to, ksize, sign):
-        key = (ts_from, ts_to, ksize, sign)
-        rb = self.rulebooks.get(key)
-        if rb is None:
-            rb = ops.rulebook_build(self.kernel_map(ts_from, ts_to, ksize, sign))
-            self.rulebooks[key] = rb
-        return rb
-
-    def map_density(self, ts_from, ts_to, ksize, sign):
-        """fraction of occupied entries of a kernel map (pairs / (K * n_out)); one reduction per map, cached."""
-        key = (ts_from, ts_to, ksize, sign)
-        d = self.densities.get(key)
-        if d is None:
-            m = self.kernel_map(ts_from, ts_to, ksize, sign)
-            d = float(ops._pairs_of(m).item()) / max(m.numel(), 1)
-            self.densities[key] = d
-        return d
-
     def level(self, ts):
         self._use(("level", ts))
         return self.levels[ts]
-
-    def tile_order(self, ts):
-        """processing order of the rows of level ts for the convolution kernels (None until its same-level map exists)"""
-        return self.tile_orders.get(ts)
 
     def to_internal(self, feats):
         return feats if self.perm is None else _permute_rows(feats, self.perm, self.inv_perm)
@@ -270,20 +247,25 @@ class CoordinateManager:
             if self.sorted and stride == 2 and ORDER_BLOCK_BITS == 4 and src.index is not None and COARSEN_FROM_INDEX:
                 # the coarse level is a bit permutation of the fine level's occupancy bitmaps: no hash, no sort
                 index, out = ops.block_index_coarsen(src.index, src.n)
-                self._built(("level", ts_out))  # event first: lock-free readers find the item only with its event
-                self.levels[ts_out] = _Level(out, index=index)
-                return ts_out
-            out, table, _ = ops.stride_coords(src.coords, ts_out)
-            if self.sorted:
-                # first-appearance order of the parents follows the fine level only roughly: sort the level itself
-                if out.shape[0] > 1:
-                    out = ops.morton_order(out, ts_out, ORDER_BLOCK_BITS, want_sorted=True)[1]
-                index, _ = ops.block_index_build(out, ts_out, ORDER_BLOCK_BITS)
-                self._built(("level", ts_out))
-                self.levels[ts_out] = _Level(out, index=index)
+                level = _Level(out, index=index)
             else:
-                self._built(("level", ts_out))
-                self.levels[ts_out] = _Level(out, table=table)
+                src_coords = src.coords
+                out, table, _ = ops.stride_coords(src_coords, ts_out)
+                if self.sorted:
+                    # first-appearance order of the parents follows the fine level only roughly: sort the level itself
+                    if out.shape[0] > 1:
+                        out = ops.morton_order(out, ts_out, ORDER_BLOCK_BITS, want_sorted=True)[1]
+                    index, _ = ops.block_index_build(out, ts_out, ORDER_BLOCK_BITS)
+                    level = _Level(out, index=index)
+                else:
+                    level = _Level(out, table=table)
+            if MAP_ORDER and level.index is not None and level.n >= MAP_ORDER_MIN_ROWS:
+                coords_p, _, phys_of, same = _order_level(level.coords, level.index, ts_out)
+                level = _Level(coords_p, index=level.index, phys_of=phys_of, same_map=same)
+                self._built((ts_out, ts_out, 3, 1))
+                self.maps[(ts_out, ts_out, 3, 1)] = same
+            self._built(("level", ts_out))  # event first: lock-free readers find the item only with its event
+            self.levels[ts_out] = level
         return ts_out
 
     def kernel_map(self, ts_from, ts_to, ksize, sign):
@@ -312,22 +294,33 @@ class CoordinateManager:
             rev = self.maps.get((ts_to, ts_from, ksize, -sign))
             if rev is not None:
                 self._use((ts_to, ts_from, ksize, -sign))
+            dst = self.levels[ts_to]
             if rev is not None and ts_from == ts_to:
                 m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
                 if hasattr(rev, "pp_pairs"):
                     m.pp_pairs = rev.pp_pairs
             elif rev is not None:
-                m = ops.kernel_map_transpose(rev, self.levels[ts_to].n)
+                # transposed strided map by scatter from the strided one; rows = physical rows of the finer level
+                m = ops.kernel_map_transpose(rev, dst.n, order=getattr(rev, "pp_order", None))
+                if MAP_ORDER and dst.n >= MAP_ORDER_MIN_ROWS:
+                    order = ops.map_order(ops.map_mask(m), dst.coords)
+                    m = ops.map_permute(m, order)
+                    m.pp_order = order
             else:
                 src = self.levels[ts_from]
                 if src.index is not None:
-                    want = ts_from == ts_to and TILE_WINDOW > 0 and ts_to not in self.tile_orders
-                    m = ops.kernel_map_bi(self.levels[ts_to].coords, src.index, ksize, min(ts_from, ts_to), sign, want_mask=want)
-                    if want:
-                        self.tile_orders[ts_to] = ops.tile_order(self.levels[ts_to].coords, m.pp_mask, ts_to, TILE_WINDOW)
+                    cross = ts_from != ts_to
+                    ordered = MAP_ORDER and cross and dst.n >= MAP_ORDER_MIN_ROWS
+                    m = ops.kernel_map_bi(dst.coords, src.index, ksize, min(ts_from, ts_to), sign, want_mask=ordered)
+                    if ordered:
+                        order = ops.map_order(m.pp_mask, dst.coords)
                         del m.pp_mask
+                        m = ops.map_permute(m, order, translate=src.phys_of)
+                        m.pp_order = order
+                    elif src.phys_of is not None:
+                        m = ops.map_permute(m, None, translate=src.phys_of)
                 else:
-                    m = ops.kernel_map(self.levels[ts_to].coords, src.table, ksize, min(ts_from, ts_to), sign)
+                    m = ops.kernel_map(dst.coords, src.table, ksize, min(ts_from, ts_to), sign)
             self._built(key)
             self.maps[key] = m
         return m
@@ -423,16 +416,17 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------------------
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, order_out=None, order_in=None, same_level=False, kflip=False):
+    def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, same_level=False, kflip=False):
         """same_level: nbr is the (+1) map of a stride-1 3x3x3 layer; its mirrored twin is nbr[K-1-k], so the transposed
-        layer (kflip) and every input gradient reuse nbr with the offsets of the packed weights reversed."""
+        layer (kflip) and every input gradient reuse nbr with the offsets of the packed weights reversed.  Cross-level
+        maps are slot-ordered (nbr.pp_order: slot -> output row)."""
         feats = feats.contiguous()
         packed = ops.pack_weight(kernel, kflip=kflip)
         cout = kernel.shape[-1]
         bf16 = _CONV_BF16[0]
-        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=order_out, bf16=bf16)
+        out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=getattr(nbr, "pp_order", None), bf16=bf16)
         ctx.save_for_backward(feats, kernel)
-        ctx.nbr, ctx.inv_fn, ctx.K, ctx.order_in, ctx.bf16 = nbr, inv_fn, K, order_in, bf16
+        ctx.nbr, ctx.inv_fn, ctx.K, ctx.bf16 = nbr, inv_fn, K, bf16
         ctx.same_level, ctx.kflip = same_level, kflip
         return out
 
@@ -448,14 +442,17 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 packed_t = ops.pack_weight(kernel, transpose=True)
                 inv = ctx.inv_fn()
-            din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K, row_order=ctx.order_in,
-                                 bf16=ctx.bf16)
+            din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
+                                 row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)
         if ctx.needs_input_grad[1]:
-            dw = ops.spconv_bwd_weight(feats, dout, ctx.nbr, ctx.K, bf16=ctx.bf16)
+            order = getattr(ctx.nbr, "pp_order", None)
+            # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
+            dout_s = dout if order is None else ops.gather_rows(dout, order.long())
+            dw = ops.spconv_bwd_weight(feats, dout_s, ctx.nbr, ctx.K, bf16=ctx.bf16)
             if ctx.kflip:
                 dw = dw.flip(0)
             dw = dw.reshape(kernel.shape)
-        return din, dw, None, None, None, None, None, None, None, None
+        return din, dw, None, None, None, None, None, None
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
@@ -582,13 +579,12 @@ class _ConvBase(nn.Module):
         n_out = cm.level(ts_out).n
         if not torch.is_grad_enabled():  # inference: cached packed weights, no autograd bookkeeping
             feats = ops.spconv_fwd(x.feats.contiguous(), self.packed(), nbr, n_out, self.out_channels, self.kernel_volume,
-                                   row_order=cm.tile_order(ts_out), bf16=_CONV_BF16[0])
+                                   row_order=getattr(nbr, "pp_order", None), bf16=_CONV_BF16[0])
             if self.bias is not None:
                 feats = feats + self.bias
             return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)
         same_level = self.stride == 1 and self.kernel_volume > 1
-        feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume, cm.tile_order(ts_out),
-                                    cm.tile_order(x.tensor_stride), same_level, self.mirrored)
+        feats = _SparseConvFn.apply(x.feats, self.kernel, nbr, inv_fn, n_out, self.kernel_volume, same_level, self.mirrored)
         if self.bias is not None:
             feats = feats + self.bias
         return SparseTensor(feats, coordinate_manager=x.coordinate_manager, tensor_stride=ts_out)
@@ -740,16 +736,9 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
         res = residual.feats
     c0 = x.feats.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
-    if (nbr is not None and conv.kernel_volume == 27 and c0 % 16 == 0 and c1 % 16 == 0 and n_out > 0
-            and _want_rulebook(conv, x, ts_out, c0 + c1, -1 if (conv.TRANSPOSED and not conv.mirrored) else 1)):
-        sign = -1 if (conv.TRANSPOSED and not conv.mirrored) else 1  # mirrored layers: forward map + reversed weights
-        rb = cm.rulebook(x.tensor_stride, ts_out, conv.kernel_size, sign)
-        feats = ops.spconv_fwd_rb(x.feats, conv.packed(), rb, conv.out_channels, in1=in1, scale=scale, shift=shift,
-                                  relu=relu, residual=res)
-    else:
-        feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
-                               scale=scale, shift=shift, relu=relu, residual=res, row_order=cm.tile_order(ts_out),
-                               bf16=_CONV_BF16[0])
+    feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
+                           scale=scale, shift=shift, relu=relu, residual=res, row_order=getattr(nbr, "pp_order", None),
+                           bf16=_CONV_BF16[0])
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

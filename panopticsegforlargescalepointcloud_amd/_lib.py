@@ -29,7 +29,7 @@ SIGNATURES = {
     "pp_stride_coords_workspace": (sz, [i64]),
     "pp_stride_coords": (C.c_int, [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, sz, vp, vp]),
     "pp_kernel_map": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
-    "pp_kernel_map_transpose": (C.c_int, [vp, i64, i32, i64, vp, vp]),
+    "pp_kernel_map_transpose": (C.c_int, [vp, i64, i32, i64, vp, vp, vp]),
     "pp_block_index_workspace": (sz, [i64]),
     "pp_block_index_capacity": (i64, [i64]),
     "pp_block_index_count": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),
@@ -37,8 +37,17 @@ SIGNATURES = {
     "pp_block_index_coarsen_workspace": (sz, [i64]),
     "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
-    "pp_tile_order_workspace": (sz, [i64]),
-    "pp_tile_order": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, sz, vp]),
+    "pp_proposal_pairs_capacity": (i64, [i32]),
+    "pp_proposal_pairs_workspace": (sz, [i64, i64, i32]),
+    "pp_proposal_pairs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_nms_paint_workspace": (sz, [i32, i32, i64]),
+    "pp_nms_paint": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, i64, vp, i32, vp, f32, i32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_map_window": (i32, []),
+    "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
+    "pp_map_order": (C.c_int, [vp, vp, i64, vp, vp]),
+    "pp_map_set_window": (C.c_int, [i32]),
+    "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i32, vp, vp]),
+    "pp_level_permute": (C.c_int, [vp, i64, vp, vp, vp, vp]),
     "pp_morton_order_workspace": (sz, [i64]),
     "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp, vp]),
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
@@ -46,11 +55,7 @@ SIGNATURES = {
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_set_scratch": (C.c_int, [vp, sz]),
     "pp_spconv_fwd_bf16": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
-    "pp_rulebook_blocks": (i64, [i64]),
-    "pp_rulebook_workspace": (sz, [i64]),
-    "pp_rulebook_offsets": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
-    "pp_rulebook_fill": (C.c_int, [vp, i64, vp, vp, vp, vp]),
-    "pp_spconv_fwd_rb": (C.c_int, [vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp]),
+    "pp_spconv_fwd_ex": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "pp_spconv_bwd_weight": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
     "pp_spconv_bwd_weight_bf16": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
     "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),

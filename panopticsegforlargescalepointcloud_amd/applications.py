@@ -183,8 +183,7 @@ class MinkowskiUnet(BaseMinkowski):
         self._set_input(data)
         data = self.input
         cm = data.coordinate_manager
-        prefetch = (ME.MAP_PREFETCH and not torch.is_grad_enabled() and ME.CONV_MODE in ("auto", "dense")
-                    and ME.TILE_WINDOW == 0)
+        prefetch = ME.MAP_PREFETCH and not torch.is_grad_enabled()
         plan = getattr(self, "_map_plan", None)
         if prefetch and plan is None:
             cm._log = []            # first inference pass of this model: record the level / map requests ...

@@ -483,8 +483,7 @@ extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const 
   int unit_shift = 0;
   while ((1 << unit_shift) < unit_src) ++unit_shift;
   BlockIndex I{bkeys, bvals, cap, start, bits, pre};
-  static const bool cube_ok = !(getenv("PP_KMAP_CUBE") && atoi(getenv("PP_KMAP_CUBE")) == 0);
-  if (block_bits <= 4 && cube_ok)
+  if (block_bits <= 4)
     hipLaunchKernelGGL(k_kernel_map_bi<true>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
                        I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
   else
@@ -494,45 +493,3 @@ extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const 
   return PP_OK;
 }
 
-// ---- tile schedule ------------------------------------------------------------------------------------------------------
-// Processing order of a level's rows for the convolution kernels: inside windows of `window` consecutive rows, rows are
-// grouped by coordinate parity and then by their 27-bit same-level neighbour mask, so the 16 rows of an MFMA tile
-// share most of their occupied offsets (same-level maps: useful work per executed tile 0.31 -> 0.43 at the finest
-// level; transposed stride-2 maps 0.42 -> 0.76).  Physical row order, and therefore every result, is unchanged.
-__global__ __launch_bounds__(256) void k_tile_keys(const int4* __restrict__ coords, const uint32_t* __restrict__ mask,
-                                                   int64_t n, int unit_shift, int window_shift, unsigned long long* key,
-                                                   int32_t* idx) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int4 c = coords[i];
-  const unsigned par = (((unsigned)(c.y + 32768) >> unit_shift) & 1u) | ((((unsigned)(c.z + 32768) >> unit_shift) & 1u) << 1) |
-                       ((((unsigned)(c.w + 32768) >> unit_shift) & 1u) << 2);
-  key[i] = ((unsigned long long)(i >> window_shift) << 30) | ((unsigned long long)par << 27) | (mask[i] & 0x7FFFFFFu);
-  idx[i] = (int32_t)i;
-}
-extern "C" size_t pp_tile_order_workspace(int64_t n) {
-  const size_t m = (size_t)std::max<int64_t>(n, 1);
-  return 2 * pp_align(m * 8) + pp_align(m * 4) + pp_sort_pairs_workspace(n) + 1024;
-}
-extern "C" int pp_tile_order(const int32_t* coords, const uint32_t* mask, int64_t n, int32_t unit, int32_t window,
-                             int32_t* order, void* workspace, size_t workspace_bytes, pp_stream_t stream) {
-  PP_REQUIRE(coords && mask && order, "pp_tile_order: null pointer");
-  PP_REQUIRE(unit >= 1 && (unit & (unit - 1)) == 0, "pp_tile_order: unit must be a power of two");
-  PP_REQUIRE(window >= 16 && (window & (window - 1)) == 0, "pp_tile_order: window must be a power of two >= 16");
-  if (workspace_bytes < pp_tile_order_workspace(n)) return PP_ERR_WORKSPACE;
-  if (n == 0) return PP_OK;
-  hipStream_t s = pp_s(stream);
-  int unit_shift = 0, window_shift = 0;
-  while ((1 << unit_shift) < unit) ++unit_shift;
-  while ((1 << window_shift) < window) ++window_shift;
-  PPArena ar(workspace, workspace_bytes);
-  uint64_t* key = ar.take<uint64_t>((size_t)n);
-  uint64_t* key2 = ar.take<uint64_t>((size_t)n);
-  int32_t* idx = ar.take<int32_t>((size_t)n);
-  hipLaunchKernelGGL(k_tile_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords, mask, n, unit_shift,
-                     window_shift, (unsigned long long*)key, idx);
-  PP_LAUNCH_CHECK();
-  int bits = 30;
-  while (bits < 63 && ((n - 1) >> window_shift) >> (bits - 30)) ++bits;
-  return pp_sort_pairs_u64(key, key2, idx, order, n, bits, ar.cur(), ar.left(), s);
-}

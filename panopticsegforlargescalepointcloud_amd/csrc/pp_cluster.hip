@@ -501,6 +501,8 @@ extern "C" int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n
   int rc = pp_exclusive_scan_i32(hist, offsets, (int64_t)n_groups + 1, nullptr, ar.cur(), ar.left(), s);
   if (rc) return rc;
   PP_HIP(hipMemcpyAsync(total, offsets + n_groups, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  // keys >= n_groups are dropped like negative ones, but they are a caller error: report their number
+  if (n_out_of_range) PP_HIP(hipMemcpyAsync(n_out_of_range, err, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   if (n > 0 && out) {
     hipLaunchKernelGGL(k_gbk_emit, dim3(pp_blocks(n, 256)), dim3(256), 0, s, idx2, ids, total, n, out);
     PP_LAUNCH_CHECK();

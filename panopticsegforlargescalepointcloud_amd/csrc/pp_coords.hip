@@ -210,23 +210,24 @@ extern "C" int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uin
 // convolution's (coarse -> fine) map with P scattered writes instead of 27 hash probes per fine row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kernel_map_transpose(const int32_t* __restrict__ in_map, int64_t n_out, int K,
-                                                              int64_t n_in, int32_t* __restrict__ out_map) {
+                                                              int64_t n_in, const int32_t* __restrict__ in_order,
+                                                              int32_t* __restrict__ out_map) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)K * n_out) return;
   int32_t i = in_map[e];
   if (i >= 0) {
     int64_t k = e / n_out, o = e - k * n_out;
-    out_map[k * n_in + i] = (int32_t)o;
+    out_map[k * n_in + i] = in_order ? in_order[o] : (int32_t)o;  // slot-ordered input map: slot o is row in_order[o]
   }
 }
-extern "C" int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, int32_t* out_map,
-                                       pp_stream_t stream) {
+extern "C" int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int64_t n_in, const int32_t* in_order,
+                                       int32_t* out_map, pp_stream_t stream) {
   PP_REQUIRE(in_map && out_map && K >= 1, "pp_kernel_map_transpose: bad arguments");
   hipStream_t s = pp_s(stream);
   if (n_in > 0) PP_HIP(hipMemsetAsync(out_map, 0xFF, sizeof(int32_t) * (size_t)K * (size_t)n_in, s));
   if (n_out == 0 || n_in == 0) return PP_OK;
   hipLaunchKernelGGL(k_kernel_map_transpose, dim3(pp_blocks((int64_t)K * n_out, 256)), dim3(256), 0, s, in_map, n_out, K,
-                     n_in, out_map);
+                     n_in, in_order, out_map);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

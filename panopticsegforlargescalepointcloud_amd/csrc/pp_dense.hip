@@ -717,8 +717,7 @@ static int segment_reduce_impl(const float* src, const int64_t* index, int64_t n
   } else {
     PP_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)total_out, s));
   }
-  static const bool seg_lds = !(getenv("PP_SEG_LDS") && atoi(getenv("PP_SEG_LDS")) == 0);
-  if (seg_lds && n > 0 && n_seg * (c + 1) <= SEG_LDS_WORDS && n * c >= 65536) {
+  if (n > 0 && n_seg * (c + 1) <= SEG_LDS_WORDS && n * c >= 65536) {
     hipLaunchKernelGGL(k_seg_accum_lds, dim3(pp_blocks(n * c, 256 * SEG_LDS_ELEMS_PER_THREAD)), dim3(256),
                        sizeof(int) * (size_t)(n_seg * (c + 1)), s, src, index, n * c, c, (int)n_seg, reduce, out,
                        (int*)out, cnt, cnt + n_seg);

@@ -1,0 +1,206 @@
+// K3d: tile scheduling at map-build time.
+//
+// The dense-offset convolution (pp_spconv2.hip) executes a kernel offset for a 16-row MFMA tile as soon as ONE of the
+// tile's rows has that neighbour; with rows in plain block / Z-order only ~0.3 of the executed tile rows are real pairs on
+// the fine levels (profiles/r01_w_layer_table.md).  Here every kernel map gets its own SLOT ORDER: inside windows of
+// PP_MAP_WINDOW consecutive rows, output rows are sorted by (batch element, neighbour mask) so that the 16 rows of a tile
+// -- and the 32 / 64 rows of a wave -- want the same offsets (measured on the bench scene: executed tile rows per pair
+// 3.2 -> 1.8 on same-level maps, 2.4 -> 1.05 on transposed stride-2 maps, 4.6 -> 2.0 on strided maps).
+//   * same-level maps: the slot order IS the physical row order of the level (pp_level_permute renumbers the level), so
+//     the convolution needs no indirection at all;
+//   * cross-level maps (strided / transposed): the map is stored slot-major (coalesced reads), `order[slot]` names the
+//     physical output row (the convolution scatters 64-byte row segments inside a window -- L2 merges them).
+// Windows are consecutive rows of the block / Z-order, so neighbours stay a few thousand rows apart (L2-resident).
+// Mask bits are compared rarest-class first (corner offsets, then edges, faces, centre): rows that differ only in the
+// common offsets end up next to each other.  The sort is a hand-written bitonic network in LDS, one workgroup per
+// window, on 49-bit composite keys (batch low bits | remapped mask | row in window): a total order, hence deterministic.
+// Reference: none -- MinkowskiEngine keeps kernel maps as unordered (in, out) pair lists per offset; results of the
+// convolution do not depend on the row order (every output row is still written exactly once, same summation order).
+#include "pp_common.h"
+
+#define MO_IDX_BITS 13           // rows per window <= 8192
+#define MO_MASK_BITS 27
+static int g_window = 8192;      // rows per window = keys per workgroup (8 B of LDS each); pp_map_set_window
+
+// significance of the 27 offsets in the sort key: corners (rarest) highest, then edges, faces, centre lowest
+__device__ __forceinline__ uint32_t mo_remap(uint32_t m) {
+  // offset k = (dx+1) + 3 (dy+1) + 9 (dz+1); class = number of non-zero components
+  constexpr uint32_t CORNER = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 8) | (1u << 18) | (1u << 20) | (1u << 24) | (1u << 26);
+  constexpr uint32_t FACE = (1u << 4) | (1u << 10) | (1u << 12) | (1u << 14) | (1u << 16) | (1u << 22);
+  constexpr uint32_t CENTRE = 1u << 13;
+  constexpr uint32_t EDGE = 0x7FFFFFFu & ~(CORNER | FACE | CENTRE);
+  // pack the bits of every class contiguously (pext-style, unrolled at compile time)
+  uint32_t out = 0;
+  int pos = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+    if (CENTRE >> k & 1u) out |= ((m >> k) & 1u) << pos++;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+    if (FACE >> k & 1u) out |= ((m >> k) & 1u) << pos++;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+    if (EDGE >> k & 1u) out |= ((m >> k) & 1u) << pos++;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+    if (CORNER >> k & 1u) out |= ((m >> k) & 1u) << pos++;
+  return out;
+}
+
+// ---- neighbour mask of a dense map ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_map_mask(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + o] >= 0 ? 1u : 0u) << k;
+  mask[o] = m;
+}
+extern "C" int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, pp_stream_t stream) {
+  PP_REQUIRE((nbr && mask) || n_out == 0, "pp_map_mask: null pointer");
+  PP_REQUIRE(K >= 1 && K <= 27, "pp_map_mask: K must be in [1,27]");
+  if (n_out == 0) return PP_OK;
+  hipLaunchKernelGGL(k_map_mask, dim3(pp_blocks(n_out, 256)), dim3(256), 0, pp_s(stream), nbr, K, n_out, mask);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- window sort ---------------------------------------------------------------------------------------------------------
+// one workgroup per window: composite keys in LDS, bitonic network, order[w * W + j] = row with the j-th smallest key
+template <int W>
+__global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restrict__ mask, const int4* __restrict__ coords,
+                                                       int64_t n, int32_t* __restrict__ order) {
+  constexpr int NT = W / 8;
+  __shared__ unsigned long long key[W];
+  const int64_t base = (int64_t)blockIdx.x * W;
+  const int cnt = (int)((n - base) < W ? (n - base) : W);
+  for (int j = threadIdx.x; j < W; j += NT) {
+    unsigned long long kk = ~0ull;  // padding sorts to the end
+    if (j < cnt) {
+      const uint32_t b = coords ? ((uint32_t)coords[base + j].x & 0xFFu) : 0u;
+      kk = ((unsigned long long)b << (MO_MASK_BITS + MO_IDX_BITS)) |
+           ((unsigned long long)mo_remap(mask[base + j] & 0x7FFFFFFu) << MO_IDX_BITS) | (unsigned long long)j;
+    }
+    key[j] = kk;
+  }
+  __syncthreads();
+  int len = 2;
+  while (len < cnt) len <<= 1;  // smallest power of two >= cnt (>= 2); the padding beyond cnt is already the maximum
+  for (int k = 2; k <= len; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (len >> 1); t += NT) {
+        // t-th compare-exchange of this stage: partner indices i < l with l = i | j
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = key[i], b = key[l];
+        if ((a > b) == up) {
+          key[i] = b;
+          key[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < cnt; j += NT)
+    order[base + j] = (int32_t)(base + (int64_t)(key[j] & ((1ull << MO_IDX_BITS) - 1ull)));
+}
+
+extern "C" int32_t pp_map_window(void) { return g_window; }
+extern "C" int pp_map_set_window(int32_t window) {
+  PP_REQUIRE(window == 1024 || window == 2048 || window == 4096 || window == 8192, "pp_map_set_window: 1024, 2048, 4096 or 8192");
+  g_window = window;
+  return PP_OK;
+}
+
+extern "C" int pp_map_order(const uint32_t* mask, const int32_t* coords, int64_t n, int32_t* order, pp_stream_t stream) {
+  PP_REQUIRE((mask && order) || n == 0, "pp_map_order: null pointer");
+  PP_REQUIRE(n < (1ll << 31), "pp_map_order: more than 2^31 rows");
+  if (n == 0) return PP_OK;
+  hipStream_t s = pp_s(stream);
+  const int4* c4 = (const int4*)coords;
+  switch (g_window) {
+    case 1024: hipLaunchKernelGGL(k_window_sort<1024>, dim3(pp_blocks(n, 1024)), dim3(128), 0, s, mask, c4, n, order); break;
+    case 2048: hipLaunchKernelGGL(k_window_sort<2048>, dim3(pp_blocks(n, 2048)), dim3(256), 0, s, mask, c4, n, order); break;
+    case 4096: hipLaunchKernelGGL(k_window_sort<4096>, dim3(pp_blocks(n, 4096)), dim3(512), 0, s, mask, c4, n, order); break;
+    default: hipLaunchKernelGGL(k_window_sort<8192>, dim3(pp_blocks(n, 8192)), dim3(1024), 0, s, mask, c4, n, order); break;
+  }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---- applying an order -----------------------------------------------------------------------------------------------------
+// out[k][s] = T(nbr[k][order[s]]),  T(v) = v < 0 ? -1 : (translate ? translate[v] : v).
+// `order` is window-local (pp_map_order), so one workgroup stages the window's slice of ONE offset in LDS with coalesced
+// loads, gathers from LDS and writes coalesced: the 27 scattered 4-byte global reads per row of the naive form
+// (14.7 ms per bench step) become LDS reads.  window = 0 selects the naive form (any order / no order).
+template <int W>
+__global__ __launch_bounds__(256) void k_map_permute_win(const int32_t* __restrict__ nbr, int64_t n,
+                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
+                                                         int32_t* __restrict__ out) {
+  __shared__ int32_t row[W];
+  const int64_t base = (int64_t)blockIdx.x * W;
+  const int k = blockIdx.y;
+  const int cnt = (int)((n - base) < W ? (n - base) : W);
+  const int32_t* src = nbr + (int64_t)k * n + base;
+  for (int j = threadIdx.x; j < cnt; j += 256) row[j] = src[j];
+  __syncthreads();
+  int32_t* dst = out + (int64_t)k * n + base;
+  for (int j = threadIdx.x; j < cnt; j += 256) {
+    int32_t v = row[order[base + j] - (int32_t)base];
+    if (translate && v >= 0) v = translate[v];
+    dst[j] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_map_permute(const int32_t* __restrict__ nbr, int K, int64_t n,
+                                                     const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
+                                                     int32_t* __restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int64_t o = order ? (int64_t)order[s] : s;
+  for (int k = 0; k < K; ++k) {
+    int32_t v = nbr[(int64_t)k * n + o];
+    if (translate && v >= 0) v = translate[v];
+    out[(int64_t)k * n + s] = v;
+  }
+}
+// window: the window size `order` was built with (pp_map_window() at that time), or 0 for an arbitrary / NULL order
+extern "C" int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
+                              int32_t window, int32_t* out, pp_stream_t stream) {
+  PP_REQUIRE((nbr && out) || n_out == 0, "pp_map_permute: null pointer");
+  PP_REQUIRE(K >= 1 && K <= 27, "pp_map_permute: K must be in [1,27]");
+  PP_REQUIRE(nbr != out, "pp_map_permute: in-place permutation is not supported");
+  if (n_out == 0) return PP_OK;
+  hipStream_t s = pp_s(stream);
+  if (order && window > 0) {
+    PP_REQUIRE(window == 1024 || window == 2048 || window == 4096 || window == 8192, "pp_map_permute: bad window");
+    const dim3 grid(pp_blocks(n_out, window), (unsigned)K);
+    switch (window) {
+      case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
+      case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
+      case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
+      default: hipLaunchKernelGGL(k_map_permute_win<8192>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
+    }
+  } else
+    hipLaunchKernelGGL(k_map_permute, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, nbr, K, n_out, order, translate, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// coords_out[s] = coords[order[s]],  inverse[order[s]] = s,  mask_out[s] = mask[order[s]] (mask optional)
+__global__ __launch_bounds__(256) void k_level_permute(const int4* __restrict__ coords, int64_t n, const int32_t* __restrict__ order,
+                                                       int4* __restrict__ coords_out, int32_t* __restrict__ inverse) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int32_t o = order[s];
+  coords_out[s] = coords[o];
+  inverse[o] = (int32_t)s;
+}
+extern "C" int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,
+                                pp_stream_t stream) {
+  PP_REQUIRE((coords && order && coords_out && inverse) || n == 0, "pp_level_permute: null pointer");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(k_level_permute, dim3(pp_blocks(n, 256)), dim3(256), 0, pp_s(stream), (const int4*)coords, n, order,
+                     (int4*)coords_out, inverse);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

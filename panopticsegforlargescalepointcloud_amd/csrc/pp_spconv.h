@@ -46,8 +46,7 @@ __device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
 // pipelined variant (pp_spconv2.hip); mode16 only, K <= 28
 // VALU-free main loop (buffer loads); needs the input row count for the descriptor
 bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in);
-int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
-int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s);
+int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, int T, int depth, hipStream_t s);
 int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s);
 
 // pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows

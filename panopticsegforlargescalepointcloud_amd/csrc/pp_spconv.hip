@@ -245,14 +245,20 @@ extern "C" int pp_spconv_set_scratch(void* scratch, size_t bytes) {
   return PP_OK;
 }
 
+// rows_per_wave (0 | 32 | 64), pipeline (0 | 1 | 3) and split_k (0 | 1 | 2 | 4 | 8) select the variant of the pipelined
+// kernel explicitly; 0 = the per-shape choice below.  The parity tests drive every variant through pp_spconv_fwd_ex.
 static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                            const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                            const float* scale, const float* shift, int32_t relu, const float* residual,
-                           const int32_t* row_order, float* out, int bf16, pp_stream_t stream) {
+                           const int32_t* row_order, float* out, int bf16, int rows_per_wave, int pipeline, int split_k,
+                           pp_stream_t stream) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
   PP_REQUIRE((c0 + c1) % 4 == 0, "pp_spconv_fwd: cin must be a multiple of 4");
+  PP_REQUIRE(rows_per_wave == 0 || rows_per_wave == 32 || rows_per_wave == 64, "pp_spconv_fwd_ex: rows_per_wave in {0, 32, 64}");
+  PP_REQUIRE(pipeline == 0 || pipeline == 1 || pipeline == 3, "pp_spconv_fwd_ex: pipeline in {0, 1, 3}");
+  PP_REQUIRE(split_k == 0 || split_k == 1 || split_k == 2 || split_k == 4 || split_k == 8, "pp_spconv_fwd_ex: split_k in {0, 1, 2, 4, 8}");
   const bool mode16 = ((c0 + c1) % 16 == 0);
   if (mode16) PP_REQUIRE(c0 % 16 == 0, "pp_spconv_fwd: with cin % 16 == 0 both sources must be multiples of 16");
   if (n_out == 0) return PP_OK;
@@ -264,39 +270,56 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
   groups = (a.NT + ntw - 1) / ntw;
-  dim3 grid(pp_blocks(n_out, 128), (unsigned)groups);
-  static int dense_ver = -1;  // PP_DENSE_VER=1 selects the un-pipelined kernel (A/B measurements)
-  if (dense_ver < 0) {
-    const char* e = getenv("PP_DENSE_VER");
-    dense_ver = e ? atoi(e) : 3;
-  }
-  if (mode16 && (dense_ver >= 3 || bf16) && K <= 28 && ntw <= 4 && pp_spconv_fwd3_ok(a, n_in)) {
+  const bool v3_ok = mode16 && K <= 28 && pp_spconv_fwd3_ok(a, n_in);
+  if (v3_ok) {
+    // rows per wave: 64 on launches with <= 2 column tiles per wave and >= 2 M rows -- narrow layers are bound by per-step
+    // work, which 64 rows halve per row -- 32 on wider ones (the extra accumulators cost occupancy: 48->48 660 vs 690 us)
+    // and on smaller ones (halving the number of waves costs more: one rank's share at 8 GPUs 34.1 vs 34.6 ms)
+    const int T = rows_per_wave ? rows_per_wave / 16 : (ntw <= 2 && n_out >= 2000000 ? 4 : 2);
+    const int depth = pipeline ? pipeline : (ntw <= 2 ? 3 : 1);
     // small launches (fewer waves than SIMD slots) are bound by the latency of one wave's walk over the 27 offsets:
     // split the offsets over up to 8 waves and add the partials in a fixed order (deterministic)
-    static const int split_env = getenv("PP_DENSE_SPLIT") ? atoi(getenv("PP_DENSE_SPLIT")) : -1;
-    const int64_t waves = ((n_out + 31) / 32) * groups;
-    if (K >= 8 && g_scratch && split_env != 1 && waves < 1536) {
-      int sk = 2;
+    const int64_t waves = ((n_out + 16 * T - 1) / (16 * T)) * groups;
+    int sk = 1;
+    if (split_k > 1)
+      sk = split_k;
+    else if (split_k == 0 && K >= 8 && g_scratch && waves < 1536) {
+      sk = 2;
       while (sk < 8 && waves * sk < 2048) sk *= 2;
-      if (split_env > 1) sk = split_env;
-      if ((size_t)sk * (size_t)n_out * (size_t)cout * sizeof(float) <= g_scratch_bytes) {
+    }
+    if (sk > 1) {
+      if (g_scratch && (size_t)sk * (size_t)n_out * (size_t)cout * sizeof(float) <= g_scratch_bytes && K >= sk) {
         a.split = sk;
         a.part = g_scratch;
+      } else if (split_k > 1) {
+        pp_set_error("pp_spconv_fwd_ex: split_k %d needs K >= split_k and a scratch of %zu bytes (pp_spconv_set_scratch)", sk,
+                     (size_t)sk * (size_t)n_out * (size_t)cout * sizeof(float));
+        return PP_ERR_WORKSPACE;
       }
     }
-    int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, pp_s(stream));
+    int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;
     if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
-  } else if (bf16) {
-    pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
-    return PP_ERR_INVALID;
-  } else if (mode16 && dense_ver >= 2 && K <= 28 && ntw <= 4) {
-    int rc = pp_spconv_fwd2_launch(a, ntw, (unsigned)groups, pp_s(stream));
-    if (rc != PP_OK) return rc;
-  } else if (mode16)
-    launch_fwd<true>(ntw, grid, pp_s(stream), a);
-  else
-    launch_fwd<false>(ntw, grid, pp_s(stream), a);
+  } else {
+    // first-version kernel: Cin % 16 != 0 (the 4 -> 16 input layer) and inputs of 4 GiB or more per source
+    if (bf16) {
+      pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
+      return PP_ERR_INVALID;
+    }
+    if (row_order) {  // only the pipelined kernel understands slot-ordered maps
+      pp_set_error("pp_spconv_fwd: a slot-ordered map needs cin %% 16 == 0 and inputs < 4 GiB per source");
+      return PP_ERR_INVALID;
+    }
+    if (rows_per_wave || pipeline || split_k > 1) {
+      pp_set_error("pp_spconv_fwd_ex: this shape runs on the first-version kernel, which has no variants");
+      return PP_ERR_INVALID;
+    }
+    dim3 grid(pp_blocks(n_out, 128), (unsigned)groups);
+    if (mode16)
+      launch_fwd<true>(ntw, grid, pp_s(stream), a);
+    else
+      launch_fwd<false>(ntw, grid, pp_s(stream), a);
+  }
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -306,14 +329,22 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
                              const float* scale, const float* shift, int32_t relu, const float* residual,
                              const int32_t* row_order, float* out, pp_stream_t stream) {
   return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
-                         row_order, out, 0, stream);
+                         row_order, out, 0, 0, 0, 0, stream);
 }
 extern "C" int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                                   const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out,
                                   int32_t cout, const float* scale, const float* shift, int32_t relu,
                                   const float* residual, const int32_t* row_order, float* out, pp_stream_t stream) {
   return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
-                         row_order, out, 1, stream);
+                         row_order, out, 1, 0, 0, 0, stream);
+}
+extern "C" int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                                const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
+                                const float* scale, const float* shift, int32_t relu, const float* residual,
+                                const int32_t* row_order, float* out, int32_t bf16, int32_t rows_per_wave,
+                                int32_t pipeline, int32_t split_k, pp_stream_t stream) {
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
+                         row_order, out, bf16 ? 1 : 0, rows_per_wave, pipeline, split_k, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,8 +406,7 @@ static int spconv_bwd_weight_impl(const float* in, int32_t cin, int64_t n_in, co
   hipStream_t s = pp_s(stream);
   PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
   if (n_out == 0) return PP_OK;
-  static const int bww_ver = getenv("PP_BWW_VER") ? atoi(getenv("PP_BWW_VER")) : 2;
-  if ((bww_ver >= 2 || bf16) && pp_spconv_bww2_ok(cin, cout, n_in, nbr))
+  if (pp_spconv_bww2_ok(cin, cout, n_in, nbr))
     return pp_spconv_bww2_launch(in, cin, n_in, dout, cout, nbr, K, n_out, dw, bf16, s);
   if (bf16) {
     pp_set_error("pp_spconv_bwd_weight_bf16: needs a kernel map, cout <= 192 and inputs < 4 GiB");

@@ -11,179 +11,9 @@
 //   * software pipeline of depth 1 in registers: the A gathers and B fragment loads of step n+1 are issued before the
 //     MFMAs of step n, so each wave overlaps its own memory latency with its own matrix work instead of relying on
 //     other waves being out of phase.
-#include <stdlib.h>
-
 #include "pp_spconv.h"
 
 #define F2_MAXK 28
-
-template <int NTW, int T>
-__global__ __launch_bounds__(256, 2) void k_spconv_fwd2(SpconvArgs a) {
-  constexpr int R = 16 * T;  // rows per wave
-  __shared__ int32_t s_idx[4][F2_MAXK][R];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  const unsigned bid = pp_xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t row_base = ((int64_t)bid * 4 + wave) * R;
-  if (row_base >= a.n_out) return;  // wave-uniform; waves never synchronise
-  const int jt0 = blockIdx.y * NTW;
-  int32_t(*idx)[R] = s_idx[wave];
-
-  // ---- prologue: indices -> LDS, per-tile occupancy masks -> SGPRs
-  unsigned m[T];
-#pragma unroll
-  for (int tt = 0; tt < T; ++tt) m[tt] = 0;
-  {
-    constexpr int KPL = 64 / R >= 1 ? 64 / R : 1;       // offsets fetched per load instruction (R = 32: 2, R = 64: 1)
-    constexpr int NL = (F2_MAXK + KPL - 1) / KPL;       // load instructions
-    const int rr = lane % R, kh = lane / R;
-    const int64_t row = row_base + rr;
-    const bool rv = row < a.n_out;
-    int v[NL];
-    // branch-free: clamped addresses, validity applied afterwards (a branch per load would serialise the loads)
-    const int64_t rowc = rv ? row : a.n_out - 1;
-    if (a.nbr) {
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = KPL * kk + kh;
-        const int kc = k < a.K ? k : a.K - 1;
-        v[kk] = a.nbr[(int64_t)kc * a.n_out + rowc];
-      }
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk)
-        if (!rv || KPL * kk + kh >= a.K) v[kk] = -1;
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < NL; ++kk) v[kk] = (rv && KPL * kk + kh < a.K) ? (int)row : -1;
-    }
-#pragma unroll
-    for (int kk = 0; kk < NL; ++kk) {
-      if (KPL * kk + kh < F2_MAXK) idx[KPL * kk + kh][rr] = v[kk];
-      const unsigned long long b = __ballot(v[kk] >= 0);
-#pragma unroll
-      for (int h = 0; h < KPL; ++h)
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt)
-          m[tt] |= (((b >> (h * R + tt * 16)) & 0xFFFFull) ? 1u : 0u) << (KPL * kk + h);
-    }
-  }
-  unsigned rem = 0;
-#pragma unroll
-  for (int tt = 0; tt < T; ++tt) {
-    m[tt] = __builtin_amdgcn_readfirstlane(m[tt]);
-    rem |= m[tt];
-  }
-
-  f32x4 acc[T][NTW];
-#pragma unroll
-  for (int tt = 0; tt < T; ++tt)
-#pragma unroll
-    for (int jt = 0; jt < NTW; ++jt) acc[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int cin = a.c0 + a.c1;
-  const int S0 = a.c0 >> 4, S = cin >> 4;
-  const float* wl = a.wp + (int64_t)jt0 * 256 + lane * 4;
-
-  if (rem) {
-    int k = __builtin_ctz(rem);
-    int s = 0;
-    int ar[T];
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) ar[tt] = idx[k][tt * 16 + i];
-    f32x4 A[T], B[NTW];
-    // loads of step (KK, SS) with neighbour rows RR[] into (X[], Y[]): unconditional, clamped addresses
-#define F2_LOAD(X, Y, KK, SS, RR)                                                           \
-  {                                                                                         \
-    const float* src_ = (SS) < S0 ? a.in0 : a.in1;                                          \
-    const int cs_ = (SS) < S0 ? a.c0 : a.c1;                                                \
-    const int ss_ = (SS) < S0 ? (SS) : (SS)-S0;                                             \
-    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                      \
-      const int r_ = RR[tt] < 0 ? 0 : RR[tt];                                               \
-      X[tt] = *(const f32x4*)(src_ + (int64_t)r_ * cs_ + ss_ * 16 + q * 4);                 \
-    }                                                                                       \
-    const float* w_ = wl + ((int64_t)(KK)*S + (SS)) * a.NT * 256;                           \
-    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) {                                    \
-      const int jc_ = jt0 + jt < a.NT ? jt : 0;                                             \
-      Y[jt] = *(const f32x4*)(w_ + jc_ * 256);                                              \
-    }                                                                                       \
-  }
-#define F2_ZERO(X, RR) \
-  _Pragma("unroll") for (int tt = 0; tt < T; ++tt) X[tt] = RR[tt] >= 0 ? X[tt] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    F2_LOAD(A, B, k, s, ar);
-    F2_ZERO(A, ar);
-    for (;;) {
-      // next step
-      int kn = k, sn = s + 1;
-      int arn[T];
-#pragma unroll
-      for (int tt = 0; tt < T; ++tt) arn[tt] = ar[tt];
-      if (sn == S) {
-        sn = 0;
-        rem &= rem - 1;
-        kn = rem ? __builtin_ctz(rem) : -1;
-        if (kn >= 0) {
-#pragma unroll
-          for (int tt = 0; tt < T; ++tt) arn[tt] = idx[kn][tt * 16 + i];
-        }
-      }
-      // loads of the next step are unconditional (the last iteration re-reads its own step) so that no branch or
-      // select sits between them and the MFMAs below: their s_waitcnt lands at the register rotation after the MFMAs
-      f32x4 An[T], Bn[NTW];
-      {
-        const int kl = kn >= 0 ? kn : k, sl = kn >= 0 ? sn : s;
-        F2_LOAD(An, Bn, kl, sl, arn);
-      }
-      // matrix work of the current step.  One guarded block per 16-row tile (a block touches only its own accumulators:
-      // the three-way both/upper/lower split made hipcc shuffle all accumulators through copies at every step)
-#pragma unroll
-      for (int tt = 0; tt < T; ++tt) {
-        if ((m[tt] >> k) & 1u) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int jt = 0; jt < NTW; ++jt)
-              acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[tt][t], B[jt][t], acc[tt][jt], 0, 0, 0);
-        }
-      }
-      if (kn < 0) break;
-#pragma unroll
-      for (int tt = 0; tt < T; ++tt) {
-        A[tt] = An[tt];
-        ar[tt] = arn[tt];
-      }
-      F2_ZERO(A, ar);
-#pragma unroll
-      for (int jt = 0; jt < NTW; ++jt) B[jt] = Bn[jt];
-      k = kn;
-      s = sn;
-    }
-#undef F2_LOAD
-#undef F2_ZERO
-  }
-
-  // epilogue: lane (col = i, row group = q) holds rows 4q+r of each 16-row tile
-#pragma unroll
-  for (int jt = 0; jt < NTW; ++jt) {
-    const int col = (jt0 + jt) * 16 + i;
-    if (jt0 + jt < a.NT && col < a.cout) {
-      const float sc = a.scale ? a.scale[col] : 1.f;
-      const float sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-      for (int rt = 0; rt < T; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t row = row_base + rt * 16 + q * 4 + r;
-          if (row < a.n_out) {
-            float v = acc[rt][jt][r] * sc + sh;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.residual) v += a.residual[row * a.cout + col];
-            a.out[row * a.cout + col] = v;
-          }
-        }
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v3: the same pipeline with (almost) no vector-ALU instruction left in the main loop.
@@ -238,12 +68,12 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     constexpr int NL = (F2_MAXK + KPL - 1) / KPL;
     const int rr = lane % R, kh = lane / R;
     const bool rv = row_base + rr < a.n_out;
-    // tile schedule: the wave's 32 "slots" may name any output rows (rows with similar neighbour masks are scheduled
-    // into the same tile by the coordinate manager); without one, slot = row
+    // slot order of a cross-level map (pp_maporder.hip): the map is stored slot-major, row_order[slot] names the output
+    // row the slot writes; same-level maps have slot = row and no row_order
     const int64_t slot = rv ? row_base + rr : a.n_out - 1;
     const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
     int v[NL];
-    const int64_t rowc = row;
+    const int64_t rowc = slot;
     if (a.nbr) {
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
@@ -405,33 +235,6 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         F3_MFMAS(A1, B1, k1);
         if (!e0) break;
       }
-    } else {
-      // two steps in flight (three register sets): narrow layers have too few MFMAs per step to cover a gather
-      int nsteps = __builtin_popcount(rem) * S;
-      f32x4 A2[T], B2[NTW];
-      F3_LOADS(A0, B0);
-      int k0 = kl, k1, k2;
-      F3_ADVANCE(more);
-      F3_LOADS(A1, B1);
-      k1 = kl;
-      F3_ADVANCE(more);
-      for (;;) {
-        F3_LOADS(A2, B2);
-        k2 = kl;
-        F3_ADVANCE(more);
-        F3_MFMAS(A0, B0, k0);
-        if (--nsteps == 0) break;
-        F3_LOADS(A0, B0);
-        k0 = kl;
-        F3_ADVANCE(more);
-        F3_MFMAS(A1, B1, k1);
-        if (--nsteps == 0) break;
-        F3_LOADS(A1, B1);
-        k1 = kl;
-        F3_ADVANCE(more);
-        F3_MFMAS(A2, B2, k2);
-        if (--nsteps == 0) break;
-      }
     }
 #undef F3_LOADS
 #undef F3_ADVANCE
@@ -484,34 +287,19 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 }
 
 template <int T, bool BF16>
-static int launch3_t(const SpconvArgs& a, int ntw, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
+static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
-  // PP_DENSE_DEPTH: loop variant for launches with <= PP_DENSE_DEPTH_NTW (default 2) column tiles per wave:
-  // 1 = one step in flight, 2 = two steps in flight, 3 (default) = one step in flight with the load side advanced
-  // before the MFMAs (16->16 at 2.5 M rows: 374 / 375 / 343 us); wider launches always use 1
-  static int depth_env = -1;
-  static int depth_ntw = 2;
-  if (depth_env < 0) {
-    depth_env = getenv("PP_DENSE_DEPTH") ? atoi(getenv("PP_DENSE_DEPTH")) : 3;
-    if (getenv("PP_DENSE_DEPTH_NTW")) depth_ntw = atoi(getenv("PP_DENSE_DEPTH_NTW"));
+  // depth: 1 = one step in flight; 3 = one step in flight with the load side advanced (LDS read of the next offsets)
+  // before the MFMAs of the current step -- pays on launches with <= 2 column tiles per wave (16->16 at 2.5 M rows:
+  // 374 -> 343 us), nothing on wider ones
+#define F3_CASE(N, D) \
+  case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+  switch (10 * depth + ntw) {
+    F3_CASE(1, 1) F3_CASE(2, 1) F3_CASE(3, 1) F3_CASE(4, 1)
+    F3_CASE(1, 3) F3_CASE(2, 3) F3_CASE(3, 3) F3_CASE(4, 3)
+    default: pp_set_error("pp_spconv_fwd3: ntw %d / depth %d out of range", ntw, depth); return PP_ERR_INVALID;
   }
-  const bool deep = depth_env == 2 && ntw <= depth_ntw;
-  const bool early = depth_env == 3 && ntw <= depth_ntw;
-  switch (ntw + (deep ? 10 : 0) + (early ? 20 : 0)) {
-    case 21: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 22: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 23: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 24: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 3>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 11: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 12: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 13: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 14: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 2>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-    default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
-  }
+#undef F3_CASE
   return PP_OK;
 }
 
@@ -541,49 +329,17 @@ bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in) {
   return (double)n_in * a.c0 * 4.0 < 4294967000.0 && (double)a.K * (a.c0 + a.c1) * a.NT * 64.0 < 4294967000.0;
 }
 
-int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s) {
-  static int t_env = -1;
-  if (t_env < 0) {
-    const char* e = getenv("PP_DENSE_T");
-    t_env = e ? atoi(e) : 0;
-  }
-  // rows per wave: 64 (T = 4) on launches with <= PP_DENSE_T4_NTW (default 2) column tiles per wave -- narrow layers are
-  // bound by per-step work, which 64 rows halve per row (end to end 186.9 -> 183.7 ms) -- and 32 (T = 2) on wider ones,
-  // where the extra accumulators cost occupancy (48->48: 660 vs 690 us), and on launches below PP_DENSE_T4_ROWS (2 M)
-  // rows, where halving the number of waves costs more (one rank's share at 8 GPUs: 34.1 vs 34.6 ms); PP_DENSE_T forces
-  // one value
-  static const int t4_ntw = getenv("PP_DENSE_T4_NTW") ? atoi(getenv("PP_DENSE_T4_NTW")) : 2;
-  static const int64_t t4_rows = getenv("PP_DENSE_T4_ROWS") ? atoll(getenv("PP_DENSE_T4_ROWS")) : 2000000;
-  const int T = t_env ? t_env : (ntw <= t4_ntw && a.n_out >= t4_rows ? 4 : 2);
+// T = 16-row tiles per wave (2 or 4), depth = loop variant (1 or 3); the caller picks them (spconv_fwd_impl)
+int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, int T, int depth, hipStream_t s) {
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
+  if (T != 2 && T != 4) {
+    pp_set_error("pp_spconv_fwd3: rows per wave must be 32 or 64");
+    return PP_ERR_INVALID;
+  }
   if (a.bf16)
-    return T == 4 ? launch3_t<4, true>(a, ntw, groups, a_bytes, w_bytes, s)
-                  : launch3_t<2, true>(a, ntw, groups, a_bytes, w_bytes, s);
-  return T == 4 ? launch3_t<4, false>(a, ntw, groups, a_bytes, w_bytes, s)
-                : launch3_t<2, false>(a, ntw, groups, a_bytes, w_bytes, s);
-}
-
-template <int T>
-static int launch_t(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s) {
-  dim3 grid(pp_blocks(a.n_out, 64 * T), groups);
-  switch (ntw) {
-    case 1: hipLaunchKernelGGL((k_spconv_fwd2<1, T>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_spconv_fwd2<2, T>), grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_spconv_fwd2<3, T>), grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_spconv_fwd2<4, T>), grid, dim3(256), 0, s, a); break;
-    default: pp_set_error("pp_spconv_fwd2: ntw %d out of range", ntw); return PP_ERR_INVALID;
-  }
-  return PP_OK;
-}
-
-// rows per wave: 32 (T = 2) or 64 (T = 4); PP_DENSE_T overrides the per-shape choice (A/B measurements)
-int pp_spconv_fwd2_launch(const SpconvArgs& a, int ntw, unsigned groups, hipStream_t s) {
-  static int t_env = -1;
-  if (t_env < 0) {
-    const char* e = getenv("PP_DENSE_T");
-    t_env = e ? atoi(e) : 0;
-  }
-  const int T = t_env ? t_env : 2;
-  return T == 4 ? launch_t<4>(a, ntw, groups, s) : launch_t<2>(a, ntw, groups, s);
+    return T == 4 ? launch3_t<4, true>(a, ntw, depth, groups, a_bytes, w_bytes, s)
+                  : launch3_t<2, true>(a, ntw, depth, groups, a_bytes, w_bytes, s);
+  return T == 4 ? launch3_t<4, false>(a, ntw, depth, groups, a_bytes, w_bytes, s)
+                : launch3_t<2, false>(a, ntw, depth, groups, a_bytes, w_bytes, s);
 }

@@ -259,26 +259,64 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False):
     return nbr
 
 
-def tile_order(coords, mask, unit, window=16384):
-    """processing order (int32 [n]) of a level's rows: (window, coordinate parity, neighbour mask) -- see pp_tile_order"""
+def map_mask(nbr):
+    """uint32-as-int32 [n_out]: bit k set <=> nbr[k][o] >= 0"""
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    mask = torch.empty(max(n_out, 1), dtype=torch.int32, device=nbr.device)
+    _lib.check(lib.pp_map_mask(_ptr(nbr), K, n_out, _ptr(mask), _stream()), "pp_map_mask")
+    return mask[:n_out]
+
+
+def map_order(mask, coords=None):
+    """slot order of a kernel map (csrc/pp_maporder.hip): order[s] = output row taking slot s.  Rows are sorted by
+    (batch element, neighbour mask) inside windows of pp_map_window() consecutive rows; `coords` ([n,4] int32, optional)
+    supplies the batch element."""
+    lib = _lib.load()
+    mask = _need(mask, torch.int32, "mask")
+    coords = _need(coords, torch.int32, "coords")
+    n = mask.shape[0]
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)
+    _lib.check(lib.pp_map_order(_ptr(mask), _ptr(coords), n, _ptr(order), _stream()), "pp_map_order")
+    order = order[:n]
+    order.pp_window = int(lib.pp_map_window())  # map_permute stages window slices in LDS
+    return order
+
+
+def map_permute(nbr, order=None, translate=None):
+    """out[k][s] = T(nbr[k][order[s]]) with T(v) = -1 if v < 0 else (translate[v] if translate is given else v)"""
+    lib = _lib.load()
+    nbr = _need(nbr, torch.int32, "nbr")
+    K, n_out = nbr.shape
+    out = torch.empty_like(nbr)
+    _lib.check(lib.pp_map_permute(_ptr(nbr), K, n_out, _ptr(_need(order, torch.int32, "order")),
+                                  _ptr(_need(translate, torch.int32, "translate")), int(getattr(order, "pp_window", 0)),
+                                  _ptr(out), _stream()), "pp_map_permute")
+    if hasattr(nbr, "pp_pairs"):
+        out.pp_pairs = nbr.pp_pairs
+    return out
+
+
+def level_permute(coords, order):
+    """(coords[order], inverse) with inverse[order[s]] = s"""
     lib = _lib.load()
     coords = _need(coords, torch.int32, "coords")
-    mask = _need(mask, torch.int32, "mask")
+    order = _need(order, torch.int32, "order")
     n = coords.shape[0]
-    order = torch.empty(max(n, 1), dtype=torch.int32, device=coords.device)
-    wsb = lib.pp_tile_order_workspace(n)
-    ws = _ws(wsb, coords.device, tag="tile_order")
-    _lib.check(lib.pp_tile_order(_ptr(coords), _ptr(mask), n, int(unit), int(window), _ptr(order), _ptr(ws), wsb, _stream()),
-               "pp_tile_order")
-    return order[:n]
+    out = torch.empty_like(coords)
+    inv = torch.empty(max(n, 1), dtype=torch.int32, device=coords.device)
+    _lib.check(lib.pp_level_permute(_ptr(coords), n, _ptr(order), _ptr(out), _ptr(inv), _stream()), "pp_level_permute")
+    return out, inv[:n]
 
 
-def kernel_map_transpose(nbr, n_in):
-    """map of the transposed strided conv from the strided conv's map: out[k][nbr[k][o]] = o."""
+def kernel_map_transpose(nbr, n_in, order=None):
+    """map of the transposed strided conv from the strided conv's map: out[k][nbr[k][o]] = o (order[o] when the map
+    is slot-ordered).  The result is indexed by physical rows of the finer level."""
     lib = _lib.load()
     K, n_out = nbr.shape
     out = torch.empty((K, n_in), dtype=torch.int32, device=nbr.device)
-    _lib.check(lib.pp_kernel_map_transpose(_ptr(nbr), n_out, K, int(n_in), _ptr(out), _stream()), "pp_kernel_map_transpose")
+    _lib.check(lib.pp_kernel_map_transpose(_ptr(nbr), n_out, K, int(n_in), _ptr(_need(order, torch.int32, "order")), _ptr(out),
+                                           _stream()), "pp_kernel_map_transpose")
     if hasattr(nbr, "pp_pairs"):
         out.pp_pairs = nbr.pp_pairs  # same pairs, roles swapped
     return out
@@ -339,7 +377,10 @@ def bf16_conv_supported(c0, c1, K, nbr_given=True):
 
 
 def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
-               row_order=None, bf16=False):
+               row_order=None, bf16=False, variant=None):
+    """variant = (rows_per_wave, pipeline, split_k): an explicit variant of the pipelined kernel through
+    pp_spconv_fwd_ex (tests / A-B runs); None = the library's per-shape choice.  row_order: slot order of a
+    cross-level map (nbr is slot-major then)."""
     lib = _lib.load()
     in0 = _need(in0, torch.float32, "in0")
     in1 = _need(in1, torch.float32, "in1")
@@ -352,69 +393,25 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     scale = _need(scale, torch.float32, "scale")
     shift = _need(shift, torch.float32, "shift")
     residual = _need(residual, torch.float32, "residual")
+    row_order = _need(row_order, torch.int32, "row_order")
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib.pp_spconv_fwd_bf16 if (bf16 and bf16_conv_supported(c0, c1, K)) else lib.pp_spconv_fwd
     _conv_scratch(lib, in0.device)
-    _lib.check(fn(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
-                  _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out), _stream()), "pp_spconv_fwd")
+    args = (_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
+            _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out))
+    use_bf16 = bool(bf16) and bf16_conv_supported(c0, c1, K)
+    if variant is not None:
+        rpw, pipe, split = variant
+        _lib.check(lib.pp_spconv_fwd_ex(*args, int(use_bf16), int(rpw), int(pipe), int(split), _stream()), "pp_spconv_fwd_ex")
+    else:
+        fn = lib.pp_spconv_fwd_bf16 if use_bf16 else lib.pp_spconv_fwd
+        _lib.check(fn(*args, _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None))
-    return out
-
-
-class Rulebook:
-    """Block-compacted form of a 27-offset kernel map (see csrc/pp_spconv_rb.hip)."""
-
-    def __init__(self, off, rb_in, rb_out, n_out, total, pairs):
-        self.off, self.rb_in, self.rb_out, self.n_out, self.total, self.pairs = off, rb_in, rb_out, n_out, total, pairs
-
-
-def rulebook_build(nbr):
-    lib = _lib.load()
-    K, n_out = nbr.shape
-    assert K == 27
-    dev = nbr.device
-    nblk = int(lib.pp_rulebook_blocks(n_out))
-    off = torch.empty(nblk * 28 + 1, dtype=torch.int32, device=dev)
-    total = torch.zeros(1, dtype=torch.int32, device=dev)
-    wsb = lib.pp_rulebook_workspace(n_out)
-    ws = _ws(wsb, dev)
-    _lib.check(lib.pp_rulebook_offsets(_ptr(nbr), n_out, _ptr(off), _ptr(total), _ptr(ws), wsb, _stream()),
-               "pp_rulebook_offsets")
-    t = int(total.item())
-    rb_in = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
-    rb_out = torch.empty(max(t, 1), dtype=torch.int32, device=dev)
-    _lib.check(lib.pp_rulebook_fill(_ptr(nbr), n_out, _ptr(off), _ptr(rb_in), _ptr(rb_out), _stream()), "pp_rulebook_fill")
-    return Rulebook(off, rb_in, rb_out, n_out, t, _pairs_of(nbr))
-
-
-def spconv_fwd_rb(in0, packed, rb, cout, in1=None, scale=None, shift=None, relu=False, residual=None):
-    lib = _lib.load()
-    in0 = _need(in0, torch.float32, "in0")
-    in1 = _need(in1, torch.float32, "in1")
-    c0 = in0.shape[1]
-    c1 = 0 if in1 is None else in1.shape[1]
-    n_out = rb.n_out
-    out = torch.empty((n_out, cout), dtype=torch.float32, device=in0.device)
-    scale = _need(scale, torch.float32, "scale")
-    shift = _need(shift, torch.float32, "shift")
-    residual = _need(residual, torch.float32, "residual")
-    prof = PROFILER
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(lib.pp_spconv_fwd_rb(_ptr(in0), c0, _ptr(in1), c1, _ptr(packed), _ptr(rb.off), _ptr(rb.rb_in),
-                                    _ptr(rb.rb_out), n_out, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
-                                    _ptr(residual), _ptr(out), _stream()), "pp_spconv_fwd_rb")
-    if prof is not None:
-        e1.record()
-        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, 27, rb.pairs, residual is not None))
     return out
 
 
@@ -561,39 +558,78 @@ class ClusterCSR:
         return ClusterCSR(torch.cat(offs), torch.cat([p.points for p in parts]), sum(p.n for p in parts))
 
 
-def overlapping_pairs(csr, max_sources=64):
-    """Proposal pairs that share points, with their intersection sizes, from the point -> proposal incidence
-    (the sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  Returns int64 tensors (a, b, inter)
-    with a < b.  In the model a point belongs to one proposal per source (region growing on raw / shifted
-    coordinates, mean shift), so the multiplicity loop below runs 1-2 times; `max_sources` only bounds it."""
+class ProposalPairs:
+    """Overlapping proposal pairs on the device (pp_proposal_pairs): a[i] < b[i] share inter[i] points, i < n_pairs[0]
+    (device counter; the arrays have `capacity` slots, entries are in no particular order).  prop_of_entry int32 [total]
+    = proposal of every CSR entry.  info int32[4]: error counters, see `check`."""
+
+    def __init__(self, a, b, inter, n_pairs, capacity, prop_of_entry, info):
+        self.a, self.b, self.inter, self.n_pairs, self.capacity = a, b, inter, n_pairs, capacity
+        self.prop_of_entry, self.info = prop_of_entry, info
+
+    def check(self):
+        """one host read of the error counters (call where the host synchronises anyway)"""
+        over, full, bad_pt, bad_grp = self.info.tolist()
+        if over:
+            raise NotImplementedError("%d points belong to more than 8 proposals" % over)
+        if full:
+            raise _lib.PanopticHipError("proposal pair table overflow (%d): more than %d overlapping pairs" % (full, self.capacity))
+        if bad_pt or bad_grp:
+            raise _lib.PanopticHipError("proposal points / batch elements out of range (%d / %d)" % (bad_pt, bad_grp))
+
+
+def proposal_pairs(csr, n_points):
+    """Pairs of proposals that share points, with their intersection sizes, from the point -> proposal incidence (the
+    sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  No host synchronisation.  Cached on the csr."""
     cached = getattr(csr, "_pairs", None)
     if cached is not None:
         return cached
-    dev = csr.points.device
+    lib = _lib.load()
+    dev = csr.offsets.device
     P = csr.n
-    sizes = csr.sizes()
-    prop_of_entry = torch.repeat_interleave(torch.arange(P, device=dev), sizes)
-    order = torch.argsort(csr.points, stable=True)
-    sp, sq = csr.points[order], prop_of_entry[order]
-    mult = int(torch.unique_consecutive(sp, return_counts=True)[1].max().item()) if sp.numel() else 0
-    if mult > max_sources:
-        raise NotImplementedError("a point belongs to %d proposals (> %d)" % (mult, max_sources))
-    keys = []
-    for d in range(1, mult):
-        if sp.numel() <= d:
-            break
-        m = sp[d:] == sp[:-d]
-        x, y = sq[:-d][m], sq[d:][m]
-        keys.append(torch.minimum(x, y) * P + torch.maximum(x, y))
-    if not keys:
-        z = torch.zeros(0, dtype=torch.int64, device=dev)
-        csr._pairs = (z, z, z, prop_of_entry)
-        return csr._pairs
-    uniq, inter = torch.unique(torch.cat(keys), return_counts=True)
-    csr._pairs = (uniq // P, uniq % P, inter, prop_of_entry)
+    total = int(csr.points.numel())
+    cap = int(lib.pp_proposal_pairs_capacity(P))
+    a = torch.empty(cap, dtype=torch.int32, device=dev)
+    b = torch.empty(cap, dtype=torch.int32, device=dev)
+    inter = torch.empty(cap, dtype=torch.int32, device=dev)
+    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    poe = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    wsb = lib.pp_proposal_pairs_workspace(total, int(n_points), P)
+    ws = _ws(wsb, dev, tag="proposal_pairs")
+    _lib.check(lib.pp_proposal_pairs(_ptr(_need(csr.offsets, torch.int32, "offsets")), _ptr(_need(csr.points, torch.int64, "points")),
+                                     P, total, int(n_points), _ptr(poe), _ptr(a), _ptr(b), _ptr(inter), _ptr(n_pairs), _ptr(info),
+                                     _ptr(ws), wsb, _stream()), "pp_proposal_pairs")
+    csr._pairs = ProposalPairs(a, b, inter, n_pairs, cap, poe[:total], info)
     return csr._pairs
 
 
+def nms_paint(csr, n_points, batch, n_groups, scores, nms_threshold=0.3, min_cluster_points=10, min_score=0.5, pairs=None):
+    """get_instances (NMS, size and score filters; structure_3heads.py:28-71) + get_cur_ins_pre_label (tracker :326-337)
+    per batch element on the device: -> (labels int32 [n_points] (-1 = none), counts int32 [n_groups], rank int32 [P]
+    (-1 = dropped), ProposalPairs or None).  scores None = no ScoreNet.  No host synchronisation."""
+    lib = _lib.load()
+    dev = csr.offsets.device
+    P = csr.n
+    total = int(csr.points.numel())
+    labels = torch.empty(max(int(n_points), 1), dtype=torch.int32, device=dev)
+    counts = torch.empty(max(int(n_groups), 1), dtype=torch.int32, device=dev)
+    rank = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+    if pairs is None and P:
+        pairs = proposal_pairs(csr, n_points)
+    scores = None if scores is None else _need(scores.detach().float(), torch.float32, "scores")
+    batch = _need(batch, torch.int64, "batch")
+    cap = pairs.capacity if pairs is not None else 0
+    wsb = lib.pp_nms_paint_workspace(P, int(n_groups), cap)
+    ws = _ws(wsb, dev, tag="nms_paint")
+    z = None
+    _lib.check(lib.pp_nms_paint(_ptr(csr.offsets), _ptr(csr.points), P, total, int(n_points),
+                                _ptr(pairs.prop_of_entry) if pairs else z, _ptr(pairs.a) if pairs else z,
+                                _ptr(pairs.b) if pairs else z, _ptr(pairs.inter) if pairs else z,
+                                _ptr(pairs.n_pairs) if pairs else z, cap, _ptr(batch), int(n_groups), _ptr(scores),
+                                float(nms_threshold), int(min_cluster_points), float(min_score), _ptr(labels), _ptr(counts),
+                                _ptr(rank), _ptr(pairs.info) if pairs else z, _ptr(ws), wsb, _stream()), "pp_nms_paint")
+    return labels[: int(n_points)], counts[: int(n_groups)], rank[:P], pairs
 
 
 def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_cluster_size, num_classes):

@@ -254,11 +254,17 @@ class PointGroup3heads(nn.Module):
             # Region growing and mean shift often return the SAME point set for a well-separated instance; identical
             # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set
             # (results unchanged; the overlap pairs are reused by NMS).
-            a, b, inter, _ = ops.overlapping_pairs(csr)
+            pairs = ops.proposal_pairs(csr, backbone_features.shape[0])  # device-side; reused by the NMS of this batch
             sz = csr.sizes()
-            dup = (inter == sz[a]) & (inter == sz[b])
-            rep = torch.arange(csr.n, device=sz.device)
-            rep.scatter_reduce_(0, b[dup], a[dup], "amin", include_self=True)
+            n_prop = csr.n
+            valid = torch.arange(pairs.capacity, device=sz.device) < pairs.n_pairs
+            a = torch.where(valid, pairs.a.long(), 0)
+            b = torch.where(valid, pairs.b.long(), 0)
+            inter = pairs.inter.long()
+            dup = valid & (inter == sz[a]) & (inter == sz[b])
+            rep = torch.arange(n_prop + 1, device=sz.device)  # slot n_prop swallows the non-duplicates
+            rep.scatter_reduce_(0, torch.where(dup, b, n_prop), torch.where(dup, a, n_prop), "amin", include_self=True)
+            rep = rep[:n_prop]
             uniq_ids = torch.nonzero(rep == torch.arange(csr.n, device=sz.device)).view(-1)
             if uniq_ids.numel() < csr.n:
                 pos_of = torch.empty(csr.n, dtype=torch.int64, device=sz.device)

@@ -1,8 +1,7 @@
 """PanopticResults / PanopticLabels with the reference's field names and get_instances semantics
 (torch_points3d/models/panoptic/structure_3heads.py:6-71): proposal x proposal IoU, greedy NMS at `nms_threshold`,
-then the size and score filters.  The dense [nProp, N] mask matmul of the reference (:40-60) is replaced by the
-point->proposal incidence kernel (pp_proposal_intersections); the greedy pick itself stays on the host as in the
-reference (non_max_suppression works on numpy there too)."""
+then the size and score filters.  The dense [nProp, N] mask matmul of the reference (:40-60) and the host NMS loop are
+replaced by device kernels (csrc/pp_nms.hip: incidence pass, overlapping pairs, greedy NMS, ranks)."""
 from typing import List, NamedTuple, Optional
 
 import numpy as np
@@ -14,8 +13,9 @@ from .. import ops
 def non_max_suppression(ious, scores, threshold):
     """Greedy NMS over a dense IoU matrix (host form of structure_3heads.py:6-16, kept for callers that hold the dense
     matrix; the model path uses the device kernels behind ops.nms_paint).  Visits proposals by descending score
-    (`argsort()[::-1]`, i.e. the reference's tie order) and drops everything a kept proposal overlaps by > threshold."""
-    order = np.argsort(scores)[::-1]
+    and drops everything a kept proposal overlaps by > threshold.  Equal scores: descending index (stable sort reversed --
+    numpy's `argsort()[::-1]` on up to 16 elements; beyond that the reference's introsort leaves ties undefined)."""
+    order = np.argsort(scores, kind="stable")[::-1]
     alive = np.ones(len(order), dtype=bool)
     kept = []
     for i in order:
@@ -42,25 +42,23 @@ class PanopticResults(NamedTuple):
         return ops.ClusterCSR.from_list(self.clusters, self.semantic_logits.device)
 
     def get_instances(self, nms_threshold=0.3, min_cluster_points=100, min_score=0.5):
-        """Returns (indices of clusters that pass NMS + size + score tests, their point lists)."""
+        """Returns (indices of clusters that pass NMS + size + score tests, their point lists), best score first --
+        structure_3heads.py:28-71 with the dense [nProp, N] mask product replaced by the device kernels of
+        csrc/pp_nms.hip (the whole batch is one NMS group here, exactly like the reference's joint IoU matrix)."""
         if not self.clusters and (self.clusters_csr is None or self.clusters_csr.n == 0):
             return [], []
         if self.cluster_scores is None:
             return None, self.clusters if self.clusters is not None else self._csr().to_list()
         csr = self._csr()
         n_points = self.semantic_logits.shape[0]
-        inter = ops.proposal_intersections(csr, n_points).cpu().numpy().astype(np.float32)
-        sizes = np.diag(inter).copy()
-        cross_ious = inter / (sizes[:, None] + sizes[None, :] - inter)
-        pick_idxs = non_max_suppression(cross_ious, self.cluster_scores.detach().cpu().numpy(), nms_threshold)
-        scores = self.cluster_scores.detach().cpu().numpy()
+        _, _, rank, pairs = ops.nms_paint(csr, n_points, None, 1, self.cluster_scores, nms_threshold, min_cluster_points,
+                                          min_score)
+        rank = rank.cpu().numpy()
+        pairs.check()
+        kept = np.nonzero(rank >= 0)[0]
+        valid_pick_ids = [int(i) for i in kept[np.argsort(-rank[kept], kind="stable")]]  # pick order = descending score
         clusters = self.clusters if self.clusters is not None else csr.to_list()
-        valid_pick_ids, valid_clusters = [], []
-        for i in pick_idxs:
-            if sizes[i] > min_cluster_points and scores[i] > min_score:
-                valid_pick_ids.append(i)
-                valid_clusters.append(clusters[i])
-        return valid_pick_ids, valid_clusters
+        return valid_pick_ids, [clusters[i] for i in valid_pick_ids]
 
 
 class PanopticLabels(NamedTuple):

@@ -6,8 +6,8 @@ vote accumulation and the ORDER-DEPENDENT greedy `block_merging`
 (torch_points3d/metrics/panoptic_tracker_pointgroup_npm3d.py:147-277,326-337,339-452).
 
 Multi-GPU: tiles are sharded over ranks (longest-first round robin); each rank runs its tiles with no
-collective on the data path; ONE exchange step all-gathers the per-tile label arrays (+ origin ids, + semantic
-votes) so the merge can run in the original block order on every rank.  torch.distributed backend "nccl" is RCCL
+collective on the data path; ONE exchange step all-gathers the per-tile label arrays, origin ids and semantic vote
+contributions (`exchange_tile_results`) so the merge can run in the original block order on every rank.  torch.distributed backend "nccl" is RCCL
 on ROCm; the same code runs on gloo/CPU tensors for the world_size-2 tests.
 """
 import numpy as np
@@ -18,66 +18,23 @@ from .applications import Data
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
 from . import ops  # noqa: E402
-from .ops import overlapping_pairs  # noqa: E402,F401  (kept importable from here)
 
 
 def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
     """get_instances per batch element (NMS, size and score filters; structure_3heads.py:28-71) and
     get_cur_ins_pre_label (surviving clusters painted in ascending score order; tracker :326-337), for all tiles of the
-    batch at once: overlaps come from one device-side pass over the incidence, the greedy picks run on the host over
-    the few overlapping pairs (the reference runs NMS on the host too), painting is one scatter-max.
+    batch at once and entirely on the device (ops.nms_paint: incidence pass -> overlapping pairs -> per-tile greedy NMS
+    -> scatter-max painting).  The only host read is the per-tile instance counts.
     Returns int32 labels [N] (-1 = none; ids restart at 0 in every tile) and the number of instances per tile."""
-    dev = batch.device
     n = batch.shape[0]
-    labels = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    counts = [0] * n_tiles
     csr = res.clusters_csr
     if csr is None or csr.n == 0:
-        return labels, counts
-    P = csr.n
-    sizes_d = csr.sizes()
-    tile_of_prop = batch[csr.points[csr.offsets[:-1].long()]].cpu().numpy()
-    sizes = sizes_d.cpu().numpy()
-    rank_of_prop = np.full(P, -1, np.int32)
-    if res.cluster_scores is None:  # no ScoreNet: every proposal is an instance (structure_3heads.py:34-35)
-        a, b, inter, prop_of_entry = overlapping_pairs(csr)
-        for t in range(n_tiles):
-            ids = np.nonzero(tile_of_prop == t)[0]
-            rank_of_prop[ids] = np.arange(len(ids))
-            counts[t] = len(ids)
-    else:
-        a, b, inter, prop_of_entry = overlapping_pairs(csr)
-        iou = inter.float() / (sizes_d[a] + sizes_d[b] - inter).float()
-        hot = iou > nms_threshold
-        ea, eb = a[hot].cpu().numpy(), b[hot].cpu().numpy()
-        scores = res.cluster_scores.detach().float().cpu().numpy()
-        adj = {}
-        for x, y in zip(ea.tolist(), eb.tolist()):
-            adj.setdefault(x, []).append(y)
-            adj.setdefault(y, []).append(x)
-        for t in range(n_tiles):
-            ids = np.nonzero(tile_of_prop == t)[0]
-            if len(ids) == 0:
-                continue
-            sc = scores[ids]
-            suppressed = set()
-            pick = []
-            for j in sc.argsort()[::-1]:  # same ordering call as non_max_suppression (structure_3heads.py:6-16)
-                i = int(ids[j])
-                if i in suppressed:
-                    continue
-                pick.append(i)
-                suppressed.update(adj.get(i, ()))
-            keep = [i for i in pick if sizes[i] > min_cluster_points and scores[i] > min_score]
-            if keep:
-                order = [keep[j] for j in np.argsort(scores[keep], kind="stable")]
-                rank_of_prop[order] = np.arange(len(order))
-                counts[t] = len(order)
-    r = torch.from_numpy(rank_of_prop).to(dev)[prop_of_entry]
-    m = r >= 0
-    # ascending score = ascending rank: the best cluster covering a point wins -> max over paint ranks
-    labels.scatter_reduce_(0, csr.points[m], r[m], "amax", include_self=True)
-    return labels, counts
+        return torch.full((n,), -1, dtype=torch.int32, device=batch.device), [0] * n_tiles
+    labels, counts, _, pairs = ops.nms_paint(csr, n, batch, n_tiles, res.cluster_scores, nms_threshold, min_cluster_points,
+                                             min_score)
+    counts_h = counts.tolist()  # the synchronisation point of the step
+    pairs.check()
+    return labels, counts_h
 
 
 # ------------------------------------------------------------------------------------------------ scene assembly
@@ -171,50 +128,97 @@ def allgather_varlen(t, group=None):
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
-def exchange_tile_results(local, group=None):
-    """local: dict tile_id -> (origin_ids int64 [n], labels int32 [n]) on this rank (tensors on one device).
-    Returns the same dict for ALL tiles on every rank.  Two collectives per scene: a small one with the per-tile row
-    counts and ONE all-gather of a padded int32 [rows, 2] buffer (origin id, label: 8 B per point -- scenes have fewer
-    than 2^31 points; 64-bit ids fall back to an int64 buffer)."""
+def exchange_tile_results(local, group=None, device=None):
+    """local: dict tile_id -> (origin_ids int64 [n], labels int32 [n]) or (origin_ids, labels, semantic log-probs f32 [n,C])
+    on this rank (tensors on one device).  Returns the same dict for ALL tiles on every rank -- what the tracker's scene
+    assembly needs from every cylinder: the semantic vote contributions `votes[origin] += logits` and the per-cylinder
+    instance labels for the order-dependent block merging (panoptic_tracker_pointgroup_npm3d.py:244-245,277).
+    Two collectives per scene: a small header and ONE all-gather of a padded int32 [rows, 2 + C] buffer (origin id, label,
+    C float32 log-probs bit-cast to int32: 8 + 4C bytes per point; scenes have fewer than 2^31 points -- 64-bit ids fall back
+    to an int64 buffer plus a separate float buffer).  `device`: where the collective's buffers live when this rank owns
+    no tile (nccl/RCCL needs device tensors even for an empty contribution); default = the current HIP device under nccl."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dict(local)
     world = dist.get_world_size(group)
     ids = sorted(local)
-    dev = local[ids[0]][0].device if ids else torch.device("cpu")
-    if dist.get_backend(group) == "gloo":  # CPU collectives (tests / single-GPU dry runs)
-        local = {t: (local[t][0].cpu(), local[t][1].cpu()) for t in ids}
+    gloo = dist.get_backend(group) == "gloo"
+    if gloo:  # CPU collectives (tests / single-GPU dry runs)
+        local = {t: tuple(x.cpu() for x in local[t]) for t in ids}
         dev = torch.device("cpu")
+    elif ids:
+        dev = local[ids[0]][0].device
+    elif device is not None:
+        dev = torch.device(device)
+    else:  # a rank without tiles still joins the collectives, with device buffers
+        dev = torch.device("cuda", torch.cuda.current_device())
+    n_cls = max([local[t][2].shape[1] for t in ids if len(local[t]) > 2] + [0])
     meta = torch.tensor([[t, local[t][0].shape[0]] for t in ids], dtype=torch.int64, device=dev).reshape(-1, 2)
     origin = torch.cat([local[t][0] for t in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
     labels = torch.cat([local[t][1] for t in ids]) if ids else torch.zeros(0, dtype=torch.int32, device=dev)
-    # header: [rows, largest origin id, tiles] of this rank, then the (tile, rows) pairs
-    head = torch.tensor([origin.shape[0], int(origin.max().item()) if origin.numel() else 0, len(ids)],
+    # header: [rows, largest origin id, tiles, classes] of this rank, then the (tile, rows) pairs
+    head = torch.tensor([origin.shape[0], int(origin.max().item()) if origin.numel() else 0, len(ids), n_cls],
                         dtype=torch.int64, device=dev)
-    heads = torch.empty((world, 3), dtype=torch.int64, device=dev)
+    heads = torch.empty((world, 4), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(heads.view(-1), head, group=group)
     heads = heads.tolist()
     max_rows = max(max(h[0] for h in heads), 1)
     max_tiles = max(max(h[2] for h in heads), 1)
+    n_cls = max(h[3] for h in heads)
     wide = max(h[1] for h in heads) >= 2 ** 31
     dt = torch.int64 if wide else torch.int32
-    # one buffer per rank: max_tiles (tile, rows) pairs followed by max_rows (origin, label) pairs
-    send = torch.zeros((max_tiles + max_rows, 2), dtype=dt, device=dev)
-    send[: len(ids)] = meta.to(dt)
+    logits = None
+    if n_cls:
+        logits = torch.zeros((origin.shape[0], n_cls), dtype=torch.float32, device=dev)
+        pos = 0
+        for t in ids:
+            n_t = local[t][0].shape[0]
+            if len(local[t]) > 2:
+                logits[pos: pos + n_t] = local[t][2].float()
+            pos += n_t
+    pack_logits = n_cls > 0 and not wide
+    width = 2 + (n_cls if pack_logits else 0)
+    # one buffer per rank: max_tiles (tile, rows) pairs followed by max_rows (origin, label[, log-probs]) rows
+    send = torch.zeros((max_tiles + max_rows, width), dtype=dt, device=dev)
+    send[: len(ids), :2] = meta.to(dt)
     send[max_tiles: max_tiles + origin.shape[0], 0] = origin.to(dt)
     send[max_tiles: max_tiles + origin.shape[0], 1] = labels.to(dt)
+    if pack_logits:
+        send[max_tiles: max_tiles + origin.shape[0], 2:] = logits.view(torch.int32)
     recv = torch.empty((world,) + tuple(send.shape), dtype=dt, device=dev)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
-    metas = recv[:, :max_tiles].tolist()
+    all_logits = None
+    if pack_logits:
+        all_logits = recv[:, max_tiles:, 2:].contiguous().view(torch.float32)
+    elif n_cls:  # 64-bit ids: the float payload travels on its own
+        fsend = torch.zeros((max_rows, n_cls), dtype=torch.float32, device=dev)
+        fsend[: origin.shape[0]] = logits
+        all_logits = torch.empty((world, max_rows, n_cls), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(all_logits.view(-1), fsend.view(-1), group=group)
+    metas = recv[:, :max_tiles, :2].tolist()
     all_origin = recv[:, max_tiles:, 0].long()   # one conversion for the scene, per-tile results are views
     all_labels = recv[:, max_tiles:, 1].to(torch.int32)
     out = {}
     for r in range(world):
         pos = 0
         for t, n in metas[r][: heads[r][2]]:
-            out[int(t)] = (all_origin[r, pos: pos + n], all_labels[r, pos: pos + n])
+            item = (all_origin[r, pos: pos + n], all_labels[r, pos: pos + n])
+            if all_logits is not None:
+                item = item + (all_logits[r, pos: pos + n],)
+            out[int(t)] = item
             pos += n
     return out
+
+
+def assemble_scene(results, tile_order, n_scene_points, num_classes):
+    """Scene assembly from the exchanged per-tile results, in the ORIGINAL block order (the greedy merge is
+    order-dependent): semantic votes + prediction counts + merged instance labels.  Runs identically on every rank."""
+    asm = SceneAssembler(n_scene_points, num_classes)
+    for t in tile_order:
+        item = results[t]
+        origin = item[0].cpu().numpy()
+        asm.add_block(origin, item[1].cpu().numpy(), item[2].cpu().numpy() if len(item) > 2 else None)
+    return asm
 
 
 # ------------------------------------------------------------------------------------------------ the hot path over tiles

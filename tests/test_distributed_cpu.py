@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _tile_results(n_tiles, n_scene):
+def _tile_results(n_tiles, n_scene, with_votes=False):
     """deterministic fake per-tile outputs: (origin_ids, labels)"""
     out = {}
     for t in range(n_tiles):
@@ -31,15 +31,15 @@ def _tile_results(n_tiles, n_scene):
         for i in range(k):
             labels[cuts[i]: cuts[i + 1]] = i
         out[t] = (torch.from_numpy(origin.astype(np.int64)), torch.from_numpy(labels))
+        if with_votes:
+            out[t] = out[t] + (torch.from_numpy(rng.normal(size=(len(origin), 9)).astype(np.float32)),)
     return out
 
 
 def _assemble(results, n_scene):
-    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler
-    asm = SceneAssembler(n_scene, 9)
-    for t in sorted(results):  # original block order (the greedy merge is order dependent)
-        asm.add_block(results[t][0].numpy(), results[t][1].numpy())
-    return asm.ins_pre, asm.max_instance, asm.prediction_count
+    from panopticsegforlargescalepointcloud_amd.scene import assemble_scene
+    asm = assemble_scene(results, sorted(results), n_scene, 9)  # original block order (the greedy merge is order dependent)
+    return asm.ins_pre, asm.max_instance, asm.prediction_count, asm.votes
 
 
 def _worker(rank, world, port, n_tiles, n_scene, q):
@@ -47,15 +47,16 @@ def _worker(rank, world, port, n_tiles, n_scene, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results, shard_tiles
-    allr = _tile_results(n_tiles, n_scene)
+    allr = _tile_results(n_tiles, n_scene, with_votes=True)
     sizes = [len(allr[t][0]) for t in range(n_tiles)]
     mine = shard_tiles(sizes, world)[rank]
     local = {t: allr[t] for t in mine}
     full = exchange_tile_results(local)
     ok = sorted(full) == list(range(n_tiles)) and all(
-        torch.equal(full[t][0], allr[t][0]) and torch.equal(full[t][1], allr[t][1]) for t in range(n_tiles))
-    ins, mx, cnt = _assemble(full, n_scene)
-    q.put((rank, ok, ins.tobytes(), mx, int(cnt.sum())))
+        torch.equal(full[t][0], allr[t][0]) and torch.equal(full[t][1], allr[t][1]) and torch.equal(full[t][2], allr[t][2])
+        for t in range(n_tiles))
+    ins, mx, cnt, votes = _assemble(full, n_scene)
+    q.put((rank, ok, ins.tobytes(), mx, int(cnt.sum()), votes.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,10 +73,13 @@ def test_exchange_and_assembly_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref_ins, ref_mx, ref_cnt = _assemble(_tile_results(n_tiles, n_scene), n_scene)
-    for rank, ok, ins_bytes, mx, cnt in got:
+    # single-process reference: votes[origin] += log-probs, prediction_count += 1, block merging in block order
+    ref_ins, ref_mx, ref_cnt, ref_votes = _assemble(_tile_results(n_tiles, n_scene, with_votes=True), n_scene)
+    assert np.abs(ref_votes).sum() > 0
+    for rank, ok, ins_bytes, mx, cnt, votes_bytes in got:
         assert ok, "rank %d did not receive every tile intact" % rank
         assert ins_bytes == ref_ins.tobytes() and mx == ref_mx and cnt == int(ref_cnt.sum())
+        assert votes_bytes == ref_votes.tobytes(), "semantic votes of the assembled scene differ on rank %d" % rank
 
 
 def _worker_edge(rank, world, port, q):
@@ -85,11 +89,13 @@ def _worker_edge(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from panopticsegforlargescalepointcloud_amd.scene import exchange_tile_results
     big = 2 ** 31 + 5
-    allr = {3: (torch.arange(big, big + 40, dtype=torch.int64), torch.arange(40, dtype=torch.int32) % 7 - 1)}
+    g = torch.Generator().manual_seed(1)
+    allr = {3: (torch.arange(big, big + 40, dtype=torch.int64), torch.arange(40, dtype=torch.int32) % 7 - 1,
+                torch.randn(40, 9, generator=g))}
     local = dict(allr) if rank == 0 else {}
     full = exchange_tile_results(local)
     ok = sorted(full) == [3] and torch.equal(full[3][0], allr[3][0]) and torch.equal(full[3][1], allr[3][1])
-    ok = ok and full[3][0].dtype == torch.int64 and full[3][1].dtype == torch.int32
+    ok = ok and full[3][0].dtype == torch.int64 and full[3][1].dtype == torch.int32 and torch.equal(full[3][2], allr[3][2])
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -141,8 +147,26 @@ def _dp_worker(rank, world, port, q):
     if rank == 1:  # a parameter that got a gradient on ONE rank only must still be reduced on both
         model[5].weight.grad = torch.ones_like(model[5].weight)
     n_buckets = allreduce_gradients(list(model.parameters()), world, bucket_bytes=200_000)
-    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert model[5].bias.grad is None  # no rank produced a gradient for it: stays None (the optimizer skips it)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()])
     q.put((rank, n_buckets, flat.numpy().tobytes()))
+    # overlapped form: hooks launch the buckets during backward; parameters without a gradient on ANY rank keep grad None
+    from panopticsegforlargescalepointcloud_amd.training import GradientReducer
+    model2 = _dp_model()
+    reducer = GradientReducer(model2.parameters(), bucket_bytes=200_000)
+    torch.nn.functional.mse_loss(model2[:5](x), y).backward()
+    nb2 = reducer.finish()  # first step: the never-used layer sits in the first bucket (reverse order) and blocks it
+    unused_none = model2[5].weight.grad is None and model2[5].bias.grad is None
+    flat2 = torch.cat([p.grad.reshape(-1) for p in list(model2.parameters())[:-2]])
+    # second step through the same reducer (state is reset by finish)
+    for p in model2.parameters():
+        p.grad = None
+    before = reducer.launched_in_backward
+    torch.nn.functional.mse_loss(model2[:5](x), y).backward()
+    in_backward = reducer.launched_in_backward - before  # ... from the second step on it trails and the others overlap
+    reducer.finish()
+    flat3 = torch.cat([p.grad.reshape(-1) for p in list(model2.parameters())[:-2]])
+    q.put((rank, "hooks", nb2, in_backward, unused_none, flat2.numpy().tobytes(), bool(torch.equal(flat2, flat3))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -156,7 +180,9 @@ def test_gradient_allreduce_world2():
     procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in range(world))
+    msgs = [q.get(timeout=120) for _ in range(2 * world)]
+    got = sorted(m for m in msgs if m[1] != "hooks")
+    hooks = sorted((m for m in msgs if m[1] == "hooks"), key=lambda m: m[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -172,4 +198,17 @@ def test_gradient_allreduce_world2():
     want = ((grads[0] + grads[1]) / 2).numpy()
     for rank, n_buckets, blob in got:
         np.testing.assert_allclose(np.frombuffer(blob, np.float32), want, rtol=1e-6, atol=1e-7)
-        assert n_buckets == len(gradient_buckets(list(_dp_model().parameters()), 200_000)) and n_buckets >= 2
+        assert n_buckets == len(gradient_buckets(list(_dp_model().parameters())[::-1], 200_000)) and n_buckets >= 2
+    n_used = sum(p.numel() for p in list(_dp_model().parameters())[:-2])
+    for rank, _, nb2, in_backward, unused_none, blob, same_again in hooks:
+        assert nb2 >= 2 and unused_none and same_again
+        assert in_backward >= 1, "no bucket was launched before backward returned (no overlap)"
+        # used parameters: mean of the two ranks' gradients (model[5] got no gradient anywhere in this run)
+        grads2 = []
+        for r in range(world):
+            m = _dp_model()
+            xx, yy = _dp_batch(r)
+            torch.nn.functional.mse_loss(m[:5](xx), yy).backward()
+            grads2.append(torch.cat([p.grad.reshape(-1) for p in list(m.parameters())[:-2]]))
+        np.testing.assert_allclose(np.frombuffer(blob, np.float32), ((grads2[0] + grads2[1]) / 2).numpy(), rtol=1e-6, atol=1e-7)
+        assert len(np.frombuffer(blob, np.float32)) == n_used

@@ -615,36 +615,120 @@ def test_morton_order_and_derived_maps(ops, oracle):
     assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))
 
 
-def test_tile_schedule_changes_nothing_but_the_order(ops, oracle):
-    """pp_tile_order is a permutation grouping rows by (window, parity, mask); pp_spconv_fwd gives bit-identical output
-    with and without it (same per-row summation order), also with cat / BN / ReLU / residual fused."""
+def _mask_sort_rank(mask):
+    """numpy restatement of mo_remap (csrc/pp_maporder.hip): centre lowest, then faces, edges, corners (most significant)"""
+    cls = np.array([(k % 3 != 1) + ((k // 3) % 3 != 1) + (k // 9 != 1) for k in range(27)])
+    order = [k for c in (0, 1, 2, 3) for k in range(27) if cls[k] == c]
+    out = np.zeros(len(mask), np.int64)
+    for pos, k in enumerate(order):
+        out |= ((mask >> k) & 1) << pos
+    return out
+
+
+def test_map_order_and_slot_ordered_maps(ops, oracle):
+    """pp_map_order is a window-local permutation sorted by (batch, remapped neighbour mask, row); pp_map_permute /
+    pp_level_permute / pp_kernel_map_transpose(order) restate the map in slot order; pp_spconv_fwd on the slot-ordered
+    map + row_order is bit-identical to the plain map (same per-row summation order), incl. cat / BN / ReLU / residual."""
     rng = np.random.default_rng(32)
-    fine = surface(rng, n=5000, n_batch=2, extent=70)
-    fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
-    idx, _ = ops.block_index_build(dev(fine), 1, 4)
-    nbr = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1, want_mask=True)
-    mask = nbr.pp_mask.cpu().numpy().astype(np.int64)
-    want_mask = ((nbr.cpu().numpy() >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
-    assert np.array_equal(mask, want_mask)
-    order = ops.tile_order(dev(fine), nbr.pp_mask, 1, 1024)
-    o = order.cpu().numpy()
-    n = len(fine)
-    assert np.array_equal(np.sort(o), np.arange(n))
-    par = (fine[:, 1] & 1) | ((fine[:, 2] & 1) << 1) | ((fine[:, 3] & 1) << 2)
-    key = ((o // 1024).astype(np.int64) << 30) | (par[o].astype(np.int64) << 27) | mask[o]
-    assert np.all(np.diff(key) >= 0)
-    for cin, cout, c1 in [(16, 16, 0), (64, 64, 0), (32, 48, 32), (96, 80, 0)]:
-        x = rng.normal(size=(n, cin)).astype(np.float32)
-        x1 = rng.normal(size=(n, c1)).astype(np.float32) if c1 else None
-        w = (rng.normal(size=(27, cin + c1, cout)) * 0.1).astype(np.float32)
-        res = rng.normal(size=(n, cout)).astype(np.float32)
-        sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
-        kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
-        a = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), nbr, n, cout, 27, **kw)
-        b = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), nbr, n, cout, 27, row_order=order, **kw)
-        assert torch.equal(a, b)
-        want = oracle.spconv_fwd(x, w, nbr.cpu().numpy(), n, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
-        np.testing.assert_allclose(b.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    lib_window = ops._lib.load().pp_map_window()
+    for n_pts, n_batch in [(24000, 3), (300, 2), (1, 1)]:
+        fine = surface(rng, n=n_pts, n_batch=n_batch, extent=110)
+        fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+        n = len(fine)
+        idx, _ = ops.block_index_build(dev(fine), 1, 4)
+        nbr = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1, want_mask=True)
+        mask = nbr.pp_mask.cpu().numpy().astype(np.int64)
+        want_mask = ((nbr.cpu().numpy() >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
+        assert np.array_equal(mask, want_mask)
+        assert np.array_equal(ops.map_mask(nbr).cpu().numpy().astype(np.int64), want_mask)
+        order = ops.map_order(nbr.pp_mask, dev(fine))
+        o = order.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(o), np.arange(n))
+        assert np.array_equal(o // lib_window, np.arange(n) // lib_window)          # rows never leave their window
+        key = ((np.arange(n) // lib_window) << 50) | ((fine[o, 0].astype(np.int64) & 255) << 40) | (_mask_sort_rank(mask[o]) << 13) \
+            | (o % lib_window)
+        assert np.all(np.diff(key) > 0)
+        # renumbered level + same-level map in physical ids
+        coords_p, phys_of = ops.level_permute(dev(fine), order)
+        assert np.array_equal(coords_p.cpu().numpy(), fine[o])
+        inv = np.empty(n, np.int64)
+        inv[o] = np.arange(n)
+        assert np.array_equal(phys_of.cpu().numpy(), inv)
+        same = ops.map_permute(nbr, order, translate=phys_of).cpu().numpy()
+        assert np.array_equal(same, oracle.kernel_map(fine[o], fine[o], 3, 1, 1))
+        if n < 100:
+            continue
+        # cross-level maps: slot-major + order; transposed map from the slot-ordered strided one
+        coarse = np.unique(np.concatenate([fine[:, :1], fine[:, 1:] // 2 * 2], 1), axis=0).astype(np.int32)
+        coarse = coarse[ops.morton_order(dev(coarse), 2, 4).cpu().numpy()]
+        down = ops.kernel_map_bi(dev(coarse), idx, 3, 1, 1, want_mask=True)      # coarse rows gather fine (block-order) rows
+        od = ops.map_order(down.pp_mask, dev(coarse))
+        down_s = ops.map_permute(down, od, translate=phys_of)
+        od_np = od.cpu().numpy()
+        assert np.array_equal(down_s.cpu().numpy(), oracle.kernel_map(coarse[od_np], fine[o], 3, 1, 1))
+        up = ops.kernel_map_transpose(down_s, n, order=od)                        # rows = fine physical rows, values = coarse rows
+        assert np.array_equal(up.cpu().numpy(), oracle.kernel_map(fine[o], coarse, 3, 1, -1))
+        ou = ops.map_order(ops.map_mask(up), coords_p)
+        up_s = ops.map_permute(up, ou)
+        for (m_plain, m_slot, m_order, n_in, n_out, cin, cout, c1) in [
+                (dev(same), dev(same), None, n, n, 16, 16, 0),
+                (ops.map_permute(down, None, translate=phys_of), down_s, od, n, len(coarse), 32, 48, 32),
+                (up, up_s, ou, len(coarse), n, 64, 64, 0), (up, up_s, ou, len(coarse), n, 96, 80, 0)]:
+            x = rng.normal(size=(n_in, cin)).astype(np.float32)
+            x1 = rng.normal(size=(n_in, c1)).astype(np.float32) if c1 else None
+            w = (rng.normal(size=(27, cin + c1, cout)) * 0.1).astype(np.float32)
+            res = rng.normal(size=(n_out, cout)).astype(np.float32)
+            sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+            kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+            a = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), m_plain, n_out, cout, 27, **kw)
+            b = ops.spconv_fwd(dev(x), ops.pack_weight(dev(w)), m_slot, n_out, cout, 27, row_order=m_order, **kw)
+            assert torch.equal(a, b)
+            want = oracle.spconv_fwd(x, w, m_plain.cpu().numpy(), n_out, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
+            np.testing.assert_allclose(b.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
+                  ("transposed", 48, 48, 32)]
+
+
+@pytest.mark.parametrize("kind,c0,c1,cout", VARIANT_SHAPES)
+@pytest.mark.parametrize("rows_per_wave", [32, 64])
+@pytest.mark.parametrize("pipeline", [1, 3])
+def test_spconv_kernel_variants_match_oracle(ops, oracle, kind, c0, c1, cout, rows_per_wave, pipeline):
+    """Every variant of the pipelined kernel the benchmark selects by shape -- 32 / 64 rows per wave, both loop forms,
+    unsplit and split-K -- on >= 20 k-row same-level, strided and transposed maps with the fused second source (ME.cat),
+    folded BN, ReLU and residual, in fp32 (1e-4 vs the oracle) and with bfloat16 compute (oracle on rounded operands)."""
+    rng = np.random.default_rng(101)
+    fine = surface(rng, n=26000, n_batch=3, extent=120)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    out_c, in_c, sign = {"same": (fine, fine, 1), "strided": (coarse, fine, 1), "transposed": (fine, coarse, -1)}[kind]
+    nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
+    n_in, n_out = len(in_c), len(out_c)
+    assert n_out >= 10000 and max(n_in, n_out) >= 20000
+    x0 = rng.normal(size=(n_in, c0)).astype(np.float32)
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32) if c1 else None
+    W = (rng.normal(size=(27, c0 + c1, cout)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(n_out, cout)).astype(np.float32)
+    packed = ops.pack_weight(dev(W))
+    kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+    want = oracle.spconv_fwd(x0, W, nbr, n_out, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
+    rb = oracle.round_bf16
+    want_bf = oracle.spconv_fwd(rb(x0), rb(W), nbr, n_out, in1=None if x1 is None else rb(x1), scale=sc, shift=sh, relu=True,
+                                residual=res)
+    outs = []
+    for split in (1, 4):
+        got = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(rows_per_wave, pipeline, split), **kw)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+        outs.append(got)
+        got_bf = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, bf16=True, variant=(rows_per_wave, pipeline, split),
+                                **kw).cpu().numpy()
+        np.testing.assert_allclose(got_bf, want_bf, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want_bf).max())))
+    assert not torch.equal(outs[0], outs[1])  # split-K really took another summation order
+    # the unsplit variants share one summation order per row: bit-identical across rows-per-wave / loop forms
+    ref = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(32, 1, 1), **kw)
+    assert torch.equal(ref, outs[0])
 
 
 @pytest.mark.parametrize("block_bits", [0, 4, 5])
@@ -681,46 +765,6 @@ def test_block_index_maps_match_oracle(ops, oracle, block_bits):
     assert ops.block_index_build(dev(dup), 1, block_bits)[1] == 1
     with pytest.raises(Exception):
         ops.block_index_build(dev(fine[::-1].copy()), 1, block_bits)
-
-
-@pytest.mark.parametrize("cin,cout,n_pts", [(16, 16, 3000), (16, 32, 3000), (64, 64, 2000), (96, 96, 1500), (32, 48, 2500),
-                                           (192, 80, 1200), (16, 16, 1), (16, 16, 129), (48, 112, 700), (80, 80, 900), (112, 96, 500)])
-def test_spconv_rulebook_matches_oracle(ops, oracle, cin, cout, n_pts):
-    """block-compacted rulebook kernel (LDS-DMA gather, LDS accumulators) vs the oracle, incl. fused cat + epilogue."""
-    rng = np.random.default_rng(13)
-    coords = surface(rng, n=n_pts, n_batch=2 if n_pts > 200 else 1, extent=40)
-    n = len(coords)
-    nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
-    x = rng.normal(size=(n, cin)).astype(np.float32)
-    W = (rng.normal(size=(27, cin, cout)) / np.sqrt(27 * cin / 4)).astype(np.float32)
-    rb = ops.rulebook_build(dev(nbr))
-    # rulebook invariants: every (k, out row) pair appears exactly once
-    off = rb.off.cpu().numpy()
-    rin, rout = rb.rb_in.cpu().numpy(), rb.rb_out.cpu().numpy()
-    assert rb.total == off[-1] and rb.total % 16 == 0
-    pairs = 0
-    RBR = 64  # RB_ROWS in csrc/pp_spconv_rb.hip
-    for b in range(len(off) // 28):
-        for k in range(27):
-            lo, hi = off[b * 28 + k], off[b * 28 + k + 1]
-            act = rout[lo:hi] >= 0
-            rows = b * RBR + rout[lo:hi][act]
-            assert np.array_equal(nbr[k][rows], rin[lo:hi][act])
-            assert np.array_equal(np.nonzero(nbr[k][b * RBR: b * RBR + RBR] >= 0)[0], rout[lo:hi][act])
-            pairs += act.sum()
-    assert pairs == (nbr >= 0).sum()
-    want = oracle.spconv_fwd(x, W, nbr, n)
-    got = ops.spconv_fwd_rb(dev(x), ops.pack_weight(dev(W)), rb, cout)
-    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
-    if cin >= 32:
-        h = cin // 2 // 16 * 16
-        sc = rng.normal(size=cout).astype(np.float32)
-        sh = rng.normal(size=cout).astype(np.float32)
-        res = rng.normal(size=(n, cout)).astype(np.float32)
-        want = oracle.spconv_fwd(x[:, :h], W, nbr, n, in1=x[:, h:], scale=sc, shift=sh, relu=True, residual=res)
-        got = ops.spconv_fwd_rb(dev(x[:, :h].copy()), ops.pack_weight(dev(W)), rb, cout, in1=dev(x[:, h:].copy()),
-                                scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
-        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
 def test_voxelize_and_cylinder_tiles_match_oracle(ops, oracle):
