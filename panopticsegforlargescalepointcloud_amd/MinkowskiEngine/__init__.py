@@ -13,6 +13,7 @@ open-addressing hash per tensor stride, offset-major kernel maps) shared by ever
 Use as a drop-in:   import panopticsegforlargescalepointcloud_amd.MinkowskiEngine as ME
 or                  sys.modules["MinkowskiEngine"] = panopticsegforlargescalepointcloud_amd.MinkowskiEngine
 """
+import enum
 import math
 import os
 import threading
@@ -283,6 +284,17 @@ class CoordinateManager:
         self._use(key)
         return m
 
+    def kernel_map_rows(self, ts_from, ts_to, ksize, sign):
+        """the same map indexed by PHYSICAL output rows (un-slotted copy of a cross-level map; same-level maps are
+        returned as they are) -- for consumers outside the convolution kernels (tests, reference-style gather loops)"""
+        m = self.kernel_map(ts_from, ts_to, ksize, sign)
+        order = getattr(m, "pp_order", None)
+        if m is None or order is None:
+            return m
+        rows = torch.empty_like(m)
+        rows[:, order.long()] = m
+        return rows
+
     def _kernel_map_locked(self, key):
         ts_from, ts_to, ksize, sign = key
         m = self.maps.get(key)
@@ -497,6 +509,24 @@ class _AffineFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # modules
 # ------------------------------------------------------------------------------------------------
+class RegionType(enum.Enum):
+    """kernel shapes ME knows; the reference's modules/MinkowskiEngine/common.py:53-62 builds lookup tables from these
+    at import time.  Only HYPER_CUBE kernels (what every panoptic config uses) are implemented."""
+    HYPER_CUBE = 0
+    HYPER_CROSS = 1
+    CUSTOM = 2
+
+
+class KernelGenerator:
+    """ME.KernelGenerator as the reference's conv helpers (common.py:117-190) construct it: a record of the kernel
+    geometry, accepted by the convolution constructors through `kernel_generator=`."""
+
+    def __init__(self, kernel_size=-1, stride=1, dilation=1, region_type=RegionType.HYPER_CUBE, axis_types=None,
+                 dimension=-1, **kwargs):
+        self.kernel_size, self.kernel_stride, self.kernel_dilation = kernel_size, stride, dilation
+        self.region_type, self.axis_types, self.dimension = region_type, axis_types, dimension
+
+
 class MinkowskiNetwork(nn.Module):
     def __init__(self, D):
         super().__init__()
@@ -519,6 +549,11 @@ class _ConvBase(nn.Module):
         super().__init__()
         if dimension not in (3, -1):
             raise NotImplementedError("only 3-D sparse convolutions are implemented")
+        if kernel_generator is not None:
+            if kernel_generator.region_type is not RegionType.HYPER_CUBE:
+                raise NotImplementedError("only HYPER_CUBE kernels are implemented (what the panoptic configs use)")
+            if kernel_size == -1:
+                kernel_size = kernel_generator.kernel_size
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.kernel_size = _to_int(kernel_size, "kernel_size")

@@ -718,7 +718,7 @@ def test_spconv_kernel_variants_match_oracle(ops, oracle, kind, c0, c1, cout, ro
     want_bf = oracle.spconv_fwd(rb(x0), rb(W), nbr, n_out, in1=None if x1 is None else rb(x1), scale=sc, shift=sh, relu=True,
                                 residual=res)
     outs = []
-    for split in (1, 4):
+    for split in (1, 2):  # (split 2: the partial sums of 78 k rows x 64 channels fit the default 64 MiB scratch)
         got = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(rows_per_wave, pipeline, split), **kw)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
         outs.append(got)

@@ -95,6 +95,32 @@ def test_build_owned_settings_yaml(name, spec):
     _check_setting(cfg, *spec[1:])
 
 
+def _structure_matches_fixture(device):
+    """the build-owned networks vs tests/golden/structure_fixture.json, which tests/test_reference_binding.py derives from
+    the REFERENCE's api_modules.py / applications/minkowski.py executing on the shim (build container only)"""
+    import json
+    from panopticsegforlargescalepointcloud_amd.applications import Minkowski
+    from panopticsegforlargescalepointcloud_amd.config import load_model_config
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "structure_fixture.json")))["networks"]
+    for name in ["setting-I", "setting-II", "setting-III", "setting-IV", "setting-V"]:
+        cfg = load_model_config(os.path.join(ROOT, "conf", "panoptic_settings.yaml"), name, data={"grid_size": 0.05})
+        for part, input_nc, conf in [("Backbone", 4, cfg.backbone.config), ("ScorerUnet", 16, cfg.scorer_unet)]:
+            net = Minkowski("unet", input_nc=input_nc, num_layers=4, config=conf).to(device)
+            assert {k: list(v.shape) for k, v in net.state_dict().items()} == fx[part]
+            assert list(net.state_dict()) == sorted(fx[part], key=list(net.state_dict()).index)
+
+
+def test_structure_fixture_cpu():
+    _structure_matches_fixture("cpu")
+
+
+@pytest.mark.gpu
+def test_structure_fixture_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    _structure_matches_fixture("cuda")
+
+
 def test_config_resolver_keeps_non_expressions():
     from panopticsegforlargescalepointcloud_amd.config import resolve
     cfg = {"a": "2*in_feat", "b": "max", "c": "ResNetDown", "d": ["FEAT", "in_feat"], "e": "1.5 * 0.05"}

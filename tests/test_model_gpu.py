@@ -119,8 +119,8 @@ def test_training_step_runs_and_matches_torch_autograd(setup):
     loss.backward()
     # dense re-implementation with index_add on the same kernel maps
     cm = st.coordinate_manager
-    down = cm.kernel_map(1, 2, 3, 1).long()
-    upm = cm.kernel_map(2, 1, 3, -1).long()
+    down = cm.kernel_map_rows(1, 2, 3, 1).long()   # indexed by physical output rows (the conv kernels use slot order)
+    upm = cm.kernel_map_rows(2, 1, 3, -1).long()
     x2 = x.detach().clone().requires_grad_(True)
     w1 = conv.kernel.detach().clone().requires_grad_(True)
     w2 = up.kernel.detach().clone().requires_grad_(True)
