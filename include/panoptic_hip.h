@@ -405,6 +405,31 @@ int pp_nms_paint(const int32_t* prop_offsets, const int64_t* prop_points, int32_
                  pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * f2 / f3  scene assembly and final evaluation on the device (csrc/pp_eval.hip)
+ * pp_histogram2d   out[a[i]][b[i]] += 1 (int64 [na][nb], zeroed by the callee): the class confusion matrix and the
+ *                  instance x class tables of the final evaluation, torch_points3d/datasets/panoptic/npm3d.py:107-397,
+ *                  metrics/panoptic_tracker_pointgroup_npm3d.py:711-879.  Rows with a negative label are skipped.
+ *                  info int32[2] = {rows skipped, rows out of range (must be 0)}.
+ * pp_pair_counts   distinct (a[i], b[i]) pairs (both >= 0, b < nb) with their multiplicities: the (prediction,
+ *                  ground truth) instance contingency table of npm3d.py:232-300 in sparse form.  Outputs have `capacity`
+ *                  slots, n_pairs (device int32) pairs are written in no particular order.
+ *                  info int32[2] = {overflow: raise capacity, rows with b >= nb}.
+ * pp_block_merge   block_merging of metrics/panoptic_tracker_pointgroup_npm3d.py:339-452 for ONE cylinder, in place on
+ *                  the scene labels (int64, -1 = none): blocks must be fed in the original block order.  block_labels
+ *                  int32 in [-1, n).  max_instance: device int64[1], carried from block to block.  state int32[8] (device):
+ *                  {any_has, any_none, any_valid, t_num, overflow, bad ids, n_pairs, 0}; overflow / bad must be 0.
+ * ---------------------------------------------------------------------------------------------- */
+int pp_histogram2d(const int64_t* a, const int64_t* b, int64_t n, int32_t na, int32_t nb, int64_t* out, int32_t* info,
+                   pp_stream_t stream);
+size_t pp_pair_counts_workspace(int64_t capacity);
+int pp_pair_counts(const int64_t* a, const int64_t* b, int64_t n, int64_t nb, int64_t capacity, int64_t* pair_a,
+                   int64_t* pair_b, int64_t* count, int32_t* n_pairs, int32_t* info, void* workspace, size_t workspace_bytes,
+                   pp_stream_t stream);
+size_t pp_block_merge_workspace(int64_t n);
+int pp_block_merge(const int64_t* origin_ids, const int32_t* block_labels, int64_t n, int64_t* scene_labels, int64_t n_scene,
+                   int64_t* max_instance, int32_t* state, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Row gather                      replaces: features[perm] / features[inverse] around ME.SparseTensor (.F in caller order,
  *                                 applications/minkowski.py:193) and backbone_features[cluster] in _compute_score,
  *                                 PointGroup3heads.py:400-410

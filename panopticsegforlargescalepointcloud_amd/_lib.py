@@ -42,6 +42,11 @@ SIGNATURES = {
     "pp_proposal_pairs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_nms_paint_workspace": (sz, [i32, i32, i64]),
     "pp_nms_paint": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, i64, vp, i32, vp, f32, i32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_histogram2d": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp]),
+    "pp_pair_counts_workspace": (sz, [i64]),
+    "pp_pair_counts": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_block_merge_workspace": (sz, [i64]),
+    "pp_block_merge": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, sz, vp]),
     "pp_map_window": (i32, []),
     "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
     "pp_map_order": (C.c_int, [vp, vp, i64, vp, vp]),

@@ -632,6 +632,76 @@ def nms_paint(csr, n_points, batch, n_groups, scores, nms_threshold=0.3, min_clu
     return labels[: int(n_points)], counts[: int(n_groups)], rank[:P], pairs
 
 
+def histogram2d(a, b, na, nb):
+    """int64 [na, nb]: out[a[i], b[i]] += 1 over the rows with a >= 0 and b >= 0 (confusion matrix, instance x class
+    tables).  Labels outside [0, na) x [0, nb) raise (one host read of the error counters)."""
+    lib = _lib.load()
+    a = _need(a, torch.int64, "a")
+    b = _need(b, torch.int64, "b")
+    out = torch.empty((int(na), int(nb)), dtype=torch.int64, device=a.device)
+    info = torch.zeros(2, dtype=torch.int32, device=a.device)
+    _lib.check(lib.pp_histogram2d(_ptr(a), _ptr(b), a.shape[0], int(na), int(nb), _ptr(out), _ptr(info), _stream()), "pp_histogram2d")
+    out.pp_info = info
+    return out
+
+
+def pair_counts(a, b, nb, capacity=None):
+    """distinct (a[i], b[i]) pairs with a, b >= 0 and their multiplicities: (pair_a, pair_b, count) int64 tensors,
+    sorted by (a, b).  One host synchronisation (the number of pairs)."""
+    lib = _lib.load()
+    a = _need(a, torch.int64, "a")
+    b = _need(b, torch.int64, "b")
+    dev = a.device
+    n = a.shape[0]
+    cap = int(capacity or max(4096, min(n, 1 << 22)))
+    while True:
+        pa = torch.empty(cap, dtype=torch.int64, device=dev)
+        pb = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = torch.empty(cap, dtype=torch.int64, device=dev)
+        n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+        info = torch.zeros(2, dtype=torch.int32, device=dev)
+        wsb = lib.pp_pair_counts_workspace(cap)
+        ws = _ws(wsb, dev, tag="pair_counts")
+        _lib.check(lib.pp_pair_counts(_ptr(a), _ptr(b), n, int(nb), cap, _ptr(pa), _ptr(pb), _ptr(cnt), _ptr(n_pairs), _ptr(info),
+                                      _ptr(ws), wsb, _stream()), "pp_pair_counts")
+        k = int(n_pairs.item())
+        over, bad = info.tolist()
+        if bad:
+            raise _lib.PanopticHipError("pair_counts: %d labels >= nb" % bad)
+        if not over:
+            break
+        cap *= 4
+    pa, pb, cnt = pa[:k], pb[:k], cnt[:k]
+    order = torch.argsort(pa * int(nb) + pb)
+    return pa[order], pb[order], cnt[order]
+
+
+def block_merge(origin_ids, block_labels, scene_labels, max_instance, state=None):
+    """block_merging of the tracker (panoptic_tracker_pointgroup_npm3d.py:339-452) for one cylinder, in place on the
+    device: scene_labels int64 [N] (-1 = none), max_instance int64 [1] device tensor carried from block to block.
+    Returns the int32[8] state tensor (check with block_merge_check; no synchronisation here)."""
+    lib = _lib.load()
+    origin_ids = _need(origin_ids, torch.int64, "origin_ids")
+    block_labels = _need(block_labels, torch.int32, "block_labels")
+    scene_labels = _need(scene_labels, torch.int64, "scene_labels")
+    max_instance = _need(max_instance, torch.int64, "max_instance")
+    dev = scene_labels.device
+    n = origin_ids.shape[0]
+    if state is None:
+        state = torch.zeros(8, dtype=torch.int32, device=dev)
+    wsb = lib.pp_block_merge_workspace(n)
+    ws = _ws(wsb, dev, tag="block_merge")
+    _lib.check(lib.pp_block_merge(_ptr(origin_ids), _ptr(block_labels), n, _ptr(scene_labels), scene_labels.shape[0],
+                                  _ptr(max_instance), _ptr(state), _ptr(ws), wsb, _stream()), "pp_block_merge")
+    return state
+
+
+def block_merge_check(state):
+    st = state.tolist()
+    if st[4] or st[5]:
+        raise _lib.PanopticHipError("block_merge: table overflow %d, bad ids / labels %d" % (st[4], st[5]))
+
+
 def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_cluster_size, num_classes):
     lib = _lib.load()
     pos = _need(pos, torch.float32, "pos")

@@ -56,6 +56,44 @@ def thing_panoptic_quality(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes, io
     return out
 
 
+def _finish_evaluation(out, iou, have, sem_final, things, stuff, C, p_size, p_cls, g_size, g_cls, best_p, best_g, iou_threshold):
+    """per-class coverage / precision / recall / RQ / SQ / PQ from the per-instance tables (shared by the NumPy and the
+    device front-end)"""
+    mucov, mwcov, prec, rec, rq, sq, pq = (np.zeros(C) for _ in range(7))
+    for c in range(C):
+        gm, pm = g_cls == c, p_cls == c
+        if gm.any() and pm.any():
+            mucov[c] = best_g[gm].mean()
+            mwcov[c] = (best_g[gm] * g_size[gm]).sum() / g_size[gm].sum()
+        if pm.any():
+            tp_mask = pm & (best_p >= iou_threshold) & bool(gm.any())
+            tp = float(tp_mask.sum())
+            prec[c] = tp / pm.sum()
+            rec[c] = tp / gm.sum() if gm.any() else 0.0
+            rq[c] = 2 * prec[c] * rec[c] / (prec[c] + rec[c]) if prec[c] + rec[c] > 0 else 0.0
+            sq[c] = best_p[tp_mask].sum() / tp if tp else 0.0
+            pq[c] = sq[c] * rq[c]
+    thing_only = np.zeros(C, bool)
+    thing_only[things] = True
+    prec, rec, rq, sq, pq = (np.where(thing_only, v, 0.0) for v in (prec, rec, rq, sq, pq))
+    for c in stuff:
+        ok = iou[c] >= iou_threshold
+        rq[c], sq[c] = (1.0, iou[c]) if ok else (0.0, 0.0)
+        pq[c] = rq[c] * sq[c]
+    things_final = [c for c in things if have[c]]
+    stuff_final = [c for c in stuff if have[c]]
+    mp, mr = float(np.mean(prec[things_final])), float(np.mean(rec[things_final]))
+    out.update({
+        "MUCov": mucov[things], "mMUCov": float(np.mean(mucov[things_final])), "MWCov": mwcov[things],
+        "mMWCov": float(np.mean(mwcov[things_final])), "Precision": prec[things], "mPrecision": mp, "Recall": rec[things],
+        "mRecall": mr, "F1": 2 * mp * mr / (mp + mr) if mp + mr > 0 else 0.0,
+        "RQ": rq[1:], "SQ": sq[1:], "PQ": pq[1:], "meanRQ": float(np.mean(rq[sem_final])), "meanSQ": float(np.mean(sq[sem_final])),
+        "meanPQ": float(np.mean(pq[sem_final])), "PQ_things": pq[things], "meanRQ_things": float(np.mean(rq[things_final])),
+        "meanSQ_things": float(np.mean(sq[things_final])), "meanPQ_things": float(np.mean(pq[things_final])),
+        "PQ_stuff": pq[stuff], "meanPQ_stuff": float(np.mean(pq[stuff_final])) if stuff_final else 0.0})
+    return out
+
+
 def panoptic_evaluation(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes=(2, 3, 4, 6, 7, 8), stuff_classes=(0, 1, 5),
                         num_classes=9, iou_threshold=0.5):
     """The reference's final scene evaluation (torch_points3d/datasets/panoptic/npm3d.py:107-397, `final_eval`) restated
@@ -108,36 +146,58 @@ def panoptic_evaluation(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes=(2, 3,
     np.maximum.at(best_p, pa[same], pair_iou[same])
     best_g = np.zeros(len(g_size))
     np.maximum.at(best_g, ga[same], pair_iou[same])
-    mucov, mwcov, prec, rec, rq, sq, pq = (np.zeros(C) for _ in range(7))
-    for c in range(C):
-        gm, pm = g_cls == c, p_cls == c
-        if gm.any() and pm.any():
-            mucov[c] = best_g[gm].mean()
-            mwcov[c] = (best_g[gm] * g_size[gm]).sum() / g_size[gm].sum()
-        if pm.any():
-            tp_mask = pm & (best_p >= iou_threshold) & bool(gm.any())
-            tp = float(tp_mask.sum())
-            prec[c] = tp / pm.sum()
-            rec[c] = tp / gm.sum() if gm.any() else 0.0
-            rq[c] = 2 * prec[c] * rec[c] / (prec[c] + rec[c]) if prec[c] + rec[c] > 0 else 0.0
-            sq[c] = best_p[tp_mask].sum() / tp if tp else 0.0
-            pq[c] = sq[c] * rq[c]
-    thing_only = np.zeros(C, bool)
-    thing_only[things] = True
-    prec, rec, rq, sq, pq = (np.where(thing_only, v, 0.0) for v in (prec, rec, rq, sq, pq))
-    for c in stuff:
-        ok = iou[c] >= iou_threshold
-        rq[c], sq[c] = (1.0, iou[c]) if ok else (0.0, 0.0)
-        pq[c] = rq[c] * sq[c]
-    things_final = [c for c in things if have[c]]
-    stuff_final = [c for c in stuff if have[c]]
-    mp, mr = float(np.mean(prec[things_final])), float(np.mean(rec[things_final]))
-    out.update({
-        "MUCov": mucov[things], "mMUCov": float(np.mean(mucov[things_final])), "MWCov": mwcov[things],
-        "mMWCov": float(np.mean(mwcov[things_final])), "Precision": prec[things], "mPrecision": mp, "Recall": rec[things],
-        "mRecall": mr, "F1": 2 * mp * mr / (mp + mr) if mp + mr > 0 else 0.0,
-        "RQ": rq[1:], "SQ": sq[1:], "PQ": pq[1:], "meanRQ": float(np.mean(rq[sem_final])), "meanSQ": float(np.mean(sq[sem_final])),
-        "meanPQ": float(np.mean(pq[sem_final])), "PQ_things": pq[things], "meanRQ_things": float(np.mean(rq[things_final])),
-        "meanSQ_things": float(np.mean(sq[things_final])), "meanPQ_things": float(np.mean(pq[things_final])),
-        "PQ_stuff": pq[stuff], "meanPQ_stuff": float(np.mean(pq[stuff_final])) if stuff_final else 0.0})
-    return out
+    return _finish_evaluation(out, iou, have, sem_final, things, stuff, C, p_size, p_cls, g_size, g_cls, best_p, best_g,
+                              iou_threshold)
+
+
+def panoptic_evaluation_device(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes=(2, 3, 4, 6, 7, 8), stuff_classes=(0, 1, 5),
+                               num_classes=9, iou_threshold=0.5):
+    """`panoptic_evaluation` for device tensors: everything that touches the N points runs on the GPU -- the class
+    confusion matrix and the instance x class tables through pp_histogram2d, the (prediction, ground truth) instance
+    contingency table through pp_pair_counts (csrc/pp_eval.hip); what is left on the host are tables with one row per
+    instance or class.  Same quantities, same quirks, same results as the NumPy version above."""
+    import torch
+    from .. import ops
+    C = num_classes + 1
+    ps_all = pred_sem.reshape(-1).long() + 1
+    gs_all = gt_sem.reshape(-1).long() + 1
+    pi_all, gi_all = pred_ins.reshape(-1).long(), gt_ins.reshape(-1).long()
+    dev = ps_all.device
+    things = np.asarray(thing_classes, np.int64) + 1
+    stuff = np.asarray(stuff_classes, np.int64) + 1
+    # ---- semantic part: one confusion matrix (ground truth x prediction)
+    conf = ops.histogram2d(gs_all, ps_all, C, C).cpu().numpy().astype(np.float64)
+    gt_cnt, pr_cnt, tp_cnt = conf.sum(1), conf.sum(0), np.diag(conf).copy()
+    have = gt_cnt > 0
+    iou = np.where(have, tp_cnt / np.maximum(gt_cnt + pr_cnt - tp_cnt, 1), 0.0)
+    sem_final = [c for c in range(1, C) if have[c]]
+    out = {"oAcc": tp_cnt.sum() / pr_cnt.sum(), "mAcc": float(np.mean(tp_cnt[sem_final] / gt_cnt[sem_final])),
+           "IoU": iou, "mIoU": float(iou.sum() / len(sem_final))}
+    # ---- instances: only points that are thing in gt or prediction
+    is_thing = torch.zeros(C, dtype=torch.bool, device=dev)
+    is_thing[torch.from_numpy(things).to(dev)] = True
+    keep = is_thing[gs_all] | is_thing[ps_all]
+    ps, gs, pi, gi = ps_all[keep], gs_all[keep], pi_all[keep], gi_all[keep]
+
+    def groups(ids, sem):
+        m = ids != -1
+        u, inv = torch.unique(ids[m], return_inverse=True)
+        full = torch.full_like(ids, -1)
+        full[m] = inv
+        k = int(u.numel())
+        if k == 0:
+            return full, np.zeros(0, np.int64), np.zeros(0, np.int64)
+        table = ops.histogram2d(full, sem, k, C).cpu().numpy()      # rows with full == -1 are skipped by the kernel
+        return full, table.sum(1), table.argmax(1)
+    pid, p_size, p_cls = groups(pi, ps)
+    gid, g_size, g_cls = groups(gi, gs)
+    ng = max(len(g_size), 1)
+    pa, ga, inter = (t.cpu().numpy() for t in ops.pair_counts(pid, gid, ng))
+    pair_iou = inter / (p_size[pa] + g_size[ga] - inter) if len(pa) else np.zeros(0)
+    same = p_cls[pa] == g_cls[ga] if len(pa) else np.zeros(0, bool)
+    best_p = np.zeros(len(p_size))
+    np.maximum.at(best_p, pa[same], pair_iou[same])
+    best_g = np.zeros(len(g_size))
+    np.maximum.at(best_g, ga[same], pair_iou[same])
+    return _finish_evaluation(out, iou, have, sem_final, things, stuff, C, p_size, p_cls, g_size, g_cls, best_p, best_g,
+                              iou_threshold)

@@ -101,6 +101,40 @@ class SceneAssembler:
         return self.votes.argmax(1)
 
 
+class SceneAssemblerGPU:
+    """SceneAssembler with every per-point array resident on the device: votes / prediction counts are index_add_'s, the
+    order-dependent block merging is ops.block_merge (csrc/pp_eval.hip) chained on the stream -- no host round trip per
+    block; `finish()` reads the error counters once.  Results equal SceneAssembler's bit for bit."""
+
+    def __init__(self, n_scene_points, num_classes, device):
+        self.votes = torch.zeros((n_scene_points, num_classes), dtype=torch.float32, device=device)
+        self.prediction_count = torch.zeros(n_scene_points, dtype=torch.int32, device=device)
+        self.ins_pre = torch.full((n_scene_points,), -1, dtype=torch.int64, device=device)
+        self._max_instance = torch.zeros(1, dtype=torch.int64, device=device)
+        self._states = []
+
+    def add_block(self, origin_ids, labels, semantic_logits=None):
+        origin_ids = origin_ids.to(self.ins_pre.device).long()
+        if semantic_logits is not None:
+            self.votes.index_add_(0, origin_ids, semantic_logits.to(self.votes.device).float())
+        self.prediction_count.index_add_(0, origin_ids, torch.ones_like(origin_ids, dtype=torch.int32))
+        self._states.append(ops.block_merge(origin_ids, labels.to(self.ins_pre.device).to(torch.int32), self.ins_pre,
+                                            self._max_instance))
+
+    def finish(self):
+        for st in self._states:
+            ops.block_merge_check(st)
+        self._states = []
+        return self
+
+    @property
+    def max_instance(self):
+        return int(self._max_instance.item())
+
+    def semantic_prediction(self):
+        return self.votes.argmax(1)
+
+
 # ------------------------------------------------------------------------------------------------ sharding / exchange
 def shard_tiles(tile_sizes, world_size):
     """Static longest-first round robin. Returns list (per rank) of tile ids, ascending within a rank."""

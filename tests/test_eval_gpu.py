@@ -1,0 +1,126 @@
+"""GPU: scene assembly (block merging) and final evaluation on the device (csrc/pp_eval.hip) vs the NumPy restatements
+(scene.block_merging / SceneAssembler, panoptic/metrics.panoptic_evaluation) and vs the numbers the reference's own
+final_eval logs (tests/golden/final_eval_cases.npz).  Integer work: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    from panopticsegforlargescalepointcloud_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_histogram2d_and_pair_counts(ops):
+    rng = np.random.default_rng(0)
+    for n, na, nb in [(0, 3, 4), (1, 1, 1), (100_000, 10, 10), (300_000, 700, 10), (200_000, 3000, 40)]:
+        a = rng.integers(-1, na, size=n)
+        b = rng.integers(-1, nb, size=n)
+        want = np.zeros((na, nb), np.int64)
+        m = (a >= 0) & (b >= 0)
+        np.add.at(want, (a[m], b[m]), 1)
+        got = ops.histogram2d(dev(a), dev(b), na, nb)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert got.pp_info.tolist() == [int((~m).sum()), 0]
+        if n:
+            pa, pb, cnt = (t.cpu().numpy() for t in ops.pair_counts(dev(a), dev(b), nb, capacity=64))  # forces the retry path
+            wa, wb = np.nonzero(want)
+            assert np.array_equal(pa, wa) and np.array_equal(pb, wb) and np.array_equal(cnt, want[wa, wb])
+    # sorted labels (the realistic case: long runs of equal pairs -> one atomic per run)
+    a = np.repeat(np.arange(50), 4000)
+    b = np.repeat(np.arange(100), 2000)
+    pa, pb, cnt = (t.cpu().numpy() for t in ops.pair_counts(dev(a), dev(b), 100))
+    assert len(pa) == 100 and np.all(cnt == 2000) and np.array_equal(pa, np.arange(100) // 2)
+    bad = ops.histogram2d(dev(np.array([0, 5])), dev(np.array([0, 0])), 3, 3)
+    assert bad.pp_info.tolist() == [0, 1]
+
+
+def test_panoptic_evaluation_device_matches_numpy_and_reference_log(ops):
+    from panopticsegforlargescalepointcloud_amd.panoptic.metrics import panoptic_evaluation, panoptic_evaluation_device
+    z = np.load(os.path.join(GOLD, "final_eval_cases.npz"))
+    cases = [(z["pred_sem_" + n], z["pred_ins_" + n], z["gt_sem_" + n], z["gt_ins_" + n]) for n in z["names"].tolist()]
+    rng = np.random.default_rng(5)
+    n = 400_000  # a scene-sized case: 300 predicted / 250 ground-truth instances with noisy overlap
+    gt_ins = rng.integers(-1, 250, size=n)
+    gt_sem = np.where(gt_ins >= 0, np.array([2, 3, 4, 6, 7, 8])[gt_ins % 6], rng.choice([-1, 0, 1, 5], size=n))
+    pred_ins = np.where(rng.random(n) < 0.85, gt_ins + (gt_ins >= 0) * 7, rng.integers(-1, 300, size=n))
+    pred_sem = np.where(rng.random(n) < 0.9, gt_sem, rng.integers(0, 9, size=n))
+    pred_sem = np.where(pred_sem < 0, 0, pred_sem)
+    cases.append((pred_sem, pred_ins, gt_sem, gt_ins))
+    for ps, pi, gs, gi in cases:
+        want = panoptic_evaluation(ps, pi, gs, gi)
+        got = panoptic_evaluation_device(dev(np.asarray(ps, np.int64)), dev(np.asarray(pi, np.int64)),
+                                         dev(np.asarray(gs, np.int64)), dev(np.asarray(gi, np.int64)))
+        assert sorted(got) == sorted(want)
+        for k in want:
+            np.testing.assert_array_equal(np.asarray(got[k]), np.asarray(want[k]), err_msg=k)  # same tables, same float ops
+    # and the device path against the reference's own log lines directly
+    for name in z["names"].tolist():
+        r = panoptic_evaluation_device(*(dev(z[k + name].astype(np.int64)) for k in ("pred_sem_", "pred_ins_", "gt_sem_", "gt_ins_")))
+        for mine, theirs in {"mIoU": "Semantic_Segmentation_mIoU", "F1": "Instance_Segmentation_F1_score",
+                             "meanPQ": "Instance_Segmentation_meanPQ", "mMWCov": "Instance_Segmentation_mMWCov"}.items():
+            np.testing.assert_allclose(r[mine], z["log_%s_%s" % (name, theirs)], rtol=1e-6, atol=1e-7)
+
+
+def _blocks(rng, n_scene, n_blocks, per_block, inst_per_block):
+    """overlapping blocks (cylinders): contiguous id windows with random instance partitions"""
+    out = []
+    for b in range(n_blocks):
+        start = int(b * (n_scene - per_block) / max(n_blocks - 1, 1))
+        origin = np.sort(rng.choice(np.arange(start, start + per_block), size=int(per_block * 0.8), replace=False)).astype(np.int64)
+        labels = np.full(len(origin), -1, np.int32)
+        k = int(rng.integers(0, inst_per_block + 1))
+        if k:
+            cuts = np.sort(rng.choice(len(origin), size=2 * k, replace=False))
+            ids = rng.permutation(k + 2)[:k]  # non-contiguous instance ids: unused ids still burn a label in the reference
+            for i in range(k):
+                labels[cuts[2 * i]: cuts[2 * i + 1]] = ids[i]
+        out.append((origin, labels))
+    return out
+
+
+def test_block_merging_device_matches_numpy(ops):
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler, SceneAssemblerGPU
+    rng = np.random.default_rng(8)
+    for n_scene, n_blocks, per_block, k in [(3000, 6, 1000, 5), (60_000, 25, 6000, 30), (400, 3, 200, 0), (50_000, 12, 9000, 60)]:
+        blocks = _blocks(rng, n_scene, n_blocks, per_block, k)
+        cpu = SceneAssembler(n_scene, 9)
+        gpu = SceneAssemblerGPU(n_scene, 9, "cuda")
+        for origin, labels in blocks:
+            logits = rng.normal(size=(len(origin), 9)).astype(np.float32)
+            cpu.add_block(origin, labels, logits)
+            gpu.add_block(dev(origin), dev(labels), dev(logits))
+        gpu.finish()
+        assert np.array_equal(gpu.ins_pre.cpu().numpy(), cpu.ins_pre)
+        assert gpu.max_instance == cpu.max_instance
+        assert np.array_equal(gpu.prediction_count.cpu().numpy(), cpu.prediction_count)
+        np.testing.assert_allclose(gpu.votes.cpu().numpy(), cpu.votes, rtol=1e-6, atol=1e-6)
+
+
+def test_block_merging_rules_device(ops):
+    """the hand-written cases of tests/test_host_logic.py::test_block_merging_rules on the device, step by step"""
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler, SceneAssemblerGPU
+    cpu, gpu = SceneAssembler(20, 3), SceneAssemblerGPU(20, 3, "cuda")
+    steps = [(np.arange(10), [0, 0, 0, 0, 0, 1, 1, 1, -1, -1]),          # untouched region: labels + max_instance
+             (np.arange(3, 13), [0, 0, 0, 0, 0, 0, 0, 1, 1, 1]),         # merge by best IoU / new instance (max_instance + 1)
+             (np.arange(0, 8), [0, 0, 1, 1, 2, 2, 3, 3]),                # fully labelled block: nothing changes
+             (np.arange(12, 20), [-1] * 8),                              # no instance in the block
+             (np.arange(8, 20), [5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5])]   # sparse instance ids: unused ids burn labels
+    for origin, labels in steps:
+        cpu.add_block(origin, np.asarray(labels))
+        gpu.add_block(dev(origin), dev(np.asarray(labels, np.int32)))
+        assert gpu.ins_pre.cpu().tolist() == cpu.ins_pre.tolist() and gpu.max_instance == cpu.max_instance
+    gpu.finish()
+    assert cpu.ins_pre[10:13].tolist() == [3, 3, 3]  # the reference allocates max_instance + 1
