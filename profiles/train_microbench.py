@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from panopticsegforlargescalepointcloud_amd import synthetic as syn  # noqa: E402
 from panopticsegforlargescalepointcloud_amd.applications import Data  # noqa: E402
-from panopticsegforlargescalepointcloud_amd.training import train_step  # noqa: E402
+from panopticsegforlargescalepointcloud_amd.training import GradientReducer, train_step  # noqa: E402
 
 
 def make_batch(scene, tiles, ids):
@@ -51,12 +51,13 @@ def main():
     data, n = make_batch(scene, tiles, ids)
     data = data.to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    reducer = GradientReducer(model.parameters()) if world > 1 else None  # bucketed all-reduce overlapped with backward
     for epoch, tag in [(1, "epoch <= prepare_epoch (heads + losses)"), (100, "epoch > prepare_epoch (+ grouping, ScorerUnet, score loss)")]:
         times = []
         for it in range(6):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            train_step(model, data, opt, epoch, dev, world)
+            train_step(model, data, opt, epoch, dev, world, reducer=reducer)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         t = float(np.median(times[2:]))
