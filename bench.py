@@ -6,8 +6,9 @@ labels) on the synthetic 10M-point urban scene cut into 64 overlapping cylinder 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the hot path over the whole scene: every rank runs its shard of the 64 tiles (tiles_per_batch
-cylinders per launch sequence) and, for N > 1, ONE RCCL all-gather of the per-tile instance labels closes the step
-(strong scaling: the scene is fixed, tiles are sharded).  Inputs (and the synthetic head statistics used for grouping,
+cylinders per launch sequence) and, for N > 1, ONE RCCL all-gather of the per-tile results (origin id, instance label and
+the 9 semantic log-probabilities per point: what the tracker's scene assembly consumes) closes the step (strong scaling:
+the scene is fixed, tiles are sharded).  Inputs (and the synthetic head statistics used for grouping,
 see DESIGN.md "what is measured") are resident in HBM before the timed region.  Random-init weights, synthetic data.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel pp_spconv_fwd, HIP
@@ -229,7 +230,9 @@ def main():
             stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
             stats["instances"] += sum(counts)
             for j, t in enumerate(ids):
-                local[t] = (dev_b["origin_id"][starts[j]: starts[j + 1]], labels[starts[j]: starts[j + 1]])
+                # what the scene assembly needs from a cylinder: origin ids, instance labels, semantic vote contributions
+                local[t] = (dev_b["origin_id"][starts[j]: starts[j + 1]], labels[starts[j]: starts[j + 1]],
+                            res.semantic_logits[starts[j]: starts[j + 1]])
         return exchange_tile_results(local) if world > 1 else local
 
     def sync():

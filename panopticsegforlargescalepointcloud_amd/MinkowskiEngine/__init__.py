@@ -48,9 +48,19 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device):
+    """the stream the coordinate levels / kernel maps are prefetched on.  Lowest priority the runtime offers: the GPU is
+    saturated by the convolutions of the main stream, so the map builders should only fill the gaps they leave
+    (PP_SIDE_PRIORITY=0 gives it the default priority; A/B runs)."""
     s = _SIDE_STREAMS.get(device)
     if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+        prio = 0
+        if os.environ.get("PP_SIDE_PRIORITY", "low") == "low":
+            try:
+                lo, hi = torch.cuda.Stream.priority_range()  # (least priority, greatest priority): larger number = lower
+                prio = max(lo, hi)
+            except Exception:
+                prio = 0
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device, priority=prio)
     return s
 
 

@@ -376,6 +376,11 @@ def bf16_conv_supported(c0, c1, K, nbr_given=True):
     return c0 % 16 == 0 and c1 % 16 == 0 and (c1 == 0 or c1 == c0) and K <= 28
 
 
+# A/B measurements only: PP_AB_T4="max_ntw,min_rows" overrides the library's rows-per-wave choice (64 rows when the launch
+# has <= max_ntw column tiles per wave and >= min_rows rows) through pp_spconv_fwd_ex
+_AB_T4 = tuple(int(v) for v in os.environ["PP_AB_T4"].split(",")) if os.environ.get("PP_AB_T4") else None
+
+
 def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
                row_order=None, bf16=False, variant=None):
     """variant = (rows_per_wave, pipeline, split_k): an explicit variant of the pipelined kernel through
@@ -403,6 +408,11 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     args = (_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
             _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out))
     use_bf16 = bool(bf16) and bf16_conv_supported(c0, c1, K)
+    if variant is None and _AB_T4 is not None and c0 % 16 == 0 and c1 % 16 == 0 and K == 27:
+        nt = (cout + 15) // 16
+        groups = (nt + 3) // 4
+        ntw = (nt + groups - 1) // groups
+        variant = (64 if (ntw <= _AB_T4[0] and n_out >= _AB_T4[1]) else 32, 0, 0)
     if variant is not None:
         rpw, pipe, split = variant
         _lib.check(lib.pp_spconv_fwd_ex(*args, int(use_bf16), int(rpw), int(pipe), int(split), _stream()), "pp_spconv_fwd_ex")
