@@ -301,15 +301,22 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": prof["flops"] / secs / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json;
-        # a PMC pass cannot run inside the timed bench), next to the algorithmic bytes per launch it is compared with
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json; a
+        # PMC pass cannot run inside the timed bench).  FETCH_SIZE counts the 128-byte requests of wide streaming loads at
+        # 64 bytes and 64-byte row gathers in full (calibrated: profiles/r02_fetch_calibration.md), so half of the bytes the
+        # kernel streams with wide loads -- its kernel map, known exactly -- is added to the raw counter.
         roof["traffic"] = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                roof["traffic"] = tj["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+                map_b = prof["map_bytes"] / max(prof["launches"], 1)
+                roof["traffic"] = tj["write_bytes_per_launch"] + tj["fetch_raw_bytes_per_launch"] + 0.5 * map_b
+                roof["traffic_bounds"] = [tj["write_bytes_per_launch"] + tj["fetch_raw_bytes_per_launch"],
+                                          tj["write_bytes_per_launch"] + 2.0 * tj["fetch_raw_bytes_per_launch"]]
+                roof["map_bytes_per_launch"] = map_b
+                roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE + FETCH_SIZE raw + 0.5 x kernel-map "
+                                          "bytes; calibration profiles/r02_fetch_calibration.md)")
             except Exception:
                 pass
         roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)

@@ -144,6 +144,10 @@ int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* 
                    int32_t window, int32_t* out, pp_stream_t stream);
 int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,
                      pp_stream_t stream);
+/* caller <-> internal row permutation of the input level: perm_out[s] = perm32[order[s]] (NULL = identity for either),
+ * inv_out[perm_out[s]] = s  (applications/minkowski.py:193: the output rows must come back in the caller's order) */
+int pp_compose_perm(const int32_t* perm32, const int32_t* order, int64_t n, int64_t* perm_out, int64_t* inv_out,
+                    pp_stream_t stream);
 
 /* Internal row order of a coordinate level, batch-major: perm[p] = input row holding the p-th smallest key.
  * unit = tensor stride of the level (coordinates are multiples of it).

@@ -161,17 +161,16 @@ class CoordinateManager:
         self.perm = self.inv_perm = None
         self.sorted = bool(reorder) and ORDER_BLOCK_BITS >= 0
         if self.sorted:
+            perm32 = order = None
             if coords.shape[0] > 1:
-                self.perm, coords = ops.morton_order(coords, 1, ORDER_BLOCK_BITS, want_sorted=True)
+                perm32, coords = ops.morton_order(coords, 1, ORDER_BLOCK_BITS, want_sorted=True, raw=True)
             index, ndup = ops.block_index_build(coords, 1, ORDER_BLOCK_BITS)
             level = _Level(coords, index=index)
             if MAP_ORDER and ndup == 0 and coords.shape[0] >= MAP_ORDER_MIN_ROWS:
                 coords_p, order, phys_of, same = _order_level(coords, index, 1)
                 level = _Level(coords_p, index=index, phys_of=phys_of, same_map=same)
-                self.perm = self.perm[order.long()]
-            if self.perm is not None:
-                self.inv_perm = torch.empty_like(self.perm)
-                self.inv_perm[self.perm] = torch.arange(self.perm.numel(), device=coords.device)
+            if perm32 is not None:  # internal row p = caller row perm[p]
+                self.perm, self.inv_perm = ops.compose_perm(perm32, order, coords.shape[0], coords.device)
         else:
             table, ndup = ops.hash_build(coords)
             level = _Level(coords, table=table)

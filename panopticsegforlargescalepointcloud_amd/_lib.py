@@ -47,6 +47,7 @@ SIGNATURES = {
     "pp_pair_counts": (C.c_int, [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_block_merge_workspace": (sz, [i64]),
     "pp_block_merge": (C.c_int, [vp, vp, i64, vp, i64, vp, vp, vp, sz, vp]),
+    "pp_compose_perm": (C.c_int, [vp, vp, i64, vp, vp, vp]),
     "pp_map_window": (i32, []),
     "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
     "pp_map_order": (C.c_int, [vp, vp, i64, vp, vp]),

@@ -204,3 +204,23 @@ extern "C" int pp_level_permute(const int32_t* coords, int64_t n, const int32_t*
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+
+// caller <-> internal row permutation of the input level in one pass: perm_out[s] = perm32[order[s]] (either may be NULL =
+// identity), inv_out[perm_out[s]] = s.  Replaces three elementwise torch launches over all input rows.
+__global__ __launch_bounds__(256) void k_compose_perm(const int32_t* __restrict__ perm32, const int32_t* __restrict__ order, int64_t n,
+                                                      int64_t* __restrict__ perm_out, int64_t* __restrict__ inv_out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int64_t o = order ? (int64_t)order[s] : s;
+  const int64_t p = perm32 ? (int64_t)perm32[o] : o;
+  perm_out[s] = p;
+  inv_out[p] = s;
+}
+extern "C" int pp_compose_perm(const int32_t* perm32, const int32_t* order, int64_t n, int64_t* perm_out, int64_t* inv_out,
+                               pp_stream_t stream) {
+  PP_REQUIRE((perm_out && inv_out) || n == 0, "pp_compose_perm: null output");
+  if (n == 0) return PP_OK;
+  hipLaunchKernelGGL(k_compose_perm, dim3(pp_blocks(n, 256)), dim3(256), 0, pp_s(stream), perm32, order, n, perm_out, inv_out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -22,15 +22,16 @@ class LaunchProfiler:
 
     def summarize(self):
         torch.cuda.synchronize()
-        tot_ms = tot_bytes = tot_flops = 0.0
+        tot_ms = tot_bytes = tot_flops = map_bytes = 0.0
         for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res) in self.records:
+            map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
             P = n_out if pairs is None else int(pairs.item())
             # features read once + written once, weights once, one (in,out) int32 pair per map entry
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
             tot_bytes += b
             tot_flops += 2.0 * P * cin * cout
             tot_ms += e0.elapsed_time(e1)
-        return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops}
+        return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes}
 
     def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12):
         """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
@@ -322,7 +323,17 @@ def kernel_map_transpose(nbr, n_in, order=None):
     return out
 
 
-def morton_order(coords, unit=1, block_bits=0, want_sorted=False):
+def compose_perm(perm32, order, n, device):
+    """(perm, inv) int64: perm[s] = perm32[order[s]] (None = identity for either), inv[perm[s]] = s"""
+    lib = _lib.load()
+    perm = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    inv = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+    _lib.check(lib.pp_compose_perm(_ptr(_need(perm32, torch.int32, "perm32")), _ptr(_need(order, torch.int32, "order")), n, _ptr(perm),
+                                   _ptr(inv), _stream()), "pp_compose_perm")
+    return perm[:n], inv[:n]
+
+
+def morton_order(coords, unit=1, block_bits=0, want_sorted=False, raw=False):
     """perm (int64 [n]): rows of `coords` in batch-major Z-order (block_bits=0) or parity-grouped block order.
     want_sorted: also return coords[perm], decoded from the sorted keys instead of gathered."""
     lib = _lib.load()
@@ -336,6 +347,8 @@ def morton_order(coords, unit=1, block_bits=0, want_sorted=False):
     srt = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) if want_sorted else None
     _lib.check(lib.pp_morton_order(_ptr(coords), n, int(unit), int(block_bits), _ptr(perm), _ptr(srt), _ptr(ws), wsb, _ptr(info),
                                    _stream()), "pp_morton_order")
+    if raw:  # int32 permutation (compose_perm turns it into the int64 pair the feature gathers use)
+        return (perm[:n], srt[:n]) if want_sorted else perm[:n]
     if want_sorted:
         return perm[:n].long(), srt[:n]
     return perm[:n].long()

@@ -4,7 +4,7 @@
 # writes gpurun_out/<tag>/{bench.json, layer_table.md, kernel_stats.md, pmc_fetch.md, pmc_write.md, traffic.json};
 # copy them to profiles/.  --pmc runs are separate passes with --kernel-trace only (gpurun refuses pmc + sys/runtime trace).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -1,19 +1,24 @@
 #!/bin/bash
-# PMC passes for one convolution shape: bash profiles/pmc_conv.sh <tag> <n_tiles> <ts> <cin> <cout> <dense|rb>
+# PMC passes for convolution shapes: bash profiles/pmc_conv.sh <tag> <n_tiles> <shape>   (shape as in profiles/conv_one.py)
+# -> gpurun_out/pmc_<tag>/{time.txt,passN.md,summary.md}.  Counter passes run with --kernel-trace only.
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/profiles/conv_one.py "$@" 2>/dev/null | tail -1 > $O/time.txt
+python $R/profiles/conv_one.py "$@" 5 2>/dev/null | tail -2 > $O/time.txt
 i=0
-for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_WAVES" \
-         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "FETCH_SIZE" ; do
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" \
+         "SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
+         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_TAG_STALL_sum" \
+         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+         "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TA_BUFFER_TOTAL_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum TCP_TCP_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
+         "FETCH_SIZE" "WRITE_SIZE" ; do
   i=$((i+1))
   rm -rf /tmp/pm_$i
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pm_$i -o p -- python $R/profiles/conv_one.py "$@" 2 > /dev/null 2>&1
   python $R/profiles/rocpd_summary.py --pmc /tmp/pm_$i/p_results.db $O/pass$i.md > /dev/null 2>&1 || echo "pass $i failed ($C)" >> $O/time.txt
 done
-cat $O/time.txt
-grep -h spconv $O/pass*.md
+( cat $O/time.txt; echo; echo "| kernel | counter | dispatches | avg per dispatch | sum |"; echo "|---|---|---|---|---|"; grep -h spconv $O/pass*.md ) > $O/summary.md
+cat $O/summary.md

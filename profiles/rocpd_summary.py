@@ -74,8 +74,13 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--layers":
 
 def traffic(db_fetch, db_write, out):
     """HBM traffic per launch of the dominant kernel family (k_spconv_fwd*), from the two PMC passes.
-    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts the 128-byte requests of wide loads at 64 bytes, so
-    it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as reported (uncalibrated there)."""
+    FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B: the 128-byte requests of wide,
+    coalesced streaming loads are tallied at 64 bytes (MI355X_MICROARCH.md, HBM section), while 64-byte row gathers -- the
+    A operand of the convolution -- are counted in full.  Calibrated on this access pattern in
+    profiles/r02_fetch_calibration.md (profiles/calibrate_fetch.sh): known / raw = 2.000 for streaming reads, 1.059 for
+    random 64-byte row gathers, 1.000 for WRITE_SIZE.  So the raw counter is stored here and bench.py adds half of the
+    bytes the kernel streams with wide loads (its kernel map, known exactly per launch):
+        traffic = WRITE_SIZE + FETCH_SIZE_raw + 0.5 * map_bytes      (lower bound: raw, upper bound: 2 x raw)."""
     import json
     res = {}
     for name, db, counter in (("fetch", db_fetch, "FETCH_SIZE"), ("write", db_write, "WRITE_SIZE")):
@@ -84,12 +89,13 @@ def traffic(db_fetch, db_write, out):
                              "and counter_name = ?", (counter,)).fetchone()
         res[name + "_launches"] = n
         res[name + "_KiB_total"] = tot
-    fetch_b = 2.0 * 1024.0 * res["fetch_KiB_total"] / max(res["fetch_launches"], 1)
+    fetch_raw = 1024.0 * res["fetch_KiB_total"] / max(res["fetch_launches"], 1)
     write_b = 1024.0 * res["write_KiB_total"] / max(res["write_launches"], 1)
-    res.update({"kernel": "k_spconv_fwd*", "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
-                "hbm_bytes_per_launch": fetch_b + write_b,
+    res.update({"kernel": "k_spconv_fwd*", "fetch_raw_bytes_per_launch": fetch_raw, "write_bytes_per_launch": write_b,
+                "calibration": {"streaming_known_over_raw": 2.0, "gather64_known_over_raw": 1.059, "write_known_over_raw": 1.0,
+                                "source": "profiles/r02_fetch_calibration.md"},
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1` (all launches of "
-                        "both steps averaged); FETCH_SIZE x2 gfx950 correction applied"})
+                        "both steps averaged); raw counters, see bench.py for the correction"})
     open(out, "w").write(json.dumps(res, indent=1) + "\n")
     print(res)
 
