@@ -42,11 +42,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef F3_WPB
 #define F3_WPB 4
 #endif
-// F3_EXP (A/B builds, profiles/ablate_conv.sh): bit 0 = loop state initialised (no undefined scalars), bit 1 = MFMAs of
-// the row tiles interleaved when every tile of the wave has the offset
-#ifndef F3_EXP
-#define F3_EXP 0
-#endif
 
 template <int NTW, int T, bool BF16, int D>
 __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
@@ -189,11 +184,6 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
             acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah_, bh_[jt], acc[tt][jt], 0, 0, 0);  \
       }                                                                                                   \
     }                                                                                                     \
-  } else if ((F3_EXP & 2) && ((mall >> (KC)) & 1u)) {                                                     \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
-        _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                  \
-            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                            \
-                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
   } else {                                                                                                \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
       if ((m[tt] >> (KC)) & 1u) {                                                                         \
@@ -203,14 +193,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
       }                                                                                                   \
     }                                                                                                     \
   }
-    unsigned mall = 0xFFFFFFFFu;  // offsets every tile of the wave has
-    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) mall &= m[tt];
-#if F3_EXP & 1
-#define F3_INIT(v) = (v)
-#else
-#define F3_INIT(v)
-#endif
-    int more F3_INIT(1);  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
+    int more = 1;  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
     // The loads are unconditional: after the last step the load side simply re-reads a valid step.  (A branch around
     // them makes hipcc merge the two paths' outstanding-load counts and wait for the NEW loads before the MFMAs.)
     if constexpr (D == 1) {
@@ -232,7 +215,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     } else if constexpr (D == 3) {
       // as D == 1, but the load side advances (LDS read of the next offsets) BEFORE the MFMAs of the current step, so
       // that read is covered by them instead of sitting between two steps
-      int k0 F3_INIT(0), k1 F3_INIT(0), e0 F3_INIT(0), e1 F3_INIT(0), nx F3_INIT(0);
+      int k0 = 0, k1 = 0, e0 = 0, e1 = 0, nx = 0;
       F3_LOADS(A0, B0);
       k0 = kl;
       F3_ADVANCE(nx);

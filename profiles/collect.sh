@@ -10,13 +10,13 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench.json
-timeout 900 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stage-timing --layer-table $O/layer_table.md 2>/dev/null | tail -1 > $O/bench_stages.json
+timeout 900 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-checks --stage-timing --layer-table $O/layer_table.md 2>/dev/null | tail -1 > $O/bench_stages.json
 rm -rf /tmp/p_kt /tmp/p_f /tmp/p_w
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-checks > /dev/null 2>&1
 python $R/profiles/rocpd_summary.py /tmp/p_kt/kt_results.db $O/kernel_stats.md > /dev/null
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-checks > /dev/null 2>&1
 python $R/profiles/rocpd_summary.py --pmc /tmp/p_f/f_results.db $O/pmc_fetch.md > /dev/null
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-checks > /dev/null 2>&1
 python $R/profiles/rocpd_summary.py --pmc /tmp/p_w/w_results.db $O/pmc_write.md > /dev/null
 python $R/profiles/rocpd_summary.py --traffic /tmp/p_f/f_results.db /tmp/p_w/w_results.db $O/traffic.json
 ls -la $O

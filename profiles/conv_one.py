@@ -42,7 +42,7 @@ def main():
             nbr, n_in = cm.kernel_map(ts_want // 2, ts_want, 3, 1), cm.level(ts_want // 2).n
         n = cm.level(ts_want).n
         order = getattr(nbr, "pp_order", None)
-        P = int((nbr >= 0).sum().item())
+        P = int(ops._pairs_of(nbr).item())
         x = torch.randn(n_in, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         pk = ops.pack_weight(w)

@@ -50,7 +50,7 @@ def test_coordinates_at_the_ends_of_the_key_range():
     c = torch.tensor([[0, 32767, 32767, 32767], [0, 32766, 32767, 32767], [0, -32768, -32768, -32768],
                       [1, -32768, -32768, -32768], [0, 0, 0, 0]], dtype=torch.int32)
     cm = ME.CoordinateManager(c.to(dev))
-    nbr = cm.kernel_map(1, 1, 3, 1).cpu().numpy()
+    nbr = cm.kernel_map_rows(1, 1, 3, 1).cpu().numpy()
     assert (nbr >= 0).sum() == 5 + 2                              # every row finds itself; one adjacent pair, both ways
     x = ME.SparseTensor(torch.randn(5, 4), coordinates=c, device=dev)
     assert torch.equal(x.C.cpu(), c)                              # caller order preserved
