@@ -262,8 +262,11 @@ class PointGroup3heads(nn.Module):
             b = torch.where(valid, pairs.b.long(), 0)
             inter = pairs.inter.long()
             dup = valid & (inter == sz[a]) & (inter == sz[b])
-            rep = torch.arange(n_prop + 1, device=sz.device)  # slot n_prop swallows the non-duplicates
-            rep.scatter_reduce_(0, torch.where(dup, b, n_prop), torch.where(dup, a, n_prop), "amin", include_self=True)
+            # non-duplicates go to private slots behind the proposals (one shared dump slot would serialise ~10^5 atomics
+            # on a single address: 1.6 ms per step)
+            slot = torch.arange(pairs.capacity, device=sz.device)
+            rep = torch.arange(n_prop + pairs.capacity, device=sz.device)
+            rep.scatter_reduce_(0, torch.where(dup, b, n_prop + slot), torch.where(dup, a, n_prop + slot), "amin", include_self=True)
             rep = rep[:n_prop]
             uniq_ids = torch.nonzero(rep == torch.arange(csr.n, device=sz.device)).view(-1)
             if uniq_ids.numel() < csr.n:
