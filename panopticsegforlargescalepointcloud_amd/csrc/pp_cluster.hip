@@ -30,10 +30,12 @@ __global__ __launch_bounds__(256) void k_rg_flag(const int64_t* __restrict__ lab
 }
 
 __device__ inline uint64_t rg_cell_key(int bc, int cx, int cy, int cz) {
-  // (batch,class) folded to 16 bits + 3 x 16-bit wrapped cell coordinates; equality of (batch,class) is
-  // re-checked on every candidate, so aliasing only adds rejected candidates.
-  return ((uint64_t)((uint32_t)bc * 2654435761u >> 16) << 48) | ((uint64_t)(uint16_t)cx << 32) |
-         ((uint64_t)(uint16_t)cy << 16) | (uint64_t)(uint16_t)cz;
+  // (batch,class) in 27 bits (exact below 2^27, i.e. 2^19 batch elements; folded beyond) + 3 x 12-bit wrapped cell
+  // coordinates; bit 63 stays clear, so the key never equals the empty marker.  Equality of (batch,class) and of the cell
+  // is re-checked on every candidate / query, so aliasing only sends the cells involved to the per-query kernel.
+  const uint32_t b = (uint32_t)bc < (1u << 27) ? (uint32_t)bc : ((uint32_t)bc * 2654435761u) >> 5;
+  return ((uint64_t)b << 36) | ((uint64_t)((uint32_t)cx & 0xFFFu) << 24) | ((uint64_t)((uint32_t)cy & 0xFFFu) << 12) |
+         (uint64_t)((uint32_t)cz & 0xFFFu);
 }
 
 __global__ __launch_bounds__(256) void k_rg_compact(const float* __restrict__ pos, const int64_t* __restrict__ labels,
@@ -85,11 +87,16 @@ __global__ __launch_bounds__(256) void k_rg_cells(const uint32_t* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------
-// ball query: one wave per query point (cell-sorted order -> neighbouring waves share cells in L1/L2).
-// Keeps the `nsample` smallest local indices among same-(batch,class) points with d^2 < r^2 (strict),
-// as a SET (order inside the list is irrelevant to the result).
+// ball query.  Keeps the `nsample` smallest local indices among same-(batch,class) points with d^2 < r^2 (strict), as a
+// SET (order inside the list is irrelevant to the result).
+//
+// Everything downstream of the cell sort is addressed by CELL-SORTED POSITION p: Lp[p] = label of the point at p (a local
+// index: the smallest ancestor found so far), list[p * nsample + t] = position of the t-th neighbour -- a wave writes and
+// reads one list with consecutive lanes, and the ~200 labels a list names live in the <= 27 cells around the point, i.e.
+// in a few dozen cache lines instead of one line per entry (labels addressed by local index made the propagation's
+// scattered label reads, 590 M of them on the bench scene, pull one L2 line each: 4.4 -> 1.1 ms for the first round).
 // ---------------------------------------------------------------------------------------------
-#define BQ_CAP 2048
+#define BQ_CAP 4096
 struct BQScan {
   const float4* spos;
   const int32_t* sbc;
@@ -98,8 +105,9 @@ struct BQScan {
   int qbc;
 };
 
-// counts hits with local index <= T; optionally appends them to buf (LDS, capacity BQ_CAP) and/or out
-__device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_t* out, int out_cap, int64_t out_stride) {
+// counts hits with local index <= T; optionally appends (index, position) to buf / bufp (LDS, capacity BQ_CAP) and/or the
+// position of the first out_cap hits to out
+__device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int* bufp, int32_t* out, int out_cap) {
   int total = 0;
   for (int c = 0; c < 27; ++c) {
     const int st = __shfl(s.my_start, c);
@@ -118,8 +126,11 @@ __device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_
       unsigned long long m = __ballot(hit);
       if (hit) {
         int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-        if (buf && pos < BQ_CAP) buf[pos] = idx;
-        if (out && pos < out_cap) out[(int64_t)pos * out_stride] = idx;
+        if (buf && pos < BQ_CAP) {
+          buf[pos] = idx;
+          bufp[pos] = st + t;
+        }
+        if (out && pos < out_cap) out[pos] = st + t;
       }
       total += __popcll(m);
     }
@@ -127,90 +138,95 @@ __device__ inline int bq_scan(const BQScan& s, int lane, int T, int* buf, int32_
   return total;
 }
 
-// Neighbour lists are stored "t-major" in cell-sorted point order: list[t * M + p] = t-th neighbour (a local index) of
-// the point at cell-sorted position p, so that the lanes of a wave (consecutive p) read and write consecutive words.
-//
 // Fallback: one wave per query, for the queries the cell kernel below could not serve (neighbourhood larger than its LDS
 // buffer, or hash-aliased cells).  Hits are compacted into an LDS buffer; beyond nsample hits the nsample-th smallest
-// index is found by bisection.
-__global__ __launch_bounds__(256) void k_ball_query(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
+// index is found by bisection (in LDS up to BQ_CAP hits -- 4096: a query of the bench scene has up to 2300 --, by
+// re-scanning the cells beyond).
+__global__ __launch_bounds__(128) void k_ball_query(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                     const uint64_t* __restrict__ keys,
                                                     const int32_t* __restrict__ cell_start,
                                                     const int32_t* __restrict__ cell_end, int64_t cap, int64_t M,
                                                     float radius, int nsample, const int32_t* __restrict__ fb_list,
                                                     const int32_t* __restrict__ fb_count, int32_t* __restrict__ list,
                                                     int32_t* __restrict__ deg) {
-  __shared__ int lds[4][BQ_CAP];
+  __shared__ int lds[2][BQ_CAP];
+  __shared__ int ldsp[2][BQ_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_fb = fb_count[0];
   int* buf = lds[wave];
-  for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < n_fb; w += (int64_t)gridDim.x * 4) {
-  const int64_t p = fb_list[w];
-  const float4 q = spos[p];
-  BQScan s;
-  s.spos = spos; s.sbc = sbc; s.qx = q.x; s.qy = q.y; s.qz = q.z; s.r2 = radius * radius; s.qbc = sbc[p];
-  s.my_start = 0; s.my_cnt = 0;
-  if (lane < 27) {
-    int cx = (int)floorf(q.x / radius) + (lane % 3 - 1);
-    int cy = (int)floorf(q.y / radius) + ((lane / 3) % 3 - 1);
-    int cz = (int)floorf(q.z / radius) + (lane / 9 - 1);
-    int64_t slot = pp_hash_find_slot(keys, cap, rg_cell_key(s.qbc, cx, cy, cz));
-    if (slot >= 0) {
-      s.my_start = cell_start[slot];
-      s.my_cnt = cell_end[slot] - s.my_start;
+  int* bufp = ldsp[wave];
+  for (int64_t w = (int64_t)blockIdx.x * 2 + wave; w < n_fb; w += (int64_t)gridDim.x * 2) {
+    const int64_t p = fb_list[w];
+    const float4 q = spos[p];
+    BQScan s;
+    s.spos = spos; s.sbc = sbc; s.qx = q.x; s.qy = q.y; s.qz = q.z; s.r2 = radius * radius; s.qbc = sbc[p];
+    s.my_start = 0; s.my_cnt = 0;
+    if (lane < 27) {
+      int cx = (int)floorf(q.x / radius) + (lane % 3 - 1);
+      int cy = (int)floorf(q.y / radius) + ((lane / 3) % 3 - 1);
+      int cz = (int)floorf(q.z / radius) + (lane / 9 - 1);
+      int64_t slot = pp_hash_find_slot(keys, cap, rg_cell_key(s.qbc, cx, cy, cz));
+      if (slot >= 0) {
+        s.my_start = cell_start[slot];
+        s.my_cnt = cell_end[slot] - s.my_start;
+      }
     }
-  }
-  int32_t* out = list + p;  // column p, stride M
-  const int total = bq_scan(s, lane, 0x7FFFFFFF, buf, nullptr, 0, 0);
-  if (total <= nsample) {
+    int32_t* out = list + p * nsample;
+    const int total = bq_scan(s, lane, 0x7FFFFFFF, buf, bufp, nullptr, 0);
+    if (total <= nsample) {
+      if (total <= BQ_CAP) {
+        for (int t = lane; t < total; t += 64) out[t] = bufp[t];
+      } else {
+        bq_scan(s, lane, 0x7FFFFFFF, nullptr, nullptr, out, nsample);
+      }
+      if (lane == 0) deg[p] = total;
+      continue;
+    }
+    // more than nsample hits: threshold T = nsample-th smallest local index (indices are distinct)
+    int lo = 0, hi = (int)M - 1;
     if (total <= BQ_CAP) {
-      for (int t = lane; t < total; t += 64) out[(int64_t)t * M] = buf[t];
+      while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for (int t = lane; t < total; t += 64) c += (buf[t] <= mid) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if (c >= nsample) hi = mid; else lo = mid + 1;
+      }
+      int wpos = 0;
+      for (int t0 = 0; t0 < total; t0 += 64) {
+        int t = t0 + lane;
+        bool keep = t < total && buf[t] <= lo;
+        unsigned long long m = __ballot(keep);
+        if (keep) out[wpos + __popcll(m & ((1ull << lane) - 1ull))] = bufp[t];
+        wpos += __popcll(m);
+      }
     } else {
-      bq_scan(s, lane, 0x7FFFFFFF, nullptr, out, nsample, M);
+      while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        int c = bq_scan(s, lane, mid, nullptr, nullptr, nullptr, 0);
+        if (c >= nsample) hi = mid; else lo = mid + 1;
+      }
+      bq_scan(s, lane, lo, nullptr, nullptr, out, nsample);
     }
-    if (lane == 0) deg[p] = total;
-    continue;
-  }
-  // more than nsample hits: threshold T = nsample-th smallest local index (indices are distinct)
-  int lo = 0, hi = (int)M - 1;
-  if (total <= BQ_CAP) {
-    while (lo < hi) {
-      int mid = lo + ((hi - lo) >> 1);
-      int c = 0;
-      for (int t = lane; t < total; t += 64) c += (buf[t] <= mid) ? 1 : 0;
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-      if (c >= nsample) hi = mid; else lo = mid + 1;
-    }
-    int wpos = 0;
-    for (int t0 = 0; t0 < total; t0 += 64) {
-      int t = t0 + lane;
-      bool keep = t < total && buf[t] <= lo;
-      unsigned long long m = __ballot(keep);
-      if (keep) out[(int64_t)(wpos + __popcll(m & ((1ull << lane) - 1ull))) * M] = buf[t];
-      wpos += __popcll(m);
-    }
-  } else {
-    while (lo < hi) {
-      int mid = lo + ((hi - lo) >> 1);
-      int c = bq_scan(s, lane, mid, nullptr, nullptr, 0, 0);
-      if (c >= nsample) hi = mid; else lo = mid + 1;
-    }
-    bq_scan(s, lane, lo, nullptr, out, nsample, M);
-  }
-  if (lane == 0) deg[p] = nsample;
+    if (lane == 0) deg[p] = nsample;
   }
 }
 
-// Main ball query: one workgroup per occupied cell.  The same-(batch,class) points of the 27 neighbouring cells are
-// staged in LDS once, sorted by local index (bitonic), and every query of the cell (one lane each) walks them in
-// ascending index order -- broadcast LDS reads, no global traffic -- appending hits until it has nsample of them:
-// exactly the nsample smallest indices inside the radius, and a dense neighbourhood stops early.
+// Main ball query: one workgroup per occupied cell.
+//   1. the local indices of the same-(batch,class) points of the 27 neighbouring cells are staged in LDS as 27 ascending
+//      runs (48-bit keys: index | run | slot in the run);
+//   2. a tree of pairwise merges (5 levels; every key finds its place with ONE binary search in the sibling run) sorts them
+//      by index;
+//   3. the candidates (x, y, z, position in the cell-sorted order) are gathered into LDS in that order (over the key
+//      buffers);
+//   4. every query of the cell is walked by ONE WAVE with a candidate per lane, 64 candidates per round in ascending
+//      index order: a ballot appends the hits until the list holds nsample of them -- exactly the nsample smallest
+//      indices inside the radius; all lanes work whatever the number of queries in the cell, a dense neighbourhood stops
+//      early, list writes are coalesced.
+// (The earlier form ranked every candidate against all 26 other runs and walked the list with a query per lane: a median
+// cell holds 5 queries, so 7 % of the lanes had work in the walk.)
 #ifndef BQC_CAP
-#define BQC_CAP 1536  // measured optimum: 768 / 1024 / 1536 / 2048 / 2560 -> region growing 29.6 / 25.8 / 19.3 / 23.6 / 35.6 ms
-                      // (16.4 / 19.2 / 19.1 ms for 1536 / 2048 / 2560 once only the keys are staged in LDS)
-#endif
-#ifndef BQC_ROUND
-#define BQC_ROUND 8  // candidates per round of the query walk (by PMC the kernel waits on LDS 3/4 of the time)
+#define BQC_CAP 1536
 #endif
 __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                           const uint64_t* __restrict__ keys,
@@ -220,13 +236,15 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
                                                           const int32_t* __restrict__ cell_p0,
                                                           const int32_t* __restrict__ n_cells, int32_t* __restrict__ list,
                                                           int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count) {
-  __shared__ int rawkey[BQC_CAP];   // local indices of the candidates as loaded: 27 runs, each ascending
-  __shared__ float4 cand[BQC_CAP];  // merged candidates: ascending in local index (.w)
+  __shared__ unsigned long long kbuf[2][BQC_CAP];  // merge ping-pong; the sorted candidates (float4) overlay both
   __shared__ int nb_start[27], nb_cnt[27], nb_off[28];
   __shared__ int n_bad;
-  const int tid = threadIdx.x;
+  float4* cand = (float4*)&kbuf[0][0];
+  static_assert(sizeof(kbuf) >= BQC_CAP * sizeof(float4), "candidate overlay");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float r2 = radius * radius;
   const int ncell = n_cells[0];
+  constexpr int PER = (BQC_CAP + 255) / 256;
   for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
     const int p0 = cell_p0[c], p1 = c + 1 < ncell ? cell_p0[c + 1] : (int)M;
     const float4 q0 = spos[p0];
@@ -257,7 +275,6 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
     const int total = nb_off[27];
     bool fallback = total > BQC_CAP;  // too many candidates for the buffer
     if (!fallback) {
-      // flat over all candidates: every lane busy, a few rounds instead of 27
       int bad = 0;
       for (int f = tid; f < total; f += 256) {
         int lo = 0, hi = 27;  // run of slot f: last k with nb_off[k] <= f
@@ -265,8 +282,10 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
           const int mid = (lo + hi) >> 1;
           if (nb_off[mid] <= f) lo = mid; else hi = mid;
         }
-        const int src = nb_start[lo] + (f - nb_off[lo]);
-        rawkey[f] = __float_as_int(spos[src].w);  // keys only: 6 KB instead of 24 KB of LDS (5 workgroups per CU, not 3)
+        const int slot = f - nb_off[lo];
+        const int src = nb_start[lo] + slot;
+        kbuf[0][f] = ((unsigned long long)(unsigned)__float_as_int(spos[src].w) << 16) | ((unsigned long long)lo << 11) |
+                     (unsigned long long)slot;
         bad += sbc[src] != bc0 ? 1 : 0;  // another (batch, class) behind an aliased cell key
       }
       if (bad) atomicAdd(&n_bad, bad);
@@ -277,60 +296,73 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
       for (int qq = p0 + tid; qq < p1; qq += 256) fb_list[atomicAdd(fb_count, 1)] = qq;
       continue;
     }
-    // 27-way merge by ranking: position = own offset in its run + number of smaller indices in every other run
-    // (indices are distinct; every run is ascending) -- ~26 short binary searches per candidate instead of a full sort
-    for (int f = tid; f < total; f += 256) {
-      int lo = 0, hi = 27;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (nb_off[mid] <= f) lo = mid; else hi = mid;
-      }
-      const float4 me = spos[nb_start[lo] + (f - nb_off[lo])];  // re-read from L2: the staging pass has just touched it
-      const int key = rawkey[f];
-      int pos = f - nb_off[lo];
-      for (int k = 0; k < 27; ++k) {
-        const int n = nb_cnt[k];
-        if (k == lo || n == 0) continue;
-        const int* run = rawkey + nb_off[k];
-        int a0 = 0, a1 = n;  // first element of the run with index > key
-        while (a0 < a1) {
-          const int mid = (a0 + a1) >> 1;
-          if (run[mid] < key) a0 = mid + 1; else a1 = mid;
+    // merge tree: at level l the runs are the groups of 2^l original runs; run i and run i ^ 1 merge
+#pragma unroll 1
+    for (int l = 0; l < 5; ++l) {
+      const unsigned long long* src = kbuf[l & 1];
+      unsigned long long* dst = kbuf[(l + 1) & 1];
+      for (int f = tid; f < total; f += 256) {
+        const unsigned long long key = src[f];
+        const int i = (int)((key >> 11) & 31u) >> l;
+        const int a0 = nb_off[min(i << l, 27)];
+        const int sib = i ^ 1;
+        const int b0 = nb_off[min(sib << l, 27)], b1 = nb_off[min((sib + 1) << l, 27)];
+        int x0 = b0, x1 = b1;  // first sibling element with a larger key (keys are distinct)
+        while (x0 < x1) {
+          const int mid = (x0 + x1) >> 1;
+          if (src[mid] < key) x0 = mid + 1; else x1 = mid;
         }
-        pos += a0;
+        dst[min(a0, b0) + (f - a0) + (x0 - b0)] = key;
       }
-      cand[pos] = me;
+      __syncthreads();
     }
-    __syncthreads();
-    for (int qq = p0 + tid; qq < p1; qq += 256) {
+    {  // sorted keys are in kbuf[1]; gather the candidates through registers, then overlay
+      float4 pc[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int f = tid + 256 * u;
+        if (f < total) {
+          const unsigned long long key = kbuf[1][f];
+          const int src = nb_start[(int)((key >> 11) & 31u)] + (int)(key & 2047u);
+          pc[u] = spos[src];
+          pc[u].w = __int_as_float(src);  // the walk needs the position, not the index: the order carries it
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int f = tid + 256 * u;
+        if (f < total) cand[f] = pc[u];
+      }
+      __syncthreads();
+    }
+    for (int qq = p0 + wave; qq < p1; qq += 4) {
       const float4 q = spos[qq];
       // hash-aliased slot (another cell behind the same key): leave the query to the per-query kernel
       if ((int)floorf(q.x / radius) != ccx || (int)floorf(q.y / radius) != ccy || (int)floorf(q.z / radius) != ccz) {
-        fb_list[atomicAdd(fb_count, 1)] = qq;
+        if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = qq;
         continue;
       }
+      int32_t* out = list + (int64_t)qq * nsample;
       int cnt = 0;
-      int j = 0;
-      for (; j + BQC_ROUND <= total && cnt < nsample; j += BQC_ROUND) {  // several candidates per round: one LDS latency
-        float4 pc[BQC_ROUND];
-        bool hit[BQC_ROUND];
-#pragma unroll
-        for (int u = 0; u < BQC_ROUND; ++u) pc[u] = cand[j + u];
-#pragma unroll
-        for (int u = 0; u < BQC_ROUND; ++u) {
-          const float dx = q.x - pc[u].x, dy = q.y - pc[u].y, dz = q.z - pc[u].z;
-          hit[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;
+      for (int c0 = 0; c0 < total && cnt < nsample; c0 += 64) {
+        const int t = c0 + lane;
+        bool hit = false;
+        int pt = 0;
+        if (t < total) {
+          const float4 pc = cand[t];
+          const float dx = q.x - pc.x, dy = q.y - pc.y, dz = q.z - pc.z;
+          hit = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2;
+          pt = __float_as_int(pc.w);
         }
-#pragma unroll
-        for (int u = 0; u < BQC_ROUND; ++u)
-          if (hit[u] && cnt < nsample) list[(int64_t)(cnt++) * M + qq] = __float_as_int(pc[u].w);
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+          const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < nsample) out[pos] = pt;
+        }
+        cnt += __popcll(m);
       }
-      for (; j < total && cnt < nsample; ++j) {
-        const float4 pc = cand[j];
-        const float dx = q.x - pc.x, dy = q.y - pc.y, dz = q.z - pc.z;
-        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2) list[(int64_t)(cnt++) * M + qq] = __float_as_int(pc.w);
-      }
-      deg[qq] = cnt;
+      if (lane == 0) deg[qq] = min(cnt, nsample);
     }
   }
 }
@@ -347,39 +379,78 @@ __global__ __launch_bounds__(256) void k_rg_cell_list(const int32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// label propagation: one lane per point (cell-sorted position p; labels live in local-index space)
+// label propagation.  A lane per point (cell-sorted position p) finds the point's current label by pointer jumping; the
+// points that have a smaller label to push than last time form the frontier, and the wave walks the list of each of
+// them with an entry per lane.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict__ list, const int32_t* __restrict__ deg,
-                                                      const float4* __restrict__ spos, int32_t* L, int32_t* pushed,
-                                                      int64_t M, int32_t* changed) {
+__global__ __launch_bounds__(256) void k_rg_init_labels(const float4* __restrict__ spos, int64_t M, int32_t* Lp, int32_t* pos_of,
+                                                        int32_t* pushed) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
-  const int g = __float_as_int(spos[p].w);
-  volatile int32_t* VL = L;
-  const int lk0 = VL[g];
-  int lk = lk0;
-  for (;;) {  // pointer jumping: L[x] <= x always, and L[L[k]] is an ancestor of k
-    int pnt = VL[lk];
-    if (pnt >= lk) break;
-    lk = pnt;
+  const int a = __float_as_int(spos[p].w);
+  Lp[p] = a;  // every point starts as its own label ...
+  pos_of[a] = (int32_t)p;
+  pushed[p] = 0x7FFFFFFF;  // ... and has told nobody yet
+}
+// back to local-index space for the cluster bookkeeping
+__global__ __launch_bounds__(256) void k_rg_labels_by_index(const float4* __restrict__ spos, const int32_t* __restrict__ Lp, int64_t M,
+                                                            int32_t* L) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < M) L[__float_as_int(spos[p].w)] = Lp[p];
+}
+
+__global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict__ list, const int32_t* __restrict__ deg,
+                                                      const int32_t* __restrict__ pos_of, int32_t* Lp, int32_t* pushed,
+                                                      int64_t M, int nsample, int32_t* changed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  volatile int32_t* VL = Lp;
+  bool ch = false, need = false;
+  int lk = 0, d = 0;
+  if (p < M) {
+    const int lk0 = VL[p];
+    lk = lk0;
+    for (;;) {  // pointer jumping: a label is the index of an ancestor, and that ancestor's label one of its ancestors
+      int pnt = VL[pos_of[lk]];
+      if (pnt >= lk) break;
+      lk = pnt;
+    }
+    if (lk < lk0) {
+      atomicMin(&Lp[p], lk);
+      ch = true;
+    }
+    // frontier: a point re-walks its neighbour list only when it has a smaller label to push than last time
+    // (labels only decrease, so a label already pushed can never be needed again by the same neighbours)
+    if (pushed[p] > lk) {
+      pushed[p] = lk;
+      need = true;
+      d = deg[p];
+    }
   }
-  bool ch = false;
-  if (lk < lk0) {
-    atomicMin(&L[g], lk);
-    ch = true;
-  }
-  // frontier: a point re-walks its neighbour list only when it has a smaller label to push than last time
-  // (labels only decrease, so a label already pushed can never be needed again by the same neighbours)
-  if (pushed[p] > lk) {
-    pushed[p] = lk;
-    const int d = deg[p];
-    for (int t = 0; t < d; ++t) {
-      const int j = list[(int64_t)t * M + p];
-      // L[j] <= j always, so a neighbour with j <= lk cannot be improved: skip its label load
-      if (j > lk && VL[j] > lk) {
-        int old = atomicMin(&L[j], lk);
-        if (old > lk) ch = true;
+  unsigned long long todo = __ballot(need);
+  const int64_t p_wave = p - lane;
+  while (todo) {
+    const int b = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int lkb = __shfl(lk, b), db = __shfl(d, b);
+    const int32_t* row = list + (p_wave + b) * nsample;
+    // 256 entries per pass: all list loads, then all label loads, then the atomics (no value read back) -- the wave has
+    // 4 + 4 loads in flight instead of one dependent pair per 64 entries
+    for (int t0 = 0; t0 < db; t0 += 256) {
+      int j[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + 64 * u + lane;
+        j[u] = t < db ? row[t] : -1;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = j[u] >= 0 ? VL[j[u]] : -1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v[u] > lkb) {
+          (void)__hip_atomic_fetch_min(&Lp[j[u]], lkb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ch = true;  // (another push may have got there first: an over-report costs at most one extra round)
+        }
     }
   }
   if (ch) changed[0] = 1;
@@ -608,20 +679,21 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   rc = pp_exclusive_scan_i32(flag, rank, M, misc + 4, ar.cur(), ar.left(), s);  // misc[4] = number of cells
   if (rc) return rc;
   hipLaunchKernelGGL(k_rg_cell_list, dim3(mb), dim3(256), 0, s, flag, rank, M, cell_p0);
-  hipLaunchKernelGGL(k_ball_query_cells, dim3((unsigned)std::min<int64_t>(M, 4096)), dim3(256), 0, s, spos, sbc, ckeys,
-                     cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg, fb_list, misc + 5);
-  hipLaunchKernelGGL(k_ball_query, dim3((unsigned)std::min<int64_t>(pp_blocks(M, 4), 2048)), dim3(256), 0, s, spos, sbc,
-                     ckeys, cell_start, cell_end, cap, M, radius, nsample, fb_list, misc + 5, list, deg);
-  hipLaunchKernelGGL(k_iota, dim3(mb), dim3(256), 0, s, L, M);
   int32_t* pushed = size;  // reused as the cluster-size array once the fixpoint is reached
-  hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks(M)), dim3(256), 0, s, pushed, 0x7FFFFFFF, M);
+  int32_t* Lp = flag;      // labels by cell-sorted position (flag / rank are free from here on)
+  int32_t* pos_of = rank;  // cell-sorted position of a local index
+  hipLaunchKernelGGL(k_rg_init_labels, dim3(mb), dim3(256), 0, s, spos, M, Lp, pos_of, pushed);
+  hipLaunchKernelGGL(k_ball_query_cells, dim3((unsigned)std::min<int64_t>(M, 8192)), dim3(256), 0, s, spos, sbc, ckeys,
+                     cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg, fb_list, misc + 5);
+  hipLaunchKernelGGL(k_ball_query, dim3((unsigned)std::min<int64_t>(pp_blocks(M, 2), 4096)), dim3(128), 0, s, spos, sbc,
+                     ckeys, cell_start, cell_end, cap, M, radius, nsample, fb_list, misc + 5, list, deg);
   PP_LAUNCH_CHECK();
   // fixpoint
   bool converged = false;
   for (int round = 0; round < 4096 && !converged; ++round) {
     PP_HIP(hipMemsetAsync(misc + 2, 0, sizeof(int32_t), s));
     for (int it = 0; it < 4; ++it)
-      hipLaunchKernelGGL(k_rg_propagate, dim3(mb), dim3(256), 0, s, list, deg, spos, L, pushed, M, misc + 2);
+      hipLaunchKernelGGL(k_rg_propagate, dim3(mb), dim3(256), 0, s, list, deg, pos_of, Lp, pushed, M, nsample, misc + 2);
     PP_LAUNCH_CHECK();
     PP_HIP(hipMemcpyAsync(h, misc + 1, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PP_HIP(hipStreamSynchronize(s));
@@ -635,6 +707,7 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
     pp_set_error("pp_region_grow: label propagation did not converge in 4096 x 4 rounds (%lld selected points)", (long long)M);
     return PP_ERR_INVALID;
   }
+  hipLaunchKernelGGL(k_rg_labels_by_index, dim3(mb), dim3(256), 0, s, spos, Lp, M, L);
   // clusters: valid roots ordered by (class, root index)
   PP_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)M, s));
   hipLaunchKernelGGL(k_rg_sizes, dim3(mb), dim3(256), 0, s, L, M, size);

@@ -350,11 +350,11 @@ def test_region_grow_bit_exact(ops, oracle, nsample, sigma):
 
 
 def test_region_grow_pileup_overflows_lds_buffer(ops, oracle):
-    """> 2048 hits per query exercises the global re-scan selection path."""
+    """> 4096 hits per query exercises the global re-scan selection path (blob 1), 2600 hits the LDS bisection (blob 2)."""
     rng = np.random.default_rng(9)
-    n = 6000
+    n = 7600
     pos = rng.normal(0, 0.01, size=(n, 3)).astype(np.float32)
-    pos[3000:] += 5.0
+    pos[5000:] += 5.0
     labels = np.ones(n, np.int64)
     batch = np.zeros(n, np.int64)
     want, _ = oracle.region_grow(pos, labels, batch, [], nsample=200, radius=0.2, min_cluster_size=10)
@@ -363,6 +363,27 @@ def test_region_grow_pileup_overflows_lds_buffer(ops, oracle):
     assert len(got) == len(want) == 2
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_region_grow_aliased_cells(ops, oracle):
+    """cell keys wrap at 4096 cells per axis and fold (batch, class) above 2^27: blobs exactly 4096 cells apart, and batch
+    ids beyond 2^19, land behind the same key -- those cells must go through the per-query path with exact results."""
+    rng = np.random.default_rng(12)
+    radius = 0.1
+    base = rng.normal(0, 0.08, size=(1500, 3)).astype(np.float32)
+    far = base[:700] + np.float32(4096 * radius) * np.array([1, 0, 0], np.float32)   # same wrapped cell coordinates
+    far2 = base[:500] + np.float32(4096 * radius) * np.array([0, -1, 1], np.float32)
+    pos = np.concatenate([base, far, far2, base[:600] + 0.01, base[:400] - 0.01])
+    labels = np.ones(len(pos), np.int64)
+    batch = np.concatenate([np.zeros(1500 + 700 + 500, np.int64), np.full(600, 524288 + 3, np.int64), np.full(400, 2 * 524288 + 3, np.int64)])
+    for nsample in (16, 200):
+        want, want_pc = oracle.region_grow(pos, labels, batch, [], nsample=nsample, radius=radius, min_cluster_size=10)
+        csr, pc = ops.region_grow_csr(dev(pos), dev(labels), dev(batch), torch.zeros(0, dtype=torch.int64), nsample, radius, 10, 2)
+        got = [c.cpu().numpy() for c in csr.to_list()]
+        assert len(got) == len(want) and len(want) >= 3
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert np.array_equal(pc.cpu().numpy(), want_pc)
 
 
 def test_region_grow_degenerate(ops):
