@@ -123,14 +123,16 @@ int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* b
                      const int32_t* start, const uint64_t* bits, const uint16_t* pre, int32_t unit_src,
                      int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,
                      int64_t* n_pairs /*device, may be NULL*/, uint32_t* mask_out /*[n_out] occupied offsets, may be NULL*/,
+                     const int32_t* translate /*may be NULL: found rows r are stored as translate[r] (the indexed level's
+                                                physical row order, pp_level_permute)*/,
                      pp_stream_t stream);
 
 /* Tile scheduling at map-build time (csrc/pp_maporder.hip).  The convolution executes a kernel offset for a 16-row
  * MFMA tile as soon as one of its rows has that neighbour, so every map gets a SLOT ORDER in which the rows of a tile
- * want the same offsets: inside windows of pp_map_window() consecutive rows, rows are sorted by (batch element, neighbour
- * mask with the rarest offset classes most significant, row).
+ * want the same offsets: inside windows of pp_map_window() consecutive rows, rows are sorted by (neighbour mask with the
+ * rarest offset classes most significant, row).
  *   pp_map_mask      mask[o] = bit k set <=> nbr[k][o] >= 0            (pp_kernel_map_bi also emits it as mask_out)
- *   pp_map_order     order[s] = row taking slot s; coords (nullable, [n,4]) supplies the batch element
+ *   pp_map_order     order[s] = row taking slot s
  *   pp_map_permute   out[k][s] = T(nbr[k][order[s]]), T(v) = v < 0 ? -1 : (translate ? translate[v] : v); order NULL = identity;
  *                    window = the pp_map_window() `order` was built with (LDS-staged form) or 0 (any order)
  *   pp_level_permute coords_out[s] = coords[order[s]], inverse[order[s]] = s   (renumbering of a level: same-level maps
@@ -139,7 +141,7 @@ int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* b
 int32_t pp_map_window(void);
 int pp_map_set_window(int32_t window /*1024 | 2048 | 4096 | 8192 (default)*/);
 int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, pp_stream_t stream);
-int pp_map_order(const uint32_t* mask, const int32_t* coords, int64_t n, int32_t* order, pp_stream_t stream);
+int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_stream_t stream);
 int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
                    int32_t window, int32_t* out, pp_stream_t stream);
 int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,

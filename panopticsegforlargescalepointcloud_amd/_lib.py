@@ -36,7 +36,7 @@ SIGNATURES = {
     "pp_block_index_fill": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp]),
     "pp_block_index_coarsen_workspace": (sz, [i64]),
     "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pp_proposal_pairs_capacity": (i64, [i32]),
     "pp_proposal_pairs_workspace": (sz, [i64, i64, i32]),
     "pp_proposal_pairs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -50,7 +50,7 @@ SIGNATURES = {
     "pp_compose_perm": (C.c_int, [vp, vp, i64, vp, vp, vp]),
     "pp_map_window": (i32, []),
     "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
-    "pp_map_order": (C.c_int, [vp, vp, i64, vp, vp]),
+    "pp_map_order": (C.c_int, [vp, i64, vp, vp]),
     "pp_map_set_window": (C.c_int, [i32]),
     "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i32, vp, vp]),
     "pp_level_permute": (C.c_int, [vp, i64, vp, vp, vp, vp]),

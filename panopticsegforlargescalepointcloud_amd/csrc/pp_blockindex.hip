@@ -336,7 +336,8 @@ template <bool CUBE>
 __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ out_coords, int64_t n_out, BlockIndex I,
                                                        int unit_shift, int block_bits, int dstep,
                                                        int32_t* __restrict__ nbr, unsigned long long* n_pairs,
-                                                       uint32_t* __restrict__ mask_out) {
+                                                       uint32_t* __restrict__ mask_out,
+                                                       const int32_t* __restrict__ translate) {
   // grid-stride over the rows: the pair count is ONE atomic per wave at the very end (an atomic per wave and row chunk
   // on the same address serialises in L2: 154 k of them cost most of the 2 ms a 9.8 M-row map used to take)
   int found = 0;
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
           r = st[k] + (int)pre[k] + __popcll(word[k] & ((1ull << bit) - 1ull));
         found += r >= 0 ? 1 : 0;
         fmask |= (r >= 0 ? 1u : 0u) << k;
+        if (translate && r >= 0) r = translate[r];
         nbr[(int64_t)k * n_out + o] = r;
       }
     } else {
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
       }
       found += r >= 0 ? 1 : 0;
       fmask |= (r >= 0 ? 1u : 0u) << k;
+      if (translate && r >= 0) r = translate[r];
       nbr[(int64_t)k * n_out + o] = r;
     }
     }
@@ -472,7 +475,7 @@ static inline unsigned kmb_grid(int64_t n_out) { return (unsigned)std::min<int64
 extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals,
                                 int64_t cap, const int32_t* start, const uint64_t* bits, const uint16_t* pre,
                                 int32_t unit_src, int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr,
-                                int64_t* n_pairs, uint32_t* mask_out, pp_stream_t stream) {
+                                int64_t* n_pairs, uint32_t* mask_out, const int32_t* translate, pp_stream_t stream) {
   PP_REQUIRE(out_coords || n_out == 0, "pp_kernel_map_bi: null coordinates");
   PP_REQUIRE(bkeys && bvals && start && bits && pre && nbr, "pp_kernel_map_bi: null index");
   PP_REQUIRE(sign == 1 || sign == -1, "pp_kernel_map_bi: sign must be +1 or -1");
@@ -485,10 +488,10 @@ extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const 
   BlockIndex I{bkeys, bvals, cap, start, bits, pre};
   if (block_bits <= 4)
     hipLaunchKernelGGL(k_kernel_map_bi<true>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
-                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
+                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out, translate);
   else
     hipLaunchKernelGGL(k_kernel_map_bi<false>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
-                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out);
+                       I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out, translate);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

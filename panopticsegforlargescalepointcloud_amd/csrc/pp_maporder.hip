@@ -3,7 +3,7 @@
 // The dense-offset convolution (pp_spconv2.hip) executes a kernel offset for a 16-row MFMA tile as soon as ONE of the
 // tile's rows has that neighbour; with rows in plain block / Z-order only ~0.3 of the executed tile rows are real pairs on
 // the fine levels (profiles/r01_w_layer_table.md).  Here every kernel map gets its own SLOT ORDER: inside windows of
-// PP_MAP_WINDOW consecutive rows, output rows are sorted by (batch element, neighbour mask) so that the 16 rows of a tile
+// PP_MAP_WINDOW consecutive rows, output rows are sorted by neighbour mask so that the 16 rows of a tile
 // -- and the 32 / 64 rows of a wave -- want the same offsets (measured on the bench scene: executed tile rows per pair
 // 3.2 -> 1.8 on same-level maps, 2.4 -> 1.05 on transposed stride-2 maps, 4.6 -> 2.0 on strided maps).
 //   * same-level maps: the slot order IS the physical row order of the level (pp_level_permute renumbers the level), so
@@ -12,8 +12,8 @@
 //     physical output row (the convolution scatters 64-byte row segments inside a window -- L2 merges them).
 // Windows are consecutive rows of the block / Z-order, so neighbours stay a few thousand rows apart (L2-resident).
 // Mask bits are compared rarest-class first (corner offsets, then edges, faces, centre): rows that differ only in the
-// common offsets end up next to each other.  The sort is a hand-written bitonic network in LDS, one workgroup per
-// window, on 49-bit composite keys (batch low bits | remapped mask | row in window): a total order, hence deterministic.
+// common offsets end up next to each other.  The sort is a hand-written stable radix sort, one workgroup per window, rows
+// in registers: ordered by (remapped mask, row in window) -- a total order, hence deterministic.
 // Reference: none -- MinkowskiEngine keeps kernel maps as unordered (in, out) pair lists per offset; results of the
 // convolution do not depend on the row order (every output row is still written exactly once, same summation order).
 #include "pp_common.h"
@@ -65,44 +65,79 @@ extern "C" int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_
 }
 
 // ---- window sort ---------------------------------------------------------------------------------------------------------
-// one workgroup per window: composite keys in LDS, bitonic network, order[w * W + j] = row with the j-th smallest key
+// one workgroup per window of W rows, 8 rows per thread in registers: stable LSD radix sort of the remapped 27-bit masks,
+// two bits per pass.  A pass: every thread counts its 8 digits in four packed 16-bit counters (one 64-bit word), the
+// workgroup scans that word (wave scan by shuffles, the 16 wave totals through LDS), the rows move to
+// base[digit] + rows with that digit in front of them through an LDS exchange.  Stable, so equal masks stay in row
+// order: the result is sorted by (mask, row) -- a total order, hence deterministic.  ~170 vector instructions per row in
+// all, against ~730 for the bitonic network this replaces (91 compare-exchange stages on 64-bit keys; 300 -> 110 us for
+// the 10 M rows of the bench scene's finest level).
 template <int W>
-__global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restrict__ mask, const int4* __restrict__ coords,
-                                                       int64_t n, int32_t* __restrict__ order) {
-  constexpr int NT = W / 8;
-  __shared__ unsigned long long key[W];
+__global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restrict__ mask, int64_t n, int32_t* __restrict__ order) {
+  constexpr int NT = W / 8, NW = NT / 64;
+  __shared__ uint32_t kl[W];
+  __shared__ unsigned short il[W];
+  __shared__ unsigned long long wtot[NW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t base = (int64_t)blockIdx.x * W;
   const int cnt = (int)((n - base) < W ? (n - base) : W);
-  for (int j = threadIdx.x; j < W; j += NT) {
-    unsigned long long kk = ~0ull;  // padding sorts to the end
-    if (j < cnt) {
-      const uint32_t b = coords ? ((uint32_t)coords[base + j].x & 0xFFu) : 0u;
-      kk = ((unsigned long long)b << (MO_MASK_BITS + MO_IDX_BITS)) |
-           ((unsigned long long)mo_remap(mask[base + j] & 0x7FFFFFFu) << MO_IDX_BITS) | (unsigned long long)j;
-    }
-    key[j] = kk;
+  uint32_t key[8];
+  int idx[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = t * 8 + r;
+    key[r] = e < cnt ? mo_remap(mask[base + e] & 0x7FFFFFFu) : 0x7FFFFFFu;  // padding: the largest key, and behind its equals
+    idx[r] = e;
   }
-  __syncthreads();
-  int len = 2;
-  while (len < cnt) len <<= 1;  // smallest power of two >= cnt (>= 2); the padding beyond cnt is already the maximum
-  for (int k = 2; k <= len; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (len >> 1); t += NT) {
-        // t-th compare-exchange of this stage: partner indices i < l with l = i | j
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const bool up = (i & k) == 0;
-        const unsigned long long a = key[i], b = key[l];
-        if ((a > b) == up) {
-          key[i] = b;
-          key[l] = a;
-        }
-      }
-      __syncthreads();
+#pragma unroll 1
+  for (int bit = 0; bit < MO_MASK_BITS; bit += 2) {
+    unsigned long long c = 0;
+    int lr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int sh = (int)((key[r] >> bit) & 3u) * 16;
+      lr[r] = (int)((c >> sh) & 0xFFFFull);
+      c += 1ull << sh;
     }
+    unsigned long long incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long v = (unsigned long long)__shfl_up((long long)incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned long long v = wtot[w];
+      if (w < wave) woff += v;
+      total += v;
+    }
+    // start of every digit's range: rows with smaller digits
+    const unsigned long long t0 = total & 0xFFFFull, t1 = (total >> 16) & 0xFFFFull, t2 = (total >> 32) & 0xFFFFull;
+    const unsigned long long pb = incl - c + woff + ((t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int sh = (int)((key[r] >> bit) & 3u) * 16;
+      const int pos = (int)((pb >> sh) & 0xFFFFull) + lr[r];
+      kl[pos] = key[r];
+      il[pos] = (unsigned short)idx[r];
+    }
+    __syncthreads();
+    const uint4 k0 = *(const uint4*)&kl[t * 8], k1 = *(const uint4*)&kl[t * 8 + 4];
+    const uint4 i4 = *(const uint4*)&il[t * 8];
+    key[0] = k0.x; key[1] = k0.y; key[2] = k0.z; key[3] = k0.w;
+    key[4] = k1.x; key[5] = k1.y; key[6] = k1.z; key[7] = k1.w;
+    idx[0] = i4.x & 0xFFFF; idx[1] = i4.x >> 16; idx[2] = i4.y & 0xFFFF; idx[3] = i4.y >> 16;
+    idx[4] = i4.z & 0xFFFF; idx[5] = i4.z >> 16; idx[6] = i4.w & 0xFFFF; idx[7] = i4.w >> 16;
+    __syncthreads();  // everything is back in registers before the next pass refills the exchange buffers
   }
-  for (int j = threadIdx.x; j < cnt; j += NT)
-    order[base + j] = (int32_t)(base + (int64_t)(key[j] & ((1ull << MO_IDX_BITS) - 1ull)));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int e = t * 8 + r;
+    if (e < cnt) order[base + e] = (int32_t)(base + idx[r]);
+  }
 }
 
 extern "C" int32_t pp_map_window(void) { return g_window; }
@@ -112,17 +147,16 @@ extern "C" int pp_map_set_window(int32_t window) {
   return PP_OK;
 }
 
-extern "C" int pp_map_order(const uint32_t* mask, const int32_t* coords, int64_t n, int32_t* order, pp_stream_t stream) {
+extern "C" int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_stream_t stream) {
   PP_REQUIRE((mask && order) || n == 0, "pp_map_order: null pointer");
   PP_REQUIRE(n < (1ll << 31), "pp_map_order: more than 2^31 rows");
   if (n == 0) return PP_OK;
   hipStream_t s = pp_s(stream);
-  const int4* c4 = (const int4*)coords;
   switch (g_window) {
-    case 1024: hipLaunchKernelGGL(k_window_sort<1024>, dim3(pp_blocks(n, 1024)), dim3(128), 0, s, mask, c4, n, order); break;
-    case 2048: hipLaunchKernelGGL(k_window_sort<2048>, dim3(pp_blocks(n, 2048)), dim3(256), 0, s, mask, c4, n, order); break;
-    case 4096: hipLaunchKernelGGL(k_window_sort<4096>, dim3(pp_blocks(n, 4096)), dim3(512), 0, s, mask, c4, n, order); break;
-    default: hipLaunchKernelGGL(k_window_sort<8192>, dim3(pp_blocks(n, 8192)), dim3(1024), 0, s, mask, c4, n, order); break;
+    case 1024: hipLaunchKernelGGL(k_window_sort<1024>, dim3(pp_blocks(n, 1024)), dim3(128), 0, s, mask, n, order); break;
+    case 2048: hipLaunchKernelGGL(k_window_sort<2048>, dim3(pp_blocks(n, 2048)), dim3(256), 0, s, mask, n, order); break;
+    case 4096: hipLaunchKernelGGL(k_window_sort<4096>, dim3(pp_blocks(n, 4096)), dim3(512), 0, s, mask, n, order); break;
+    default: hipLaunchKernelGGL(k_window_sort<8192>, dim3(pp_blocks(n, 8192)), dim3(1024), 0, s, mask, n, order); break;
   }
   PP_LAUNCH_CHECK();
   return PP_OK;
@@ -130,25 +164,62 @@ extern "C" int pp_map_order(const uint32_t* mask, const int32_t* coords, int64_t
 
 // ---- applying an order -----------------------------------------------------------------------------------------------------
 // out[k][s] = T(nbr[k][order[s]]),  T(v) = v < 0 ? -1 : (translate ? translate[v] : v).
-// `order` is window-local (pp_map_order), so one workgroup stages the window's slice of ONE offset in LDS with coalesced
-// loads, gathers from LDS and writes coalesced: the 27 scattered 4-byte global reads per row of the naive form
-// (14.7 ms per bench step) become LDS reads.  window = 0 selects the naive form (any order / no order).
+// `order` is window-local (pp_map_order), so a workgroup stages the window's slices in LDS with coalesced loads, gathers
+// from LDS and writes coalesced: the 27 scattered 4-byte global reads per row of the naive form (14.7 ms per bench step)
+// become LDS reads.  window = 0 selects the naive form (any order / no order).
 template <int W>
-__global__ __launch_bounds__(256) void k_map_permute_win(const int32_t* __restrict__ nbr, int64_t n,
-                                                         const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
-                                                         int32_t* __restrict__ out) {
-  __shared__ int32_t row[W];
+__global__ __launch_bounds__(1024) void k_map_permute_win(const int32_t* __restrict__ nbr, int K, int64_t n,
+                                                          const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
+                                                          int32_t* __restrict__ out) {
+  // one workgroup per window, all K offsets: the window's order (16-bit local) and, with `translate`, the window's own
+  // slice of it stay in LDS -- most neighbours of a window's rows live in the window itself (rows are in block order), so
+  // the translation is an LDS read for them and a global gather only across window borders; the K slices of the map
+  // stream through registers (next slice's loads in flight while the current one is permuted)
+  constexpr int NT = 1024, PER = (W + NT - 1) / NT;
+  __shared__ int32_t cur[W];
+  __shared__ int32_t tr[W];
+  __shared__ unsigned short ord[W];
   const int64_t base = (int64_t)blockIdx.x * W;
-  const int k = blockIdx.y;
   const int cnt = (int)((n - base) < W ? (n - base) : W);
-  const int32_t* src = nbr + (int64_t)k * n + base;
-  for (int j = threadIdx.x; j < cnt; j += 256) row[j] = src[j];
-  __syncthreads();
-  int32_t* dst = out + (int64_t)k * n + base;
-  for (int j = threadIdx.x; j < cnt; j += 256) {
-    int32_t v = row[order[base + j] - (int32_t)base];
-    if (translate && v >= 0) v = translate[v];
-    dst[j] = v;
+  for (int j = threadIdx.x; j < cnt; j += NT) {
+    ord[j] = (unsigned short)(order[base + j] - (int32_t)base);
+    if (translate) tr[j] = translate[base + j];
+  }
+  int32_t stage[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int j = threadIdx.x + NT * u;
+    stage[u] = j < cnt ? nbr[base + j] : -1;
+  }
+  for (int k = 0; k < K; ++k) {
+    if (k) __syncthreads();  // the previous slice has been read
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = threadIdx.x + NT * u;
+      if (j < cnt) cur[j] = stage[u];
+    }
+    __syncthreads();
+    if (k + 1 < K) {
+      const int32_t* src = nbr + (int64_t)(k + 1) * n + base;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int j = threadIdx.x + NT * u;
+        stage[u] = j < cnt ? src[j] : -1;
+      }
+    }
+    int32_t* dst = out + (int64_t)k * n + base;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = threadIdx.x + NT * u;
+      if (j < cnt) {
+        int32_t v = cur[ord[j]];
+        if (translate && v >= 0) {
+          const int64_t l = (int64_t)v - base;
+          v = (l >= 0 && l < cnt) ? tr[l] : translate[v];
+        }
+        dst[j] = v;
+      }
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_map_permute(const int32_t* __restrict__ nbr, int K, int64_t n,
@@ -173,12 +244,12 @@ extern "C" int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, cons
   hipStream_t s = pp_s(stream);
   if (order && window > 0) {
     PP_REQUIRE(window == 1024 || window == 2048 || window == 4096 || window == 8192, "pp_map_permute: bad window");
-    const dim3 grid(pp_blocks(n_out, window), (unsigned)K);
+    const dim3 grid(pp_blocks(n_out, window));
     switch (window) {
-      case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
-      case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
-      case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
-      default: hipLaunchKernelGGL(k_map_permute_win<8192>, grid, dim3(256), 0, s, nbr, n_out, order, translate, out); break;
+      case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
+      case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
+      case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
+      default: hipLaunchKernelGGL(k_map_permute_win<8192>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
     }
   } else
     hipLaunchKernelGGL(k_map_permute, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, nbr, K, n_out, order, translate, out);

@@ -241,8 +241,9 @@ def block_index_coarsen(fine, n_fine_rows):
     return bi, coords[:nc]
 
 
-def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False):
-    """nbr int32 [27, n_out] through a BlockIndex: row in the indexed level of out_coords + sign*offset*step (or -1)."""
+def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, translate=None):
+    """nbr int32 [27, n_out] through a BlockIndex: row in the indexed level of out_coords + sign*offset*step (or -1).
+    translate (int32 [rows of the indexed level], optional): found rows r are stored as translate[r]."""
     if ksize != 3:
         raise NotImplementedError("kernel_map_bi: 3x3x3 kernels only")
     lib = _lib.load()
@@ -253,7 +254,8 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False):
     mask = torch.empty(max(n_out, 1), dtype=torch.int32, device=out_coords.device) if want_mask else None
     _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap, _ptr(index.start),
                                     _ptr(index.bits), _ptr(index.pre), index.unit, index.block_bits, int(step), int(sign),
-                                    _ptr(nbr), _ptr(pairs), _ptr(mask), _stream()), "pp_kernel_map_bi")
+                                    _ptr(nbr), _ptr(pairs), _ptr(mask), _ptr(_need(translate, torch.int32, "translate")),
+                                    _stream()), "pp_kernel_map_bi")
     nbr.pp_pairs = pairs
     if want_mask:
         nbr.pp_mask = mask  # int32 [n_out]: bit k set <=> offset k occupied
@@ -269,16 +271,14 @@ def map_mask(nbr):
     return mask[:n_out]
 
 
-def map_order(mask, coords=None):
+def map_order(mask):
     """slot order of a kernel map (csrc/pp_maporder.hip): order[s] = output row taking slot s.  Rows are sorted by
-    (batch element, neighbour mask) inside windows of pp_map_window() consecutive rows; `coords` ([n,4] int32, optional)
-    supplies the batch element."""
+    (neighbour mask, row) inside windows of pp_map_window() consecutive rows."""
     lib = _lib.load()
     mask = _need(mask, torch.int32, "mask")
-    coords = _need(coords, torch.int32, "coords")
     n = mask.shape[0]
     order = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)
-    _lib.check(lib.pp_map_order(_ptr(mask), _ptr(coords), n, _ptr(order), _stream()), "pp_map_order")
+    _lib.check(lib.pp_map_order(_ptr(mask), n, _ptr(order), _stream()), "pp_map_order")
     order = order[:n]
     order.pp_window = int(lib.pp_map_window())  # map_permute stages window slices in LDS
     return order

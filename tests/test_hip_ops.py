@@ -647,7 +647,7 @@ def _mask_sort_rank(mask):
 
 
 def test_map_order_and_slot_ordered_maps(ops, oracle):
-    """pp_map_order is a window-local permutation sorted by (batch, remapped neighbour mask, row); pp_map_permute /
+    """pp_map_order is a window-local permutation sorted by (remapped neighbour mask, row); pp_map_permute /
     pp_level_permute / pp_kernel_map_transpose(order) restate the map in slot order; pp_spconv_fwd on the slot-ordered
     map + row_order is bit-identical to the plain map (same per-row summation order), incl. cat / BN / ReLU / residual."""
     rng = np.random.default_rng(32)
@@ -662,12 +662,11 @@ def test_map_order_and_slot_ordered_maps(ops, oracle):
         want_mask = ((nbr.cpu().numpy() >= 0).astype(np.int64) << np.arange(27)[:, None]).sum(0)
         assert np.array_equal(mask, want_mask)
         assert np.array_equal(ops.map_mask(nbr).cpu().numpy().astype(np.int64), want_mask)
-        order = ops.map_order(nbr.pp_mask, dev(fine))
+        order = ops.map_order(nbr.pp_mask)
         o = order.cpu().numpy().astype(np.int64)
         assert np.array_equal(np.sort(o), np.arange(n))
         assert np.array_equal(o // lib_window, np.arange(n) // lib_window)          # rows never leave their window
-        key = ((np.arange(n) // lib_window) << 50) | ((fine[o, 0].astype(np.int64) & 255) << 40) | (_mask_sort_rank(mask[o]) << 13) \
-            | (o % lib_window)
+        key = ((np.arange(n) // lib_window) << 50) | (_mask_sort_rank(mask[o]) << 13) | (o % lib_window)
         assert np.all(np.diff(key) > 0)
         # renumbered level + same-level map in physical ids
         coords_p, phys_of = ops.level_permute(dev(fine), order)
@@ -683,13 +682,15 @@ def test_map_order_and_slot_ordered_maps(ops, oracle):
         coarse = np.unique(np.concatenate([fine[:, :1], fine[:, 1:] // 2 * 2], 1), axis=0).astype(np.int32)
         coarse = coarse[ops.morton_order(dev(coarse), 2, 4).cpu().numpy()]
         down = ops.kernel_map_bi(dev(coarse), idx, 3, 1, 1, want_mask=True)      # coarse rows gather fine (block-order) rows
-        od = ops.map_order(down.pp_mask, dev(coarse))
+        od = ops.map_order(down.pp_mask)
         down_s = ops.map_permute(down, od, translate=phys_of)
+        down_t = ops.kernel_map_bi(dev(coarse), idx, 3, 1, 1, translate=phys_of)  # translation folded into the lookup
+        assert torch.equal(down_t, ops.map_permute(down, None, translate=phys_of))
         od_np = od.cpu().numpy()
         assert np.array_equal(down_s.cpu().numpy(), oracle.kernel_map(coarse[od_np], fine[o], 3, 1, 1))
         up = ops.kernel_map_transpose(down_s, n, order=od)                        # rows = fine physical rows, values = coarse rows
         assert np.array_equal(up.cpu().numpy(), oracle.kernel_map(fine[o], coarse, 3, 1, -1))
-        ou = ops.map_order(ops.map_mask(up), coords_p)
+        ou = ops.map_order(ops.map_mask(up))
         up_s = ops.map_permute(up, ou)
         for (m_plain, m_slot, m_order, n_in, n_out, cin, cout, c1) in [
                 (dev(same), dev(same), None, n, n, 16, 16, 0),
