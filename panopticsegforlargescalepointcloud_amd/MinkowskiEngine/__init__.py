@@ -94,12 +94,15 @@ class _Level:
 
 
 def _order_level(coords_m, index, ts):
-    """physical order of a level from its same-level map: (coords_p, order, phys_of, same_map in physical ids)"""
+    """physical order of a level from its same-level map: (coords_p, order, phys_of, finish) -- `finish()` returns the
+    same-level map in physical ids.  The level (coords_p, phys_of) is usable before that last pass has run: a strided map
+    onto the level only needs its row order, so the caller can build it first (the scorer's first convolution is strided
+    and waits for exactly that chain)."""
     nbr_m = ops.kernel_map_bi(coords_m, index, 3, ts, 1, want_mask=True)
     order = ops.map_order(nbr_m.pp_mask)
+    del nbr_m.pp_mask
     coords_p, phys_of = ops.level_permute(coords_m, order)
-    same = ops.map_permute(nbr_m, order, translate=phys_of)
-    return coords_p, order, phys_of, same
+    return coords_p, order, phys_of, lambda: ops.map_permute(nbr_m, order, translate=phys_of)
 
 
 class _PermuteRowsFn(torch.autograd.Function):
@@ -159,8 +162,8 @@ class CoordinateManager:
             index, ndup = ops.block_index_build(coords, 1, ORDER_BLOCK_BITS)
             level = _Level(coords, index=index)
             if MAP_ORDER and ndup == 0 and coords.shape[0] >= MAP_ORDER_MIN_ROWS:
-                coords_p, order, phys_of, same = _order_level(coords, index, 1)
-                level = _Level(coords_p, index=index, phys_of=phys_of, same_map=same)
+                coords_p, order, phys_of, finish = _order_level(coords, index, 1)
+                level = _Level(coords_p, index=index, phys_of=phys_of, same_map=finish())
             if perm32 is not None:  # internal row p = caller row perm[p]
                 self.perm, self.inv_perm = ops.compose_perm(perm32, order, coords.shape[0], coords.device)
         else:
@@ -171,6 +174,7 @@ class CoordinateManager:
                              "(GridSampling3D guarantees it; ME's random sub-sampling of duplicates is not reproduced)" % ndup)
         self.levels = {1: level}
         self.maps = {}
+        self._pending_same = {}
         if level.same_map is not None:
             self.maps[(1, 1, 3, 1)] = level.same_map
         # prefetch support: one lock around level / map construction, an event per built item (the builder's stream
@@ -265,10 +269,9 @@ class CoordinateManager:
                 else:
                     level = _Level(out, table=table)
             if MAP_ORDER and level.index is not None and level.n >= MAP_ORDER_MIN_ROWS:
-                coords_p, _, phys_of, same = _order_level(level.coords, level.index, ts_out)
-                level = _Level(coords_p, index=level.index, phys_of=phys_of, same_map=same)
-                self._built((ts_out, ts_out, 3, 1))
-                self.maps[(ts_out, ts_out, 3, 1)] = same
+                coords_p, _, phys_of, finish = _order_level(level.coords, level.index, ts_out)
+                level = _Level(coords_p, index=level.index, phys_of=phys_of)
+                self._pending_same[ts_out] = finish  # run by the first request for the level's same-level map
             self._built(("level", ts_out))  # event first: lock-free readers find the item only with its event
             self.levels[ts_out] = level
         return ts_out
@@ -311,7 +314,10 @@ class CoordinateManager:
             if rev is not None:
                 self._use((ts_to, ts_from, ksize, -sign))
             dst = self.levels[ts_to]
-            if rev is not None and ts_from == ts_to:
+            finish = self._pending_same.pop(ts_to, None) if (ts_from == ts_to and sign == 1 and ksize == 3) else None
+            if finish is not None:
+                m = dst.same_map = finish()
+            elif rev is not None and ts_from == ts_to:
                 m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
                 if hasattr(rev, "pp_pairs"):
                     m.pp_pairs = rev.pp_pairs
