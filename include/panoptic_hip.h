@@ -93,11 +93,12 @@ int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int
  * K1b/K3c  block index of a level + kernel maps through it (what the coordinate manager uses; the
  * row-level hash of pp_hash_build / pp_kernel_map gives the same maps and stays available).
  * The rows must already be in pp_morton_order(unit, block_bits) order.  Per group of <= 4096 voxels
- * (key >> 12) the index keeps the first row, a 4096-bit occupancy map in key order and per-word
- * prefix counts; a voxel's row is start + prefix + popcount.  Two steps because the number of blocks
- * sizes the arrays: count (row_block int32 [n]; counts int32[4] = {blocks, duplicated rows, unsorted
- * pairs, rows outside the key range}) then fill (bkeys/bvals [cap], cap = pp_block_index_capacity;
- * start int32 [n_blocks]; bits uint64 [n_blocks*64]; pre uint16 [n_blocks*64]).
+ * (key >> 12) the index keeps the first row and 64 records {64 bits of the 4096-bit occupancy map in key
+ * order, row of the first voxel of that word}; a voxel's row is record.row + popcount(record.bits below
+ * its bit): one 16-byte load.  Two steps because the number of blocks sizes the arrays: count (row_block
+ * int32 [n]; counts int32[4] = {blocks, duplicated rows, unsorted pairs, rows outside the key range}) then
+ * fill (bkeys/bvals [cap], cap = pp_block_index_capacity; start int32 [n_blocks]; rec uint64 [n_blocks*128]:
+ * word pairs (bits, row)).
  * pp_kernel_map_bi: same definition as pp_kernel_map (nbr[k][o] = row of out_coords[o] + sign*offset_k*step
  * in the indexed level, -1 if absent or off its lattice).
  * ---------------------------------------------------------------------------------------------- */
@@ -107,7 +108,7 @@ int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int32_t unit, 
                          int32_t* counts /*int32[4]*/, void* workspace, size_t workspace_bytes, pp_stream_t stream);
 int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
                         const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals, int64_t cap,
-                        int32_t* start, uint64_t* bits, uint16_t* pre,
+                        int32_t* start, uint64_t* rec /*[n_blocks*128]*/,
                         uint64_t* bkey_ord /*[n_blocks] block keys in block order, may be NULL*/, pp_stream_t stream);
 /* The next coarser level (tensor stride unit_coarse = 2 x the indexed level's) computed from the index alone: with
  * the parity-block order the coarse bitmaps are bit permutations of the fine ones (replaces K2, pp_stride_coords +
@@ -115,12 +116,12 @@ int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, i
  * the fine level (nb_fine blocks, cap = pp_block_index_capacity(nb_fine), n_fine rows for coords [.,4]);
  * counts = {coarse blocks, coarse rows}.  Rows come out in the coarse level's own order. */
 size_t pp_block_index_coarsen_workspace(int64_t nb_fine);
-int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_bits, int64_t nb_fine, int32_t unit_coarse,
+int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine, int32_t unit_coarse,
                            int32_t block_bits, uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
-                           uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord, int32_t* coords, int32_t* counts /*int32[2]*/,
+                           uint64_t* rec, uint64_t* bkey_ord, int32_t* coords, int32_t* counts /*int32[2]*/,
                            void* workspace, size_t workspace_bytes, pp_stream_t stream);
 int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals, int64_t cap,
-                     const int32_t* start, const uint64_t* bits, const uint16_t* pre, int32_t unit_src,
+                     const uint64_t* rec, int32_t unit_src,
                      int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,
                      int64_t* n_pairs /*device, may be NULL*/, uint32_t* mask_out /*[n_out] occupied offsets, may be NULL*/,
                      const int32_t* translate /*may be NULL: found rows r are stored as translate[r] (the indexed level's

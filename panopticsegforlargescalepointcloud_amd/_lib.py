@@ -33,10 +33,10 @@ SIGNATURES = {
     "pp_block_index_workspace": (sz, [i64]),
     "pp_block_index_capacity": (i64, [i64]),
     "pp_block_index_count": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),
-    "pp_block_index_fill": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp]),
+    "pp_block_index_fill": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp]),
     "pp_block_index_coarsen_workspace": (sz, [i64]),
-    "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pp_proposal_pairs_capacity": (i64, [i32]),
     "pp_proposal_pairs_workspace": (sz, [i64, i64, i32]),
     "pp_proposal_pairs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

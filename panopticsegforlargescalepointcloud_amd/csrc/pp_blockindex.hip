@@ -4,11 +4,10 @@
 // 12 bits enumerate the positions inside a group of at most 4096 voxels (a 16^3 block), its upper bits name the group.
 // The index stores, per occupied group ("block"),
 //     start   first row of the block                                   int32
-//     bits    4096-bit occupancy map in key order (64 x uint64)
-//     pre     number of occupied positions before each 64-bit word     uint16 x 64
+//     rec     64 x { 64 bits of the 4096-bit occupancy map in key order, row of the first voxel of that word }   (16 B each)
 // plus a small open-addressing hash  block key -> block number.  The row of a voxel is then
-//     start[b] + pre[b][w] + popcount(bits[b][w] & lower bits)          (w = word of its 12-bit code)
-// i.e. ONE 8-byte word (+ 2 bytes) from a 640-byte record shared by ~300 voxels, instead of a 12-byte probe of a
+//     rec[b][w].row + popcount(rec[b][w].bits & lower bits)             (w = word of its 12-bit code)
+// i.e. ONE 16-byte load from a 1-KiB record shared by the voxels of the block, instead of a 12-byte probe of a
 // row-level hash table spread over ~10 KiB per block: the 27 lookups of a kernel-map row and of its neighbours in the
 // wave hit the same few records in L1/L2.  The block hash is probed only when a neighbour leaves the previous block.
 // Replaces the per-row hash probing of pp_kernel_map for the coordinate manager (same map definition, same results;
@@ -21,9 +20,7 @@ struct BlockIndex {
   const uint64_t* bkeys;
   const int32_t* bvals;
   int64_t cap;
-  const int32_t* start;
-  const uint64_t* bits;
-  const uint16_t* pre;
+  const ulonglong2* rec;  // [n_blocks * 64]: x = occupancy word, y = row of the word's first voxel
 };
 
 __device__ inline int bi_find_block(const BlockIndex& I, uint64_t blk) {
@@ -70,14 +67,14 @@ __global__ __launch_bounds__(256) void k_bi_hash_fill(uint64_t* keys, int64_t ca
 __global__ __launch_bounds__(256) void k_bi_scatter(const int4* __restrict__ coords, int64_t n, int unit_shift,
                                                     int block_bits, const int32_t* __restrict__ row_block,
                                                     uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
-                                                    unsigned long long* bits, uint64_t* bkey_ord) {
+                                                    unsigned long long* rec, uint64_t* bkey_ord) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = coords[i];
   const uint64_t key = pp_order_key(c.x, c.y, c.z, c.w, unit_shift, block_bits);
   const int b = row_block[i];
   const int code = (int)(key & 4095ull);
-  atomicOr(&bits[(size_t)b * BI_WORDS + (code >> 6)], 1ull << (code & 63));
+  atomicOr(&rec[2 * ((size_t)b * BI_WORDS + (code >> 6))], 1ull << (code & 63));
   if (i == 0 || row_block[i - 1] != b) {  // first row of the block: owns start[] and the hash entry
     start[b] = (int32_t)i;
     const uint64_t blk = key >> 12;
@@ -95,19 +92,19 @@ __global__ __launch_bounds__(256) void k_bi_scatter(const int4* __restrict__ coo
     }
   }
 }
-// one wave per block: exclusive prefix of the 64 word popcounts
-__global__ __launch_bounds__(256) void k_bi_prefix(const uint64_t* __restrict__ bits, int64_t nb, uint16_t* pre) {
+// one wave per block: first row of every word = start of the block + exclusive prefix of the 64 word popcounts
+__global__ __launch_bounds__(256) void k_bi_prefix(unsigned long long* rec, const int32_t* __restrict__ start, int64_t nb) {
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= nb) return;
-  const int c = __popcll(bits[(size_t)b * BI_WORDS + lane]);
+  const int c = __popcll(rec[2 * ((size_t)b * BI_WORDS + lane)]);
   int incl = c;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(incl, off);
     if (lane >= off) incl += v;
   }
-  pre[(size_t)b * BI_WORDS + lane] = (uint16_t)(incl - c);
+  rec[2 * ((size_t)b * BI_WORDS + lane) + 1] = (unsigned long long)(unsigned)(start[b] + incl - c);
 }
 
 extern "C" size_t pp_block_index_workspace(int64_t n) {
@@ -146,21 +143,20 @@ extern "C" int pp_block_index_count(const int32_t* coords_sorted, int64_t n, int
 }
 extern "C" int pp_block_index_fill(const int32_t* coords_sorted, int64_t n, int32_t unit, int32_t block_bits,
                                    const int32_t* row_block, int64_t n_blocks, uint64_t* bkeys, int32_t* bvals,
-                                   int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord,
-                                   pp_stream_t stream) {
-  PP_REQUIRE(bkeys && bvals && start && bits && pre, "pp_block_index_fill: null output");
+                                   int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord, pp_stream_t stream) {
+  PP_REQUIRE(bkeys && bvals && start && rec, "pp_block_index_fill: null output");
   PP_REQUIRE(cap >= 2 * n_blocks && (cap & (cap - 1)) == 0, "pp_block_index_fill: cap must be a power of two >= 2 n_blocks");
   hipStream_t s = pp_s(stream);
   int unit_shift = 0;
   while ((1 << unit_shift) < unit) ++unit_shift;
   hipLaunchKernelGGL(k_bi_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, bkeys, cap);
   PP_LAUNCH_CHECK();
-  if (n_blocks > 0) PP_HIP(hipMemsetAsync(bits, 0, sizeof(uint64_t) * BI_WORDS * (size_t)n_blocks, s));
+  if (n_blocks > 0) PP_HIP(hipMemsetAsync(rec, 0, 2 * sizeof(uint64_t) * BI_WORDS * (size_t)n_blocks, s));
   if (n == 0) return PP_OK;
   hipLaunchKernelGGL(k_bi_scatter, dim3(pp_blocks(n, 256)), dim3(256), 0, s, (const int4*)coords_sorted, n, unit_shift,
-                     block_bits, row_block, bkeys, bvals, cap, start, (unsigned long long*)bits, bkey_ord);
+                     block_bits, row_block, bkeys, bvals, cap, start, (unsigned long long*)rec, bkey_ord);
   PP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bi_prefix, dim3(pp_blocks(n_blocks, 4)), dim3(256), 0, s, bits, n_blocks, pre);
+  hipLaunchKernelGGL(k_bi_prefix, dim3(pp_blocks(n_blocks, 4)), dim3(256), 0, s, (unsigned long long*)rec, start, n_blocks);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -191,9 +187,9 @@ __global__ __launch_bounds__(256) void k_bic_first_child(const int32_t* __restri
   if (b < nb && flag[b]) first_child[rank[b]] = (int32_t)b;
 }
 // one wave per coarse block: its bitmap from the children's bitmaps, its voxel count and key
-__global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ fbits,
+__global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ frec,
                                                   int64_t nb_f, const int32_t* __restrict__ first_child,
-                                                  const int32_t* __restrict__ n_coarse, uint64_t* cbits, int32_t* ccount,
+                                                  const int32_t* __restrict__ n_coarse, uint64_t* crec, int32_t* ccount,
                                                   uint64_t* ckey) {
   __shared__ unsigned long long lds[4][BI_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ f
     if (lane < 8) {
       unsigned long long o = 0ull;
 #pragma unroll
-      for (int par = 0; par < 8; ++par) o |= fbits[(size_t)b * BI_WORDS + par * 8 + lane];
+      for (int par = 0; par < 8; ++par) o |= frec[2 * ((size_t)b * BI_WORDS + par * 8 + lane)];
       while (o) {
         const int bit = __builtin_ctzll(o);
         o &= o - 1ull;
@@ -225,7 +221,7 @@ __global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ f
   }
   __builtin_amdgcn_wave_barrier();
   const unsigned long long mine = w[lane];
-  cbits[(size_t)c * BI_WORDS + lane] = mine;
+  crec[2 * ((size_t)c * BI_WORDS + lane)] = mine;
   int cnt = __popcll(mine);
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
   if (lane == 0) {
@@ -234,14 +230,13 @@ __global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ f
   }
 }
 // one wave per coarse block: prefix counts, hash entry, coordinate rows (decoded from block key + code)
-__global__ __launch_bounds__(256) void k_bic_finish(const uint64_t* __restrict__ ckey, const uint64_t* __restrict__ cbits,
+__global__ __launch_bounds__(256) void k_bic_finish(const uint64_t* __restrict__ ckey, uint64_t* crec,
                                                     const int32_t* __restrict__ cstart, const int32_t* __restrict__ n_coarse,
-                                                    int unit_shift, uint64_t* bkeys, int32_t* bvals, int64_t cap,
-                                                    uint16_t* cpre, int4* coords) {
+                                                    int unit_shift, uint64_t* bkeys, int32_t* bvals, int64_t cap, int4* coords) {
   const int lane = threadIdx.x & 63;
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= n_coarse[0]) return;
-  unsigned long long word = cbits[(size_t)c * BI_WORDS + lane];
+  unsigned long long word = crec[2 * ((size_t)c * BI_WORDS + lane)];
   const int cnt = __popcll(word);
   int incl = cnt;
 #pragma unroll
@@ -250,7 +245,7 @@ __global__ __launch_bounds__(256) void k_bic_finish(const uint64_t* __restrict__
     if (lane >= off) incl += v;
   }
   const int before = incl - cnt;
-  cpre[(size_t)c * BI_WORDS + lane] = (uint16_t)before;
+  crec[2 * ((size_t)c * BI_WORDS + lane) + 1] = (uint64_t)(unsigned)(cstart[c] + before);
   const uint64_t blk = ckey[c];
   if (lane == 0) {
     const uint64_t mask = (uint64_t)cap - 1;
@@ -283,12 +278,11 @@ extern "C" size_t pp_block_index_coarsen_workspace(int64_t nb_fine) {
 }
 // All outputs have capacity nb_fine blocks (cap = pp_block_index_capacity(nb_fine)) resp. n_fine rows; counts = {coarse
 // blocks, coarse rows}.  unit_coarse = tensor stride of the NEW level.  block_bits must be 4.
-extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_bits, int64_t nb_fine,
+extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine,
                                       int32_t unit_coarse, int32_t block_bits, uint64_t* bkeys, int32_t* bvals,
-                                      int64_t cap, int32_t* start, uint64_t* bits, uint16_t* pre, uint64_t* bkey_ord,
-                                      int32_t* coords, int32_t* counts, void* workspace, size_t workspace_bytes,
-                                      pp_stream_t stream) {
-  PP_REQUIRE(f_bkey_ord && f_bits && bkeys && bvals && start && bits && pre && bkey_ord && coords && counts,
+                                      int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord, int32_t* coords,
+                                      int32_t* counts, void* workspace, size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(f_bkey_ord && f_rec && bkeys && bvals && start && rec && bkey_ord && coords && counts,
              "pp_block_index_coarsen: null pointer");
   PP_REQUIRE(block_bits == 4, "pp_block_index_coarsen: needs the parity-block row order (block_bits = 4)");
   PP_REQUIRE(unit_coarse >= 2 && (unit_coarse & (unit_coarse - 1)) == 0, "pp_block_index_coarsen: unit must be a power of two >= 2");
@@ -313,13 +307,13 @@ extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t
   if (rc) return rc;
   hipLaunchKernelGGL(k_bic_first_child, dim3(gb), dim3(256), 0, s, flag, rank, nb_fine, first_child);
   PP_HIP(hipMemsetAsync(ccount, 0, sizeof(int32_t) * (size_t)nb_fine, s));
-  hipLaunchKernelGGL(k_bic_bits, dim3(gw), dim3(256), 0, s, f_bkey_ord, f_bits, nb_fine, first_child, counts, bits, ccount,
+  hipLaunchKernelGGL(k_bic_bits, dim3(gw), dim3(256), 0, s, f_bkey_ord, f_rec, nb_fine, first_child, counts, rec, ccount,
                      bkey_ord);
   PP_LAUNCH_CHECK();
   rc = pp_exclusive_scan_i32(ccount, start, nb_fine, counts + 1, ar.cur(), ar.left(), s);  // counts[1] = coarse rows
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bic_finish, dim3(gw), dim3(256), 0, s, bkey_ord, bits, start, counts, unit_shift, bkeys, bvals, cap,
-                     pre, (int4*)coords);
+  hipLaunchKernelGGL(k_bic_finish, dim3(gw), dim3(256), 0, s, bkey_ord, rec, start, counts, unit_shift, bkeys, bvals, cap,
+                     (int4*)coords);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -329,9 +323,11 @@ extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t
 // previous neighbour is kept in registers (a row's neighbours touch <= 8 blocks, usually 1-3).
 // CUBE (block_bits <= 4: a block is a 16^3 cube of the level's lattice): along one axis the three neighbour positions
 // fall into at most two blocks, so the 27 probes touch at most 2 x 2 x 2 blocks.  Those are looked up first; then the
-// bitmap words and prefixes of ALL 27 probes are loaded unconditionally (index 0 for absent ones) before any of them is
-// used.  By PMC the one-probe-at-a-time form spent 88 % of its wave cycles in s_waitcnt on a chain of 4-5 dependent
-// loads per probe (2.9 us per probe); here a row pays the lookup chain once and one batch of 54 independent loads.
+// 16-byte records of ALL 27 probes are loaded unconditionally (index 0 for absent ones) before any of them is used.
+// By PMC the one-probe-at-a-time form spent 88 % of its wave cycles in s_waitcnt on a chain of 4-5 dependent loads per
+// probe (2.9 us per probe); here a row pays the lookup chain once and one batch of 27 independent loads (54 + 8 block
+// starts while the occupancy words and the prefix counts were separate arrays: the kernel is bound by the number of
+// scattered load instructions, 1.22 -> 0.9 ms for the 10 M rows of the bench scene's finest level).
 template <bool CUBE>
 __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ out_coords, int64_t n_out, BlockIndex I,
                                                        int unit_shift, int block_bits, int dstep,
@@ -382,32 +378,25 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
           }
         }
       }
-      int lb[8], ls[8];
+      int lb[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         lb[t] = -1;
-        ls[t] = 0;
         if (bok && (!(t & 1) || alt[0]) && (!(t & 2) || alt[1]) && (!(t & 4) || alt[2])) {
           const uint64_t blk = (kb >> 12) | ((t & 1) ? pb[0] : pa[0]) | ((t & 2) ? pb[1] : pa[1]) | ((t & 4) ? pb[2] : pa[2]);
           lb[t] = bi_find_block(I, blk);
-          ls[t] = lb[t] >= 0 ? I.start[lb[t]] : 0;
         }
       }
-      uint64_t word[27];
-      uint32_t pre[27], meta[27];  // meta: bit 0..5 = bit index, bit 8 = probe valid; the block start goes to st[]
-      int st[27];
+      ulonglong2 rec[27];  // one 16-byte load per probe: occupancy word + row of its first voxel
+      uint32_t meta[27];   // bit 0..5 = bit index, bit 8 = probe valid
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz) {
-        int zb[4], zs[4];
+        int zb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          zb[t] = sel[2][dz] ? lb[4 + t] : lb[t];
-          zs[t] = sel[2][dz] ? ls[4 + t] : ls[t];
-        }
+        for (int t = 0; t < 4; ++t) zb[t] = sel[2][dz] ? lb[4 + t] : lb[t];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int yb0 = sel[1][dy] ? zb[2] : zb[0], yb1 = sel[1][dy] ? zb[3] : zb[1];
-          const int ys0 = sel[1][dy] ? zs[2] : zs[0], ys1 = sel[1][dy] ? zs[3] : zs[1];
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
             const int k = dx + 3 * dy + 9 * dz;
@@ -415,10 +404,8 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
             const bool valid = blk_i >= 0 && ok[0][dx] && ok[1][dy] && ok[2][dz];
             const uint32_t code = (uint32_t)((ax[0][dx] | ax[1][dy] | ax[2][dz]) & 4095ull);
             const uint32_t w = valid ? (uint32_t)blk_i * BI_WORDS + (code >> 6) : 0u;  // word 0 always exists
-            word[k] = I.bits[w];
-            pre[k] = I.pre[w];
+            rec[k] = I.rec[w];
             meta[k] = (code & 63u) | (valid ? 256u : 0u);
-            st[k] = sel[0][dx] ? ys1 : ys0;
           }
         }
       }
@@ -426,8 +413,8 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
       for (int k = 0; k < 27; ++k) {
         const int bit = (int)(meta[k] & 63u);
         int32_t r = -1;
-        if ((meta[k] & 256u) && ((word[k] >> bit) & 1ull))
-          r = st[k] + (int)pre[k] + __popcll(word[k] & ((1ull << bit) - 1ull));
+        if ((meta[k] & 256u) && ((rec[k].x >> bit) & 1ull))
+          r = (int)(uint32_t)rec[k].y + __popcll(rec[k].x & ((1ull << bit) - 1ull));
         found += r >= 0 ? 1 : 0;
         fmask |= (r >= 0 ? 1u : 0u) << k;
         if (translate && r >= 0) r = translate[r];
@@ -435,7 +422,7 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
       }
     } else {
     uint64_t last_blk = ~0ull;
-    int last_b = -1, last_start = 0;
+    int last_b = -1;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
       const int dx = k % 3, dy = (k / 3) % 3, dz = k / 9;
@@ -446,14 +433,13 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
         if (blk != last_blk) {
           last_blk = blk;
           last_b = bi_find_block(I, blk);
-          last_start = last_b >= 0 ? I.start[last_b] : 0;
         }
         if (last_b >= 0) {
           const int code = (int)(key & 4095ull);
           const size_t w = (size_t)last_b * BI_WORDS + (code >> 6);
-          const uint64_t word = I.bits[w];
+          const ulonglong2 rc = I.rec[w];
           const int bit = code & 63;
-          if ((word >> bit) & 1ull) r = last_start + (int)I.pre[w] + __popcll(word & ((1ull << bit) - 1ull));
+          if ((rc.x >> bit) & 1ull) r = (int)(uint32_t)rc.y + __popcll(rc.x & ((1ull << bit) - 1ull));
         }
       }
       found += r >= 0 ? 1 : 0;
@@ -473,11 +459,11 @@ __global__ __launch_bounds__(256) void k_kernel_map_bi(const int4* __restrict__ 
 static inline unsigned kmb_grid(int64_t n_out) { return (unsigned)std::min<int64_t>(pp_blocks(n_out, 256), 256 * 16); }
 
 extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals,
-                                int64_t cap, const int32_t* start, const uint64_t* bits, const uint16_t* pre,
-                                int32_t unit_src, int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr,
+                                int64_t cap, const uint64_t* rec, int32_t unit_src, int32_t block_bits, int32_t step,
+                                int32_t sign, int32_t* nbr,
                                 int64_t* n_pairs, uint32_t* mask_out, const int32_t* translate, pp_stream_t stream) {
   PP_REQUIRE(out_coords || n_out == 0, "pp_kernel_map_bi: null coordinates");
-  PP_REQUIRE(bkeys && bvals && start && bits && pre && nbr, "pp_kernel_map_bi: null index");
+  PP_REQUIRE(bkeys && bvals && rec && nbr, "pp_kernel_map_bi: null index");
   PP_REQUIRE(sign == 1 || sign == -1, "pp_kernel_map_bi: sign must be +1 or -1");
   PP_REQUIRE(unit_src >= 1 && (unit_src & (unit_src - 1)) == 0, "pp_kernel_map_bi: unit must be a power of two");
   hipStream_t s = pp_s(stream);
@@ -485,7 +471,7 @@ extern "C" int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const 
   if (n_out == 0) return PP_OK;
   int unit_shift = 0;
   while ((1 << unit_shift) < unit_src) ++unit_shift;
-  BlockIndex I{bkeys, bvals, cap, start, bits, pre};
+  BlockIndex I{bkeys, bvals, cap, (const ulonglong2*)rec};
   if (block_bits <= 4)
     hipLaunchKernelGGL(k_kernel_map_bi<true>, dim3(kmb_grid(n_out)), dim3(256), 0, s, (const int4*)out_coords, n_out,
                        I, unit_shift, block_bits, sign * step, nbr, (unsigned long long*)n_pairs, mask_out, translate);

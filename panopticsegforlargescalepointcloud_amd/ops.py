@@ -176,10 +176,10 @@ def kernel_map(out_coords, table, ksize, step, sign):
 
 
 class BlockIndex:
-    """Block index of a coordinate level (csrc/pp_blockindex.hip): per group of <= 4096 voxels the first row, a
-    4096-bit occupancy map and prefix counts, plus a hash block key -> block number."""
+    """Block index of a coordinate level (csrc/pp_blockindex.hip): per group of <= 4096 voxels the first row and 64
+    records (64 bits of the occupancy map, row of the word's first voxel), plus a hash block key -> block number."""
 
-    __slots__ = ("unit", "block_bits", "n_blocks", "cap", "bkeys", "bvals", "start", "bits", "pre", "bkey_ord")
+    __slots__ = ("unit", "block_bits", "n_blocks", "cap", "bkeys", "bvals", "start", "rec", "bkey_ord")
 
 
 def block_index_build(coords_sorted, unit, block_bits):
@@ -205,12 +205,11 @@ def block_index_build(coords_sorted, unit, block_bits):
     bi.bkeys = torch.empty(bi.cap, dtype=torch.int64, device=dev)
     bi.bvals = torch.empty(bi.cap, dtype=torch.int32, device=dev)
     bi.start = torch.empty(max(nb, 1), dtype=torch.int32, device=dev)
-    bi.bits = torch.empty(max(nb, 1) * 64, dtype=torch.int64, device=dev)
-    bi.pre = torch.empty(max(nb, 1) * 64, dtype=torch.int16, device=dev)
+    bi.rec = torch.empty(max(nb, 1) * 128, dtype=torch.int64, device=dev)
     bi.bkey_ord = torch.empty(max(nb, 1), dtype=torch.int64, device=dev)
     if ndup == 0:
         _lib.check(lib.pp_block_index_fill(_ptr(coords), n, int(unit), int(block_bits), _ptr(row_block), nb, _ptr(bi.bkeys),
-                                           _ptr(bi.bvals), bi.cap, _ptr(bi.start), _ptr(bi.bits), _ptr(bi.pre),
+                                           _ptr(bi.bvals), bi.cap, _ptr(bi.start), _ptr(bi.rec),
                                            _ptr(bi.bkey_ord), _stream()), "pp_block_index_fill")
     return bi, ndup
 
@@ -218,7 +217,7 @@ def block_index_build(coords_sorted, unit, block_bits):
 def block_index_coarsen(fine, n_fine_rows):
     """Next coarser level (tensor stride doubled) from a BlockIndex alone: (BlockIndex, coords int32 [n_coarse,4])."""
     lib = _lib.load()
-    dev = fine.bits.device
+    dev = fine.rec.device
     nbf = fine.n_blocks
     bi = BlockIndex()
     bi.unit, bi.block_bits = fine.unit * 2, fine.block_bits
@@ -226,15 +225,14 @@ def block_index_coarsen(fine, n_fine_rows):
     bi.bkeys = torch.empty(bi.cap, dtype=torch.int64, device=dev)
     bi.bvals = torch.empty(bi.cap, dtype=torch.int32, device=dev)
     bi.start = torch.empty(max(nbf, 1), dtype=torch.int32, device=dev)
-    bi.bits = torch.empty(max(nbf, 1) * 64, dtype=torch.int64, device=dev)
-    bi.pre = torch.empty(max(nbf, 1) * 64, dtype=torch.int16, device=dev)
+    bi.rec = torch.empty(max(nbf, 1) * 128, dtype=torch.int64, device=dev)
     bi.bkey_ord = torch.empty(max(nbf, 1), dtype=torch.int64, device=dev)
     coords = torch.empty((max(int(n_fine_rows), 1), 4), dtype=torch.int32, device=dev)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     wsb = lib.pp_block_index_coarsen_workspace(nbf)
     ws = _ws(wsb, dev)
-    _lib.check(lib.pp_block_index_coarsen(_ptr(fine.bkey_ord), _ptr(fine.bits), nbf, bi.unit, bi.block_bits, _ptr(bi.bkeys),
-                                          _ptr(bi.bvals), bi.cap, _ptr(bi.start), _ptr(bi.bits), _ptr(bi.pre), _ptr(bi.bkey_ord),
+    _lib.check(lib.pp_block_index_coarsen(_ptr(fine.bkey_ord), _ptr(fine.rec), nbf, bi.unit, bi.block_bits, _ptr(bi.bkeys),
+                                          _ptr(bi.bvals), bi.cap, _ptr(bi.start), _ptr(bi.rec), _ptr(bi.bkey_ord),
                                           _ptr(coords), _ptr(counts), _ptr(ws), wsb, _stream()), "pp_block_index_coarsen")
     nbc, nc = [int(v) for v in counts.tolist()]
     bi.n_blocks = nbc
@@ -252,8 +250,8 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, transla
     nbr = torch.empty((27, n_out), dtype=torch.int32, device=out_coords.device)
     pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
     mask = torch.empty(max(n_out, 1), dtype=torch.int32, device=out_coords.device) if want_mask else None
-    _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap, _ptr(index.start),
-                                    _ptr(index.bits), _ptr(index.pre), index.unit, index.block_bits, int(step), int(sign),
+    _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap,
+                                    _ptr(index.rec), index.unit, index.block_bits, int(step), int(sign),
                                     _ptr(nbr), _ptr(pairs), _ptr(mask), _ptr(_need(translate, torch.int32, "translate")),
                                     _stream()), "pp_kernel_map_bi")
     nbr.pp_pairs = pairs

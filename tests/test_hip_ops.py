@@ -832,8 +832,7 @@ def test_coarser_levels_from_the_block_index(ops, oracle):
         ref_idx, _ = ops.block_index_build(dev(want), ts, 4)
         assert got_idx.n_blocks == ref_idx.n_blocks and got_idx.unit == ts
         nb = ref_idx.n_blocks
-        assert torch.equal(got_idx.bits[: nb * 64], ref_idx.bits[: nb * 64])
-        assert torch.equal(got_idx.pre[: nb * 64], ref_idx.pre[: nb * 64])
+        assert torch.equal(got_idx.rec[: nb * 128], ref_idx.rec[: nb * 128])
         assert torch.equal(got_idx.start[:nb], ref_idx.start[:nb]) and torch.equal(got_idx.bkey_ord[:nb], ref_idx.bkey_ord[:nb])
         # maps through the derived index == oracle
         same = ops.kernel_map_bi(got, got_idx, 3, ts, 1)
