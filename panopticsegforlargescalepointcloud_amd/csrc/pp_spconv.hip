@@ -266,11 +266,12 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
   a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
-  const int max_ntw = mode16 ? 4 : 7;
+  const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
+  const int max_ntw = (mode16 || c4) ? 4 : 7;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
   groups = (a.NT + ntw - 1) / ntw;
-  const bool v3_ok = mode16 && K <= 28 && pp_spconv_fwd3_ok(a, n_in);
+  const bool v3_ok = (mode16 || c4) && K <= 28 && pp_spconv_fwd3_ok(a, n_in);
   if (v3_ok) {
     // rows per wave: 64 on launches with <= 2 column tiles per wave and >= 2 M rows -- narrow layers are bound by per-step
     // work, which 64 rows halve per row -- 32 on wider ones (the extra accumulators cost occupancy: 48->48 660 vs 690 us)
@@ -301,7 +302,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     if (rc != PP_OK) return rc;
     if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
   } else {
-    // first-version kernel: Cin % 16 != 0 (the 4 -> 16 input layer) and inputs of 4 GiB or more per source
+    // first-version kernel: Cin % 16 != 0 other than the 4-channel input layer, and inputs of 4 GiB or more per source
     if (bf16) {
       pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
       return PP_ERR_INVALID;

@@ -43,7 +43,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F3_WPB 4
 #endif
 
-template <int NTW, int T, bool BF16, int D>
+// C4: the 4-channel input layer (rows of 16 bytes).  A step is one kernel offset with ONE fp32 MFMA per tile (k = the four
+// channels): lane (i, q) loads channel q of its row and weight [q][column i] as single dwords.
+template <int NTW, int T, bool BF16, int D, bool C4 = false>
 __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
@@ -124,12 +126,13 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     for (int jt = 0; jt < NTW; ++jt) acc[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (rem && F3_ABLATE != 1) {
-    const int S0 = a.c0 >> 4, S = (a.c0 + a.c1) >> 4;
-    const unsigned q16 = (unsigned)q * 16u;
-    const unsigned lane16 = (unsigned)lane * 16u;
+    const int S0 = C4 ? 1 : a.c0 >> 4, S = C4 ? 1 : (a.c0 + a.c1) >> 4;
+    constexpr unsigned WT = C4 ? 256u : 1024u;  // bytes of packed weights per (k, s, column tile)
+    const unsigned q16 = (unsigned)q * (C4 ? 4u : 16u);
+    const unsigned lane16 = (unsigned)lane * (C4 ? 4u : 16u);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)w_bytes, 0x00020000);
-    const unsigned w_step = (unsigned)a.NT * 1024u;  // bytes of packed weights per (k, s)
-    const unsigned w_jt0 = (unsigned)jt0 * 1024u;
+    const unsigned w_step = (unsigned)a.NT * WT;  // bytes of packed weights per (k, s)
+    const unsigned w_jt0 = (unsigned)jt0 * WT;
 
     // load side runs one step ahead of the compute side.  Its state (rem, kl, sl) is scalar; descriptor base and weight
     // offset are recomputed from it every step (carrying them across iterations makes hipcc treat them as divergent and
@@ -145,13 +148,21 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
   {                                                                                                            \
     const float* src_ = sl < S0 ? a.in0 + sl * 16 : a.in1 + (sl - S0) * 16;                                    \
     const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)a_bytes, 0x00020000); \
-    _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                           \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                         \
+      if constexpr (C4)                                                                                        \
+        AX[tt][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, (int)vo[tt], 0, 0));   \
+      else                                                                                                     \
         AX[tt] = F3_ABLATE == 3 ? (f32x4){1.f, 2.f, 3.f, (float)vo[tt]}                                         \
                                 : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)vo[tt], 0, 0)); \
+    }                                                                                                          \
     const unsigned wso_ = (unsigned)(kl * S + sl) * w_step + w_jt0;                                            \
-    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                         \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) {                                                       \
+      if constexpr (C4)                                                                                        \
+        BX[jt][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, (int)(lane16 + jt * WT), (int)wso_, 0)); \
+      else                                                                                                     \
         BX[jt] = F3_ABLATE == 4 ? (f32x4){1.f, 2.f, 3.f, (float)wso_}                                           \
-                                : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * 1024u), (int)wso_, 0)); \
+                                : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * WT), (int)wso_, 0)); \
+    }                                                                                                          \
   }
     // advance the load side; VALID = false when no step is left (the state then still names a valid step)
 #define F3_ADVANCE(VALID)                                             \
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                    \
       if ((m[tt] >> (KC)) & 1u) {                                                                         \
         _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                 \
+            _Pragma("unroll") for (int t = 0; t < (C4 ? 1 : 4); ++t)                                      \
                 acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
       }                                                                                                   \
     }                                                                                                     \
@@ -289,6 +300,18 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+  if constexpr (!BF16) {
+    if (a.c0 == 4) {  // the input layer: one column-tile count per launch is enough (cout = 16 in every published model)
+      switch (ntw) {
+        case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+        case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+        case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+        case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+        default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
+      }
+      return PP_OK;
+    }
+  }
   // depth: 1 = one step in flight; 3 = one step in flight with the load side advanced (LDS read of the next offsets)
   // before the MFMAs of the current step -- pays on launches with <= 2 column tiles per wave (16->16 at 2.5 M rows:
   // 374 -> 343 us), nothing on wider ones
@@ -326,13 +349,15 @@ int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s) {
 bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in) {
   if (a.c1 != 0 && a.c1 != a.c0) return false;
   if (n_in <= 0) return false;
+  if (a.c0 % 16 != 0 && !(a.c0 == 4 && a.c1 == 0 && !a.bf16)) return false;
   return (double)n_in * a.c0 * 4.0 < 4294967000.0 && (double)a.K * (a.c0 + a.c1) * a.NT * 64.0 < 4294967000.0;
 }
 
 // T = 16-row tiles per wave (2 or 4), depth = loop variant (1 or 3); the caller picks them (spconv_fwd_impl)
 int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, int T, int depth, hipStream_t s) {
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
-  const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
+  const unsigned w_bytes = a.c0 == 4 ? (unsigned)((uint64_t)a.K * a.NT * 256u)
+                                     : (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   if (T != 2 && T != 4) {
     pp_set_error("pp_spconv_fwd3: rows per wave must be 32 or 64");
     return PP_ERR_INVALID;
