@@ -82,6 +82,18 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
                   int64_t cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, int64_t* n_pairs,
                   pp_stream_t stream);
 
+/* The two device-wide primitives every compaction / ordering of the library goes through (csrc/pp_scan.hip; hand-written:
+ * reduce-then-scan over 4096-element tiles; stable LSD radix sort, 8 bits per pass, tiles sorted in registers by 2-bit
+ * splits).  pp_exclusive_scan: out[i] = in[0] + ... + in[i-1] (int32, in place allowed), total (device, may be NULL) = sum.
+ * pp_sort_pairs: stable sort of (key, int32 value) pairs by the key bits [0, end_bit); keys uint32 / uint64 (key_bytes);
+ * not in place. */
+size_t pp_exclusive_scan_workspace(int64_t n);
+int pp_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* workspace, size_t workspace_bytes,
+                      pp_stream_t stream);
+size_t pp_sort_pairs_workspace_bytes(int64_t n);
+int pp_sort_pairs(const void* keys_in, void* keys_out, int32_t key_bytes, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                  int32_t end_bit, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+
 /* Derived maps (no hash probes).  pp_kernel_map_transpose: out_map[k][in_map[k][o]] = o, i.e. the map of the
  * transposed strided convolution (coarse -> fine, ME's "swapped" kernel map, api_modules.py:288-311) from the
  * strided convolution's map; out_map is int32 [K][n_in], filled with -1 first.  in_order (nullable): in_map is

@@ -15,7 +15,6 @@
 //      nature; samples run concurrently).
 // Distances are accumulated in dimension order without FMA contraction so that results are bit-identical to the CPU
 // oracle (oracle/panoptic_oracle.c: hdbscan_one), which fixes the same conventions.
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <vector>

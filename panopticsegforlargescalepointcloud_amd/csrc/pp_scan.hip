@@ -1,6 +1,5 @@
-// Library plumbing: error reporting, version, device scan / radix-sort wrappers (rocPRIM via hipCUB headers),
-// and the HBM triad used by bench.py to confirm the roofline denominator.
-#include <hipcub/hipcub.hpp>
+// Library plumbing: error reporting, version, the device-wide exclusive scan and radix sort every compaction / ordering of
+// the library goes through, and the HBM triad used by bench.py to confirm the roofline denominator.
 #include <stdarg.h>
 
 #include "pp_common.h"
@@ -38,50 +37,290 @@ extern "C" int pp_triad(float* a, const float* b, const float* c, float s, int64
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t pp_scan_workspace(int64_t n) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)std::max<int64_t>(n, 1));
-  return pp_align(bytes) + 256;
+// Device-wide exclusive prefix sum (int32): reduce-then-scan over tiles of 4096 elements.
+//   k_scan_sums   one workgroup per tile: the tile's sum
+//   (the tile sums are scanned by the same three steps, recursively: one level reaches 16 M elements, two 2^31)
+//   k_scan_tiles  one workgroup per tile: 16 elements per thread in registers, serial prefix in the thread, shuffle scan of
+//                 the thread totals in the wave, the 4 wave totals through LDS, plus the tile's offset
+// In place (in == out) is fine: a tile is read completely before it is written and the sums are taken first.
+// ---------------------------------------------------------------------------------------------
+#define SC_NT 256
+#define SC_IPT 16
+#define SC_TILE (SC_NT * SC_IPT)
+
+__device__ __forceinline__ int sc_block_exclusive(int v, int* total) {  // exclusive scan of one value per thread over the workgroup
+  __shared__ int wsum[SC_NT / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SC_NT / 64; ++w) {
+    const int u = wsum[w];
+    if (w < wave) woff += u;
+    tot += u;
+  }
+  *total = tot;
+  return incl - v + woff;
+}
+__global__ __launch_bounds__(SC_NT) void k_scan_sums(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE;
+  int v = 0;
+#pragma unroll
+  for (int r = 0; r < SC_IPT; ++r) {
+    const int64_t e = base + (int64_t)r * SC_NT + threadIdx.x;  // strided: coalesced, the order inside the sum is irrelevant
+    v += e < n ? in[e] : 0;
+  }
+  int tot;
+  sc_block_exclusive(v, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SC_NT) void k_scan_tiles(const int32_t* in, int32_t* out, int64_t n,
+                                                      const int32_t* __restrict__ offs, int32_t* __restrict__ total) {
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
+  int v[SC_IPT];
+  int sum = 0;
+#pragma unroll
+  for (int r = 0; r < SC_IPT; ++r) {
+    v[r] = base + r < n ? in[base + r] : 0;
+    sum += v[r];
+  }
+  int tot;
+  int run = sc_block_exclusive(sum, &tot) + (offs ? offs[blockIdx.x] : 0);
+#pragma unroll
+  for (int r = 0; r < SC_IPT; ++r) {
+    if (base + r < n) {
+      out[base + r] = run;
+      if (total && base + r == n - 1) total[0] = run + v[r];
+    }
+    run += v[r];
+  }
 }
 
-__global__ void k_scan_total(const int32_t* in, const int32_t* out, int64_t n, int32_t* total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = n > 0 ? out[n - 1] + in[n - 1] : 0;
+size_t pp_scan_workspace(int64_t n) {
+  size_t bytes = 256;
+  for (int64_t m = std::max<int64_t>(n, 1); m > SC_TILE;) {
+    m = (m + SC_TILE - 1) / SC_TILE;
+    bytes += pp_align(2 * (size_t)m * 4);  // tile sums + their scan
+  }
+  return bytes;
 }
 
 int pp_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* ws, size_t ws_bytes,
                           hipStream_t stream) {
-  if (n > 0) {
-    size_t bytes = ws_bytes;
-    PP_HIP(hipcub::DeviceScan::ExclusiveSum(ws, bytes, in, out, (int)n, stream));
+  if (n <= 0) {
+    if (total) PP_HIP(hipMemsetAsync(total, 0, sizeof(int32_t), stream));
+    return PP_OK;
   }
-  if (total) {
-    hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(64), 0, stream, in, out, n, total);
+  if (ws_bytes < pp_scan_workspace(n)) return PP_ERR_WORKSPACE;
+  const int64_t nb = (n + SC_TILE - 1) / SC_TILE;
+  const int32_t* offs = nullptr;
+  if (nb > 1) {
+    int32_t* sums = (int32_t*)ws;
+    int32_t* scanned = sums + nb;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SC_NT), 0, stream, in, n, sums);
     PP_LAUNCH_CHECK();
+    const size_t used = pp_align((size_t)2 * nb * 4);
+    int rc = pp_exclusive_scan_i32(sums, scanned, nb, nullptr, (char*)ws + used, ws_bytes - used, stream);
+    if (rc) return rc;
+    offs = scanned;
   }
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)nb), dim3(SC_NT), 0, stream, in, out, n, offs, total);
+  PP_LAUNCH_CHECK();
   return PP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-wide stable LSD radix sort of (key, int32 value) pairs on the key bits [0, end_bit), 8 bits per pass.  A pass:
+//   k_rs_hist     one workgroup per tile of 2048 pairs: digit counts (LDS atomics) -> hist[digit][tile]
+//   exclusive scan of hist (digit-major), i.e. the first output position of every (digit, tile)
+//   k_rs_scatter  one workgroup per tile, 8 pairs per thread: the tile is sorted by the digit with four stable 2-bit
+//                 splits (packed 16-bit counters in one 64-bit word, scanned by shuffles + LDS -- the scheme of the map
+//                 window sort, pp_maporder.hip), on 32-bit words (digit | position in the tile); keys and values wait in
+//                 LDS and are written out in sorted order, so every run of equal digits is one contiguous store
+// Passes alternate between the output and a temporary pair of arrays so that the last one writes keys_out / vals_out.
+// ---------------------------------------------------------------------------------------------
+#define RS_NT 256
+#define RS_IPT 8
+#define RS_TILE (RS_NT * RS_IPT)
+
+template <typename K>
+__global__ __launch_bounds__(RS_NT) void k_rs_hist(const K* __restrict__ keys, int64_t n, int shift, uint32_t dmask, int64_t nb,
+                                                   int32_t* __restrict__ hist) {
+  __shared__ int h[256];
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int64_t e = base + (int64_t)r * RS_NT + threadIdx.x;
+    if (e < n) atomicAdd(&h[(int)((uint32_t)(keys[e] >> shift) & dmask)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename K>
+__global__ __launch_bounds__(RS_NT) void k_rs_scatter(const K* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                                                      K* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+                                                      int shift, uint32_t dmask, int64_t nb,
+                                                      const int32_t* __restrict__ goff) {
+  __shared__ K ks[RS_TILE];
+  __shared__ int32_t vs[RS_TILE];
+  __shared__ uint32_t ex[RS_TILE];
+  __shared__ unsigned long long wtot[RS_NT / 64];
+  __shared__ int first[256], gbase[256];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  const int cnt = (int)((n - base) < RS_TILE ? (n - base) : RS_TILE);
+  if (t < 256) gbase[t] = goff[(int64_t)t * nb + blockIdx.x];
+  uint32_t pk[RS_IPT];  // digit << 12 | position in the tile
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int e = t * RS_IPT + r;
+    K key = 0;
+    int32_t val = 0;
+    if (e < cnt) {
+      key = keys_in[base + e];
+      val = vals_in[base + e];
+    }
+    ks[e] = key;
+    vs[e] = val;
+    // rows past the end carry the largest digit: the sort is stable, so they end up behind every real row
+    pk[r] = ((e < cnt ? (uint32_t)(key >> shift) & dmask : 255u) << 12) | (uint32_t)e;
+  }
+#pragma unroll 1
+  for (int bit = 12; bit < 20; bit += 2) {
+    unsigned long long c = 0;
+    int lr[RS_IPT];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+      const int sh = (int)((pk[r] >> bit) & 3u) * 16;
+      lr[r] = (int)((c >> sh) & 0xFFFFull);
+      c += 1ull << sh;
+    }
+    unsigned long long incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long u = (unsigned long long)__shfl_up((long long)incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < RS_NT / 64; ++w) {
+      const unsigned long long u = wtot[w];
+      if (w < wave) woff += u;
+      total += u;
+    }
+    const unsigned long long t0 = total & 0xFFFFull, t1 = (total >> 16) & 0xFFFFull, t2 = (total >> 32) & 0xFFFFull;
+    const unsigned long long pb = incl - c + woff + ((t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48));
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+      const int sh = (int)((pk[r] >> bit) & 3u) * 16;
+      ex[(int)((pb >> sh) & 0xFFFFull) + lr[r]] = pk[r];
+    }
+    __syncthreads();
+    const uint4 a = *(const uint4*)&ex[t * RS_IPT], b = *(const uint4*)&ex[t * RS_IPT + 4];
+    pk[0] = a.x; pk[1] = a.y; pk[2] = a.z; pk[3] = a.w;
+    pk[4] = b.x; pk[5] = b.y; pk[6] = b.z; pk[7] = b.w;
+    if (bit + 2 < 20) __syncthreads();  // (after the last split ex[] keeps the sorted tile for the run starts below)
+  }
+  // first position of every digit's run in the sorted tile
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int p = t * RS_IPT + r;
+    const uint32_t d = pk[r] >> 12;
+    if (p == 0 || (ex[p - 1] >> 12) != d) first[d] = p;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int p = r * RS_NT + t;  // sorted position, strided over the threads: a run of equal digits is a contiguous store
+    if (p < cnt) {
+      const uint32_t w = ex[p];
+      const int d = (int)(w >> 12), src = (int)(w & 4095u);
+      const int64_t pos = (int64_t)gbase[d] + (p - first[d]);
+      keys_out[pos] = ks[src];
+      vals_out[pos] = vs[src];
+    }
+  }
+}
+
+static size_t rs_hist_ints(int64_t n) { return (size_t)256 * (size_t)((std::max<int64_t>(n, 1) + RS_TILE - 1) / RS_TILE); }
+
 size_t pp_sort_pairs_workspace(int64_t n) {
-  size_t b64 = 0, b32 = 0;
-  int nn = (int)std::max<int64_t>(n, 1);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b64, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr,
-                                     (int32_t*)nullptr, nn, 0, 64);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
-                                     (int32_t*)nullptr, nn, 0, 32);
-  return pp_align(std::max(b64, b32)) + 256;
+  const size_t m = (size_t)std::max<int64_t>(n, 1);
+  return pp_align(m * 8) + pp_align(m * 4) + 2 * pp_align(rs_hist_ints(n) * 4) + pp_scan_workspace((int64_t)rs_hist_ints(n)) + 256;
+}
+
+template <typename K>
+static int rs_sort(const K* keys_in, K* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n, int end_bit, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  if (n <= 0) return PP_OK;
+  PP_REQUIRE(keys_in && keys_out && vals_in && vals_out, "pp_sort_pairs: null pointer");
+  PP_REQUIRE((const void*)keys_in != (const void*)keys_out && vals_in != vals_out, "pp_sort_pairs: in-place sorting is not supported");
+  PP_REQUIRE(n < (1ll << 31) && end_bit >= 0 && end_bit <= (int)(8 * sizeof(K)), "pp_sort_pairs: bad size / bit range");
+  if (ws_bytes < pp_sort_pairs_workspace(n)) return PP_ERR_WORKSPACE;
+  PPArena ar(ws, ws_bytes);
+  K* tk = (K*)ar.take<uint64_t>((size_t)n);
+  int32_t* tv = ar.take<int32_t>((size_t)n);
+  const size_t hi = rs_hist_ints(n);
+  int32_t* hist = ar.take<int32_t>(hi);
+  int32_t* goff = ar.take<int32_t>(hi);
+  if (!tk || !tv || !hist || !goff) return PP_ERR_WORKSPACE;
+  const int64_t nb = (n + RS_TILE - 1) / RS_TILE;
+  int passes = (std::max(end_bit, 1) + 7) / 8;
+  const K* src_k = keys_in;
+  const int32_t* src_v = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) & 1) == 0;  // the last pass writes the caller's arrays
+    K* dst_k = to_out ? keys_out : tk;
+    int32_t* dst_v = to_out ? vals_out : tv;
+    const uint32_t dmask = end_bit - 8 * p >= 8 ? 255u : (1u << (end_bit - 8 * p)) - 1u;  // bits at or above end_bit do not count
+    hipLaunchKernelGGL((k_rs_hist<K>), dim3((unsigned)nb), dim3(RS_NT), 0, stream, src_k, n, 8 * p, dmask, nb, hist);
+    PP_LAUNCH_CHECK();
+    int rc = pp_exclusive_scan_i32(hist, goff, (int64_t)hi, nullptr, ar.cur(), ar.left(), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_rs_scatter<K>), dim3((unsigned)nb), dim3(RS_NT), 0, stream, src_k, src_v, dst_k, dst_v, n, 8 * p, dmask,
+                       nb, goff);
+    PP_LAUNCH_CHECK();
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  return PP_OK;
 }
 
 int pp_sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
                       int64_t n, int end_bit, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (n <= 0) return PP_OK;
-  size_t bytes = ws_bytes;
-  PP_HIP(hipcub::DeviceRadixSort::SortPairs(ws, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream));
-  return PP_OK;
+  return rs_sort<uint32_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, ws, ws_bytes, stream);
 }
 int pp_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
                       int64_t n, int end_bit, void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (n <= 0) return PP_OK;
-  size_t bytes = ws_bytes;
-  PP_HIP(hipcub::DeviceRadixSort::SortPairs(ws, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, stream));
-  return PP_OK;
+  return rs_sort<uint64_t>(keys_in, keys_out, vals_in, vals_out, n, end_bit, ws, ws_bytes, stream);
+}
+
+// the two primitives through the C ABI (tests, callers outside the library)
+extern "C" size_t pp_exclusive_scan_workspace(int64_t n) { return pp_scan_workspace(n); }
+extern "C" int pp_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* workspace,
+                                 size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE((in && out) || n <= 0, "pp_exclusive_scan: null pointer");
+  return pp_exclusive_scan_i32(in, out, n, total, workspace, workspace_bytes, pp_s(stream));
+}
+extern "C" size_t pp_sort_pairs_workspace_bytes(int64_t n) { return pp_sort_pairs_workspace(n); }
+extern "C" int pp_sort_pairs(const void* keys_in, void* keys_out, int32_t key_bytes, const int32_t* vals_in, int32_t* vals_out,
+                             int64_t n, int32_t end_bit, void* workspace, size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(key_bytes == 4 || key_bytes == 8, "pp_sort_pairs: keys are uint32 or uint64");
+  if (key_bytes == 4)
+    return pp_sort_pairs_u32((const uint32_t*)keys_in, (uint32_t*)keys_out, vals_in, vals_out, n, end_bit, workspace,
+                             workspace_bytes, pp_s(stream));
+  return pp_sort_pairs_u64((const uint64_t*)keys_in, (uint64_t*)keys_out, vals_in, vals_out, n, end_bit, workspace,
+                           workspace_bytes, pp_s(stream));
 }

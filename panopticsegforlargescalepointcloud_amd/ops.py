@@ -260,6 +260,37 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, transla
     return nbr
 
 
+def exclusive_scan(x, want_total=False):
+    """exclusive prefix sum of an int32 vector (csrc/pp_scan.hip); want_total: (scan, total int32 [1])"""
+    lib = _lib.load()
+    x = _need(x, torch.int32, "x")
+    n = x.shape[0]
+    out = torch.empty_like(x)
+    total = torch.zeros(1, dtype=torch.int32, device=x.device) if want_total else None
+    wsb = lib.pp_exclusive_scan_workspace(n)
+    ws = _ws(wsb, x.device, tag="scan")
+    _lib.check(lib.pp_exclusive_scan(_ptr(x), _ptr(out), n, _ptr(total), _ptr(ws), wsb, _stream()), "pp_exclusive_scan")
+    return (out, total) if want_total else out
+
+
+def sort_pairs(keys, vals, end_bit=None):
+    """stable sort of (key, value) pairs by the low end_bit bits of the keys (int32 / int64 tensors read as unsigned; values
+    int32): (sorted keys, sorted values)"""
+    lib = _lib.load()
+    if keys.dtype not in (torch.int32, torch.int64):
+        raise TypeError("sort_pairs: keys must be int32 or int64")
+    keys = _need(keys, keys.dtype, "keys")
+    vals = _need(vals, torch.int32, "vals")
+    n = keys.shape[0]
+    kb = keys.element_size()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    wsb = lib.pp_sort_pairs_workspace_bytes(n)
+    ws = _ws(wsb, keys.device, tag="sort")
+    _lib.check(lib.pp_sort_pairs(_ptr(keys), _ptr(ko), kb, _ptr(vals), _ptr(vo), n, 8 * kb if end_bit is None else int(end_bit),
+                                 _ptr(ws), wsb, _stream()), "pp_sort_pairs")
+    return ko, vo
+
+
 def map_mask(nbr):
     """uint32-as-int32 [n_out]: bit k set <=> nbr[k][o] >= 0"""
     lib = _lib.load()

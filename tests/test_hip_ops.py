@@ -636,6 +636,40 @@ def test_morton_order_and_derived_maps(ops, oracle):
     assert torch.equal(torch.flip(same, [0]), ops.kernel_map(d, table, 3, 1, -1))
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 2047, 2048, 2049, 4096, 4097, 100_003, 5_000_000, 17_000_001])
+def test_exclusive_scan(ops, n):
+    """the library's own device scan (reduce-then-scan over 4096-element tiles; 17 M elements take two levels)"""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randint(0, 100, (n,), dtype=torch.int32, device="cuda", generator=g)
+    out, total = ops.exclusive_scan(x, want_total=True)
+    want = torch.cumsum(x.long(), 0) - x.long()
+    assert torch.equal(out.long(), want) and int(total) == int(x.long().sum())
+    if n:  # in place
+        y = x.clone()
+        lib = ops._lib.load()
+        wsb = lib.pp_exclusive_scan_workspace(n)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        ops._lib.check(lib.pp_exclusive_scan(y.data_ptr(), y.data_ptr(), n, None, ws.data_ptr(), wsb, None), "scan")
+        assert torch.equal(y.long(), want)
+
+
+@pytest.mark.parametrize("n,dtype,end_bit", [(0, torch.int32, 32), (1, torch.int64, 64), (2047, torch.int32, 32), (2049, torch.int64, 64),
+                                              (100_003, torch.int32, 9), (100_003, torch.int64, 40), (3_000_000, torch.int64, 64),
+                                              (3_000_000, torch.int32, 20), (70_001, torch.int32, 0)])
+def test_sort_pairs(ops, n, dtype, end_bit):
+    """the library's own stable LSD radix sort: sorted by the low end_bit bits only, ties keep their input order"""
+    g = torch.Generator(device="cuda").manual_seed(n + end_bit)
+    hi = 2 ** 31 - 1 if dtype == torch.int32 else 2 ** 62
+    keys = torch.randint(0, hi, (n,), dtype=dtype, device="cuda", generator=g)
+    if n > 10:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]  # plenty of ties
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    ko, vo = ops.sort_pairs(keys, vals, end_bit)
+    masked = keys.long() & ((1 << end_bit) - 1) if end_bit < 63 else keys.long()
+    order = torch.sort(masked, stable=True)[1]
+    assert torch.equal(vo.long(), order) and torch.equal(ko, keys[order])
+
+
 def _mask_sort_rank(mask):
     """numpy restatement of mo_remap (csrc/pp_maporder.hip): centre lowest, then faces, edges, corners (most significant)"""
     cls = np.array([(k % 3 != 1) + ((k // 3) % 3 != 1) + (k // 9 != 1) for k in range(27)])
