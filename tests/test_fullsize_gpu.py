@@ -1,0 +1,193 @@
+"""GPU, BASELINE.json sizes (several million rows per level, the sizes the benchmark's launches have): the oracle cannot follow
+there in test time, so the hot path is checked through size-independent properties it must satisfy EXACTLY --
+  * kernel maps: the centre offset is the identity, offset k and its mirror 26 - k are inverse relations, the pair count equals
+    the number of entries, the transposed map holds the same pairs with the roles swapped, slot order / row translation are
+    pure renumberings;
+  * convolution: with a one-hot kernel (W[k] = I for one offset, 0 elsewhere) it is the row gather the map names -- bit-exact,
+    for every offset, through the 64-rows-per-wave / unsplit variants only launches of this size take; it is linear in the
+    features (1e-4); the slot-ordered and the plain map give bit-identical results;
+  * coarsening: every fine voxel's parent exists once, rows stay in block order;
+  * region growing on a full tile batch (2 M points): clusters are disjoint, uniform in (batch, class), at least
+    min_cluster_size large, ascending inside, and identical from run to run (the fixpoint does not depend on the order the
+    atomics land in); device sort: sorted, stable, a permutation (30 M pairs).
+All through the C ABI (ops -> libpanoptic_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N_ROWS = 6_000_000
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from panopticsegforlargescalepointcloud_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def level(ops):
+    """~6 M unique voxels on noisy surfaces in 24 batch elements, in block order, with index, same-level map and slot order"""
+    g = torch.Generator(device="cuda").manual_seed(2022)
+    n_raw = int(N_ROWS * 1.25)
+    b = torch.randint(0, 24, (n_raw,), device="cuda", generator=g, dtype=torch.int32)
+    u = torch.rand((n_raw, 2), device="cuda", generator=g) * 380 - 190
+    kind = torch.randint(0, 3, (n_raw,), device="cuda", generator=g)
+    h = torch.randn(n_raw, device="cuda", generator=g) * 0.7
+    x = torch.where(kind == 1, 40 + h, u[:, 0])                       # ground (z ~ 0), two kinds of walls
+    y = torch.where(kind == 2, -25 + h, u[:, 1])
+    z = torch.where(kind == 0, h + 0.02 * u[:, 0], (u[:, 0] + u[:, 1]).abs() * 0.2)
+    c = torch.stack([b, x.round().int(), y.round().int(), z.round().int()], 1)
+    c = torch.unique(c, dim=0)[:N_ROWS].contiguous()
+    perm, cs = ops.morton_order(c, 1, 4, want_sorted=True, raw=True)
+    index, ndup = ops.block_index_build(cs, 1, 4)
+    assert ndup == 0 and cs.shape[0] > 3_000_000
+    nbr = ops.kernel_map_bi(cs, index, 3, 1, 1, want_mask=True)
+    return {"coords": cs, "index": index, "nbr": nbr, "n": cs.shape[0]}
+
+
+def test_same_level_map_is_a_symmetric_relation(ops, level):
+    nbr, n = level["nbr"], level["n"]
+    rows = torch.arange(n, device="cuda", dtype=torch.int32)
+    assert torch.equal(nbr[13], rows)                                   # centre offset: every voxel is its own neighbour
+    assert int(nbr.pp_pairs) == int((nbr >= 0).sum())
+    assert torch.equal(nbr.pp_mask, ops.map_mask(nbr))
+    for k in range(13):                                                 # offset k and its mirror are inverse relations
+        i = nbr[k]
+        has = i >= 0
+        back = nbr[26 - k][i[has].long()]
+        assert torch.equal(back, rows[has])
+        assert int(has.sum()) == int((nbr[26 - k] >= 0).sum())
+    assert torch.equal(ops.kernel_map_bi(level["coords"], level["index"], 3, 1, -1), torch.flip(nbr, [0]))
+
+
+def test_slot_order_is_a_renumbering_and_conv_does_not_see_it(ops, level):
+    nbr, n, coords = level["nbr"], level["n"], level["coords"]
+    order = ops.map_order(nbr.pp_mask)
+    w = order.pp_window
+    o = order.long()
+    assert torch.equal(torch.sort(o)[0], torch.arange(n, device="cuda"))
+    assert torch.equal(o // w, torch.arange(n, device="cuda") // w)       # rows never leave their window
+    coords_p, phys_of = ops.level_permute(coords, order)
+    assert torch.equal(coords_p, coords[o]) and torch.equal(phys_of[o].long(), torch.arange(n, device="cuda"))
+    same = ops.map_permute(nbr, order, translate=phys_of)
+    # same relation, renumbered: same[k][s] = phys_of[nbr[k][order[s]]]
+    for k in (0, 4, 13, 22, 26):
+        want = nbr[k][o]
+        want = torch.where(want >= 0, phys_of[want.clamp(min=0).long()], want)
+        assert torch.equal(same[k], want)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((n, 16), device="cuda", generator=g)
+    wgt = torch.randn((27, 16, 16), device="cuda", generator=g) * 0.1
+    pk = ops.pack_weight(wgt)
+    plain = ops.spconv_fwd(x, pk, nbr, n, 16, 27)
+    slot = ops.spconv_fwd(x[o], pk, same, n, 16, 27)
+    assert torch.equal(slot, plain[o])                                   # bit-identical: per-row summation order is the same
+    level["order"], level["same"], level["phys_of"] = order, same, phys_of
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (4, 16), (32, 32), (64, 48)])
+def test_one_hot_kernel_is_the_gather_the_map_names(ops, level, cin, cout):
+    """exact at any size: with W[k] = [I | 0] the convolution must return the input row nbr[k][o] (zeros where there is none)"""
+    nbr, n = level["nbr"], level["n"]
+    g = torch.Generator(device="cuda").manual_seed(cin)
+    x = torch.randn((n, cin), device="cuda", generator=g)
+    c = min(cin, cout)
+    for k in (0, 13, 17, 26):
+        wgt = torch.zeros((27, cin, cout), device="cuda")
+        wgt[k, :c, :c] = torch.eye(c, device="cuda")
+        out = ops.spconv_fwd(x, ops.pack_weight(wgt), nbr, n, cout, 27)
+        i = nbr[k]
+        want = torch.zeros((n, cout), device="cuda")
+        want[:, :c] = torch.where((i >= 0)[:, None], x[i.clamp(min=0).long()][:, :c], torch.zeros((), device="cuda"))
+        assert torch.equal(out, want), (cin, cout, k)
+
+
+def test_convolution_is_linear_at_full_size(ops, level):
+    nbr, n = level["nbr"], level["n"]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x, y = torch.randn((n, 32), device="cuda", generator=g), torch.randn((n, 32), device="cuda", generator=g)
+    pk = ops.pack_weight(torch.randn((27, 32, 32), device="cuda", generator=g) * 0.05)
+    fx, fy = ops.spconv_fwd(x, pk, nbr, n, 32, 27), ops.spconv_fwd(y, pk, nbr, n, 32, 27)
+    fz = ops.spconv_fwd(2.0 * x - 0.5 * y, pk, nbr, n, 32, 27)
+    torch.testing.assert_close(fz, 2.0 * fx - 0.5 * fy, rtol=1e-4, atol=5e-5)   # fp32 rounding of ~200-term sums of O(1) values
+    # fused epilogue at this size: BN scale / shift, ReLU, residual
+    sc, sh = torch.rand(32, device="cuda", generator=g) + 0.5, torch.randn(32, device="cuda", generator=g)
+    full = ops.spconv_fwd(x, pk, nbr, n, 32, 27, scale=sc, shift=sh, relu=True, residual=y)
+    torch.testing.assert_close(full, torch.relu(fx * sc + sh) + y, rtol=1e-5, atol=1e-5)         # same sums, epilogue only
+
+
+def test_coarse_level_and_cross_level_maps(ops, level):
+    coords, index, n = level["coords"], level["index"], level["n"]
+    cidx, cc = ops.block_index_coarsen(index, n)
+    nc = cc.shape[0]
+    parents = torch.cat([coords[:, :1], coords[:, 1:] // 2 * 2], 1)
+    assert nc == torch.unique(parents, dim=0).shape[0]                   # every occupied parent exactly once
+    down = ops.kernel_map_bi(cc, index, 3, 1, 1)                         # coarse rows gather fine rows
+    assert int(down.pp_pairs) == int((down >= 0).sum())
+    # a fine voxel at offset d from its parent's corner is found from the parent through offsets {0,1}^3 only
+    fine_of = down[13]
+    has = fine_of >= 0
+    assert torch.equal(coords[fine_of[has].long()], cc[has])
+    up = ops.kernel_map_transpose(down, n)
+    assert int((up >= 0).sum()) == int(down.pp_pairs)
+    for k in (0, 13, 26):                                                # up[k][i] = c  <=>  down[k][c] = i
+        c_of = up[k]
+        h = c_of >= 0
+        assert torch.equal(down[k][c_of[h].long()].long(), torch.nonzero(h).view(-1))
+    # every fine voxel reaches its parent through exactly one of the 8 non-negative offsets
+    reach = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for k in range(27):
+        dx, dy, dz = k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1
+        if min(dx, dy, dz) >= 0:
+            c_of = up[k]
+            h = c_of >= 0
+            is_parent = torch.zeros(n, dtype=torch.bool, device="cuda")
+            is_parent[h] = (cc[c_of[h].long()] == parents[h]).all(1)
+            reach += is_parent.int()
+    assert bool((reach == 1).all())
+
+
+def test_sort_is_sorted_stable_and_a_permutation(ops):
+    n = 30_000_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    keys = torch.randint(0, 2 ** 40, (n,), dtype=torch.int64, device="cuda", generator=g)
+    keys[::3] = keys[1::3][: keys[::3].shape[0]]
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    ko, vo = ops.sort_pairs(keys, vals, 40)
+    assert bool((ko[1:] >= ko[:-1]).all())                               # sorted
+    assert bool(((ko[1:] > ko[:-1]) | (vo[1:] > vo[:-1])).all())         # stable: ties keep ascending input positions
+    assert torch.equal(keys[vo.long()], ko)                              # the values name the rows the keys came from
+    seen = torch.zeros(n, dtype=torch.bool, device="cuda")
+    seen[vo.long()] = True
+    assert bool(seen.all())                                              # a permutation
+
+
+def test_region_growing_properties_on_a_full_batch(ops):
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    import bench
+    scene, tiles, _ = bench.build_scene(2_000_000, 4, 0.05, 2022)
+    b = syn.tile_batch(scene, tiles, list(range(len(tiles))))
+    cls, off, _ = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(1))
+    pos = torch.from_numpy(b["pos"] + off).cuda()
+    pred, batch = torch.from_numpy(cls).cuda(), torch.from_numpy(b["batch"]).cuda()
+    ignore = torch.tensor(syn.NPM3D_STUFF)
+    radius = 0.075
+    csr, pc = ops.region_grow_csr(pos, pred, batch, ignore, 200, radius, 10, syn.NPM3D_NUM_CLASSES)
+    assert csr.n > 100
+    pts, offs = csr.points, csr.offsets.long()
+    sizes = offs[1:] - offs[:-1]
+    assert int(sizes.min()) >= 10 and int(sizes.sum()) == pts.shape[0]
+    assert torch.unique(pts).shape[0] == pts.shape[0]                    # clusters are disjoint
+    cid = torch.repeat_interleave(torch.arange(csr.n, device="cuda"), sizes)
+    assert torch.equal(pc[pts], cid.int()) and int((pc >= 0).sum()) == pts.shape[0]
+    first = pts[offs[:-1]]
+    assert torch.equal(pred[pts], pred[first][cid]) and torch.equal(batch[pts], batch[first][cid])   # uniform (batch, class)
+    assert not bool(torch.isin(pred[pts], ignore.cuda()).any())
+    inside = torch.ones_like(pts, dtype=torch.bool)
+    inside[offs[:-1]] = False
+    assert bool((pts[1:] > pts[:-1])[inside[1:]].all())                  # points ascend inside a cluster
+    # deterministic: the fixpoint does not depend on the order the atomics land in
+    csr2, pc2 = ops.region_grow_csr(pos, pred, batch, ignore, 200, radius, 10, syn.NPM3D_NUM_CLASSES)
+    assert torch.equal(pc2, pc) and torch.equal(csr2.points, pts) and torch.equal(csr2.offsets, csr.offsets)
