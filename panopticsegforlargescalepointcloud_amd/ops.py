@@ -17,8 +17,17 @@ class LaunchProfiler:
     """Optional per-launch timing of the dominant kernel (pp_spconv_fwd) with HIP events recorded on the stream the
     kernel is launched on (bench.py uses it for the roofline object; off by default)."""
 
-    def __init__(self):
+    def __init__(self, reserve=0):
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual)
+        # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
+        # (bench.py: launches per step x steps, counted during the warm-up) so that a timed launch only pays the records
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * int(reserve))]
+
+    def events(self):
+        pool = self._pool
+        if len(pool) >= 2:
+            return pool.pop(), pool.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def summarize(self):
         torch.cuda.synchronize()
@@ -443,8 +452,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     row_order = _need(row_order, torch.int32, "row_order")
     prof = PROFILER
     if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0, e1 = prof.events()
         e0.record()
     _conv_scratch(lib, in0.device)
     args = (_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), K, n_out, cout, _ptr(scale),
