@@ -228,9 +228,21 @@ class CoordinateManager:
                 err, self._worker_err = self._worker_err, None
                 raise err
 
+    @staticmethod
+    def _consumed_here(*tensors):
+        """a tensor built on the prefetch stream belongs to that stream's allocator pool: tell the allocator that the
+        calling stream reads it too, so that the block is not handed out again while this stream's kernels are pending"""
+        cur = torch.cuda.current_stream()
+        for t in tensors:
+            if t is not None and t.is_cuda and getattr(t, "pp_seen_by", None) != cur.cuda_stream:
+                t.record_stream(cur)
+                t.pp_seen_by = cur.cuda_stream
+
     def level(self, ts):
         self._use(("level", ts))
-        return self.levels[ts]
+        lv = self.levels[ts]
+        self._consumed_here(lv.coords)
+        return lv
 
     def to_internal(self, feats):
         return feats if self.perm is None else _permute_rows(feats, self.perm, self.inv_perm)
@@ -289,6 +301,7 @@ class CoordinateManager:
             with self._lock:
                 m = self._kernel_map_locked(key)
         self._use(key)
+        self._consumed_here(m, getattr(m, "pp_order", None))
         return m
 
     def kernel_map_rows(self, ts_from, ts_to, ksize, sign):
