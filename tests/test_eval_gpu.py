@@ -109,6 +109,22 @@ def test_block_merging_device_matches_numpy(ops):
         np.testing.assert_allclose(gpu.votes.cpu().numpy(), cpu.votes, rtol=1e-6, atol=1e-6)
 
 
+def test_block_merging_device_matches_the_reference(ops):
+    """the device assembler against the output of the reference's own block_merging, block after block
+    (tests/golden/block_merging_cases.npz, make_golden.py)"""
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssemblerGPU
+    z = np.load(os.path.join(GOLD, "block_merging_cases.npz"))
+    for name in z["names"].tolist():
+        n_scene = int(z["n_scene_" + name])
+        offs, origin, labels = z["block_offsets_" + name], z["origin_" + name], z["labels_" + name]
+        gpu = SceneAssemblerGPU(n_scene, 2, "cuda")
+        for b in range(len(offs) - 1):
+            gpu.add_block(dev(origin[offs[b]: offs[b + 1]]), dev(labels[offs[b]: offs[b + 1]].astype(np.int32)))
+            assert np.array_equal(gpu.ins_pre.cpu().numpy(), z["after_" + name][b]), (name, b)
+            assert gpu.max_instance == int(z["max_instance_" + name][b])
+        gpu.finish()
+
+
 def test_block_merging_rules_device(ops):
     """the hand-written cases of tests/test_host_logic.py::test_block_merging_rules on the device, step by step"""
     from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler, SceneAssemblerGPU

@@ -199,6 +199,25 @@ def test_block_merging_rules():
     assert np.array_equal(before, asm.ins_pre)
 
 
+def test_block_merging_matches_the_reference_block_after_block():
+    """scene.block_merging / SceneAssembler against the output of the reference's OWN block_merging
+    (tests/golden/block_merging_cases.npz, generated by running the tracker's method, make_golden.py): scene labels and
+    max_instance after every block, incl. its label-allocation quirks (unused block-local ids burn labels, max_instance + 1)."""
+    from panopticsegforlargescalepointcloud_amd.scene import SceneAssembler, block_merging
+    z = np.load(os.path.join(ROOT, "tests", "golden", "block_merging_cases.npz"))
+    for name in z["names"].tolist():
+        n_scene = int(z["n_scene_" + name])
+        offs, origin, labels = z["block_offsets_" + name], z["origin_" + name], z["labels_" + name]
+        asm = SceneAssembler(n_scene, 2)
+        cur, mx = np.full(n_scene, -1, np.int64), 0
+        for b in range(len(offs) - 1):
+            o, lab = origin[offs[b]: offs[b + 1]], labels[offs[b]: offs[b + 1]]
+            cur, mx = block_merging(o, lab, cur, mx)
+            asm.add_block(o, lab)
+            assert np.array_equal(cur, z["after_" + name][b]) and mx == int(z["max_instance_" + name][b]), (name, b)
+            assert np.array_equal(asm.ins_pre, z["after_" + name][b]) and asm.max_instance == mx
+
+
 def test_panoptic_quality_metric():
     from panopticsegforlargescalepointcloud_amd.panoptic.metrics import thing_panoptic_quality
     gt_sem = np.array([2] * 10 + [2] * 10 + [3] * 10 + [0] * 10)
