@@ -171,6 +171,21 @@ def make_nms():
         ids, cl = res.get_instances(**kw)
         out["ids_" + tag] = np.asarray([int(i) for i in ids], np.int64)
         out["sizes_" + tag] = np.asarray([len(c) for c in cl], np.int64)
+    # the tracker's painting of the surviving proposals (get_cur_ins_pre_label, panoptic_tracker_pointgroup_npm3d.py:326-337),
+    # method extracted with `ast` and fed exactly like track() does (:249-257): with scores (after get_instances with the
+    # tracker's min_cluster_points) and without a ScoreNet (scores None: every proposal, proposal order)
+    import ast
+    tpath = os.path.join(REF, "torch_points3d/metrics/panoptic_tracker_pointgroup_npm3d.py")
+    ttree = ast.parse(open(tpath).read())
+    tfn = [m for c in ttree.body if isinstance(c, ast.ClassDef) for m in c.body
+           if isinstance(m, ast.FunctionDef) and m.name == "get_cur_ins_pre_label"][0]
+    tns = {"np": np}
+    exec(compile(ast.Module(body=[tfn], type_ignores=[]), tpath, "exec"), tns)
+    sem = np.zeros(n, np.int64)
+    ids, cl = res.get_instances(min_cluster_points=10)
+    c_scores = scores[[int(i) for i in ids]].numpy()
+    out["paint_tracker"] = tns["get_cur_ins_pre_label"](None, cl, c_scores, sem).astype(np.int64)
+    out["paint_noscore"] = tns["get_cur_ins_pre_label"](None, clusters, None, sem).astype(np.int64)
     np.savez_compressed(os.path.join(OUT, "nms_cases.npz"), n=np.int64(n),
                         cluster_offsets=np.cumsum([0] + [len(c) for c in clusters]),
                         cluster_points=torch.cat(clusters).numpy(), scores=scores.numpy(), **out)
@@ -425,6 +440,9 @@ def make_block_merging():
 if __name__ == "__main__":
     if "--grid-only" in sys.argv:
         make_grid_cylinders()
+        sys.exit(0)
+    if "--nms-only" in sys.argv:
+        make_nms()
         sys.exit(0)
     if "--block-merging-only" in sys.argv:
         make_block_merging()

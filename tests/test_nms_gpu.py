@@ -98,6 +98,24 @@ def test_get_instances_matches_reference_golden(ops):
     assert empty.get_instances() == ([], [])
 
 
+def test_painting_matches_the_reference_tracker(ops):
+    """NMS + painting on the device vs the labels the reference's own tracker paints (get_instances with the tracker's
+    min_cluster_points, then get_cur_ins_pre_label executed by make_golden.py: `paint_tracker`), and the ScoreNet-less
+    case (`paint_noscore`: every proposal, proposal order)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "nms_cases.npz"))
+    offs = z["cluster_offsets"]
+    n = int(z["n"])
+    clusters = [torch.from_numpy(z["cluster_points"][offs[i]: offs[i + 1]]) for i in range(len(offs) - 1)]
+    csr = ops.ClusterCSR.from_list(clusters, "cuda")
+    batch = torch.zeros(n, dtype=torch.int64, device="cuda")
+    labels, counts, _, pairs = ops.nms_paint(csr, n, batch, 1, torch.from_numpy(z["scores"]).cuda(), 0.3, 10, 0.5)
+    pairs.check()
+    assert np.array_equal(labels.cpu().numpy().astype(np.int64), z["paint_tracker"])
+    assert counts.tolist() == [len(z["ids_tracker"])]
+    labels0, counts0, _, _ = ops.nms_paint(csr, n, batch, 1, None, 0.3, 10, 0.5)
+    assert np.array_equal(labels0.cpu().numpy().astype(np.int64), z["paint_noscore"]) and counts0.tolist() == [len(clusters)]
+
+
 def test_equal_scores_and_many_sources(ops):
     """duplicated proposals (identical sets, identical scores) keep exactly one copy; a point in 3 proposals yields 3 pairs;
     more than 8 proposals on one point is reported."""
