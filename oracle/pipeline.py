@@ -144,6 +144,39 @@ def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False):
     return out
 
 
+def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=False, timings=None):
+    """Proposal generation of PointGroup3heads (PointGroup3heads.py:163-390): cluster_type 1 = region growing on the shifted
+    points (nsample 200), 2 = on the raw positions (torch-points-kernels' default nsample 16) then on the shifted points,
+    5 = shifted points then mean shift on the embeddings of the thing points, 6 = raw, shifted, mean shift.  Returns
+    (clusters, cluster_type codes) in the reference's order; _cluster2 marks the votes as type 1 only when there are
+    position clusters (:208-210).  Pinned on the reference's own functions: tests/golden/proposal_cases.npz."""
+    T = {} if timings is None else timings
+    ct = int(opt["cluster_type"])
+    ignore = [-1] + [int(c) for c in stuff_classes]
+    radius = float(opt["cluster_radius_search"])
+    pos_cl = []
+    if ct in (2, 6):
+        pos_cl, _ = O.region_grow(pos, pred, batch, ignore, nsample=16, radius=radius, min_cluster_size=10)
+    t0 = time.perf_counter()
+    votes, _ = O.region_grow(pos + off, pred, batch, ignore, nsample=200, radius=radius, min_cluster_size=10)
+    T["region_grow"] = time.perf_counter() - t0
+    ms = []
+    if ct in (5, 6):
+        t0 = time.perf_counter()
+        mask = ~np.isin(pred, ignore)
+        ms = meanshift_clusters(emb[mask], batch[mask], np.nonzero(mask)[0], float(opt["bandwidth"]), use_sklearn=use_sklearn_meanshift)
+        T["meanshift"] = time.perf_counter() - t0
+    if ct == 1:
+        return list(votes), [0] * len(votes)
+    if ct == 2:
+        return list(pos_cl) + list(votes), [0] * len(pos_cl) + [1 if len(pos_cl) else 0] * len(votes)
+    if ct == 5:
+        return list(votes) + ms, [0] * len(votes) + [1] * len(ms)
+    if ct == 6:
+        return list(pos_cl) + list(votes) + ms, [0] * len(pos_cl) + [1] * len(votes) + [2] * len(ms)
+    raise NotImplementedError("cluster_type %d" % ct)
+
+
 def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None):
     """Eval forward of PointGroup3heads (setting IV / cluster_type 5 or type 1) on CPU.
     data: dict with pos [N,3], coords [N,3], batch [N], x [N,4].  Returns dict of outputs."""
@@ -159,20 +192,8 @@ def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklear
     T["heads"] = time.perf_counter() - t0
     if override is not None:
         pred, off, emb = override
-    ignore = [-1] + [int(c) for c in stuff_classes]
-    t0 = time.perf_counter()
-    votes, _ = O.region_grow(data["pos"] + off, pred, data["batch"], ignore, nsample=200,
-                             radius=float(opt["cluster_radius_search"]), min_cluster_size=10)
-    T["region_grow"] = time.perf_counter() - t0
-    clusters, ctype = list(votes), [0] * len(votes)
-    if int(opt["cluster_type"]) == 5:
-        t0 = time.perf_counter()
-        mask = ~np.isin(pred, ignore)
-        ms = meanshift_clusters(emb[mask], data["batch"][mask], np.nonzero(mask)[0], float(opt["bandwidth"]),
-                                use_sklearn=use_sklearn_meanshift)
-        T["meanshift"] = time.perf_counter() - t0
-        clusters += ms
-        ctype += [1] * len(ms)
+    clusters, ctype = group(data["pos"], data["batch"], pred, off, emb, opt, stuff_classes, use_sklearn_meanshift, T)
+    clusters, ctype = list(clusters), list(ctype)
     scores = None
     if clusters:
         t0 = time.perf_counter()

@@ -186,7 +186,8 @@ class PointGroup3heads(nn.Module):
     def _cluster2(self, pred, off, emb):
         pos = self._grow(self.raw_pos, pred, None)
         votes = self._grow(self.raw_pos + off, pred, 200)
-        return ops.ClusterCSR.concat([pos, votes]), self._types([(pos, 0), (votes, 1)], pred.device)
+        # (the reference marks the votes as type 1 only when there are position clusters: PointGroup3heads.py:208-210)
+        return ops.ClusterCSR.concat([pos, votes]), self._types([(pos, 0), (votes, 1 if pos.n else 0)], pred.device)
 
     def _lap(self, name):
         if getattr(self, "_timer", None) is not None:

@@ -437,9 +437,77 @@ def make_block_merging():
     print("block merging:", {n: int(cases["max_instance_" + n][-1]) for n in names})
 
 
+def make_proposals():
+    """Proposal generation of the reference model: PointGroup3heads._cluster / _cluster2 / _cluster5 / _cluster6
+    (torch_points3d/models/panoptic/PointGroup3heads.py:163-390) extracted with `ast` and executed here, with the
+    reference's OWN utils/meanshift_cluster.py (sklearn MeanShift workers) behind them.  torch_points_kernels.region_grow
+    (absent library) is the one stand-in: the CPU oracle's restatement with tpk's defaults (nsample 16) -- its own output is
+    part of the fixture only through these functions.  Pins: which coordinates / nsample every call uses, the order in which
+    the groups of proposals are concatenated, the cluster_type codes (incl. _cluster2's quirk: the votes get type 1 only if
+    the position clusters are not empty), the per-sample mean shift with its `> 3 points` rule."""
+    import ast
+    os.environ["OMP_NUM_THREADS"] = "1"  # the reference forks a worker Pool: no OpenMP team may exist in this process before
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import oracle as O
+    ms_ref = _load(os.path.join(REF, "torch_points3d/utils/meanshift_cluster.py"), "ref_meanshift_cluster")
+    sys.modules["ref_meanshift_cluster"] = ms_ref  # its Pool workers are pickled by reference
+    path = os.path.join(REF, "torch_points3d/models/panoptic/PointGroup3heads.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PointGroup3heads"][0]
+    wanted = ("_cluster", "_cluster2", "_cluster5", "_cluster6")
+    fns = [m for m in cls.body if isinstance(m, ast.FunctionDef) and m.name in wanted]
+
+    def region_grow(pos, labels, batch, ignore_labels=[], radius=0.02, nsample=16, min_cluster_size=32):
+        cl, _ = O.region_grow(pos.numpy(), labels.numpy(), batch.numpy(), [int(v) for v in ignore_labels], nsample=nsample,
+                              radius=float(radius), min_cluster_size=min_cluster_size)
+        return [torch.from_numpy(c) for c in cl]
+
+    ns = {"torch": torch, "np": np, "region_grow": region_grow, "meanshift_cluster": ms_ref}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(31)
+    cases, names = {}, []
+    for t, (n, n_inst, sparse_pos) in enumerate([(5000, 14, False), (3000, 8, True)]):
+        inst = rng.integers(0, n_inst, size=n)
+        batch = np.sort(rng.integers(0, 2, size=n)).astype(np.int64)
+        inst_cls = np.array([2, 3, 4, 6, 7, 8, 0, 1, 5, 2, 3, 4, 6, 7])[:n_inst]
+        pred = inst_cls[inst].astype(np.int64)
+        cen = rng.uniform(-6, 6, size=(n_inst, 3))
+        spread = 2.5 if sparse_pos else 0.45      # sparse_pos: raw positions too far apart for region growing at nsample 16
+        pos = (cen[inst] + rng.normal(0, spread, size=(n, 3)) + batch[:, None] * 0.01).astype(np.float32)
+        off = (cen[inst] - pos + rng.normal(0, 0.03, size=(n, 3))).astype(np.float32)
+        e_inst = rng.normal(0, 2.0, size=(n_inst, 5))
+        emb = (e_inst[inst] + rng.normal(0, 0.12, size=(n, 5))).astype(np.float32)
+        sem = np.full((n, 9), -5.0, np.float32)
+        sem[np.arange(n), pred] = 5.0
+        me = types.SimpleNamespace(raw_pos=torch.from_numpy(pos), input=types.SimpleNamespace(batch=torch.from_numpy(batch)),
+                                   device="cpu", _stuff_classes=torch.tensor([0, 1, 5]),
+                                   opt=types.SimpleNamespace(cluster_radius_search=0.3, bandwidth=0.6))
+        name = "p%d" % t
+        names.append(name)
+        for k, v in dict(pos=pos, off=off, emb=emb, pred=pred, batch=batch, sem=sem).items():
+            cases["%s_%s" % (k, name)] = v
+        cases["radius_" + name], cases["bandwidth_" + name] = np.float64(0.3), np.float64(0.6)
+        for fn_name in wanted:
+            args = [torch.from_numpy(sem), torch.from_numpy(off)] + ([torch.from_numpy(emb)] if fn_name in ("_cluster5", "_cluster6") else [])
+            cl, ct = ns[fn_name](me, *args)
+            tag = "%s%s" % (name, fn_name)
+            cases["offsets_" + tag] = np.cumsum([0] + [len(c) for c in cl]).astype(np.int64)
+            cases["points_" + tag] = torch.cat(cl).numpy().astype(np.int64) if cl else np.zeros(0, np.int64)
+            cases["types_" + tag] = np.asarray(ct.cpu().numpy() if torch.is_tensor(ct) else ct, np.uint8)
+            print("proposals", tag, len(cl), "clusters, types", np.bincount(cases["types_" + tag], minlength=3).tolist())
+    cases["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "proposal_cases.npz"), **cases)
+
+
 if __name__ == "__main__":
     if "--grid-only" in sys.argv:
         make_grid_cylinders()
+        sys.exit(0)
+    if "--proposals-only" in sys.argv:
+        if os.environ.get("OMP_NUM_THREADS") != "1":  # the reference forks a worker Pool: torch / BLAS must not hold OpenMP teams
+            os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1",
+                                                                         OPENBLAS_NUM_THREADS="1"))
+        make_proposals()
         sys.exit(0)
     if "--nms-only" in sys.argv:
         make_nms()
@@ -459,6 +527,7 @@ if __name__ == "__main__":
     make_final_eval()
     make_grid_cylinders()
     make_block_merging()
+    print("proposal_cases.npz: run `python tests/golden/make_golden.py --proposals-only` (single-threaded environment)")
 # tests/golden/ref_written_npm3d_like.ply (+ _values.npz): 50 vertices written by the reference's own
 # torch_points3d/models/panoptic/ply.py:write_ply (fields x, y, z, scalar_class, scalar_label as float32, the way
 # CloudCompare exports NPM3D) -- generated once with the snippet in the commit that added panopticsegforlargescalepointcloud_amd/io.py.
