@@ -2,7 +2,8 @@
 passes and A/B builds of the library (PP_HIP_LIB).
 usage (GPU box): python profiles/conv_one.py <n_tiles> <shape>[,<shape>...] [reps]
    shape = ts:cin:cout[:kind]   kind = same (default) | up (transposed, ts*2 -> ts) | down (strided, ts/2 -> ts)
-   e.g.  python profiles/conv_one.py 16 1:16:16,2:32:32,4:48:48,1:64:64:up"""
+   e.g.  python profiles/conv_one.py 16 1:16:16,2:32:32,4:48:48,1:64:64:up
+   PP_CONV_VARIANT="rows_per_wave,pipeline,split_k" selects an explicit kernel variant (pp_spconv_fwd_ex)"""
 import os
 import sys
 
@@ -46,7 +47,8 @@ def main():
         x = torch.randn(n_in, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         pk = ops.pack_weight(w)
-        fn = lambda: ops.spconv_fwd(x, pk, nbr, n, cout, 27, row_order=order)  # noqa: E731
+        var = tuple(int(v) for v in os.environ["PP_CONV_VARIANT"].split(",")) if os.environ.get("PP_CONV_VARIANT") else None
+        fn = lambda: ops.spconv_fwd(x, pk, nbr, n, cout, 27, row_order=order, variant=var)  # noqa: E731
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
