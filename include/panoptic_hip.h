@@ -37,7 +37,8 @@ enum {
   PP_ERR_INVALID = 1,  /* bad argument (null pointer, unsupported size) */
   PP_ERR_RANGE = 2,    /* coordinate/batch index not representable in the 64-bit key */
   PP_ERR_HIP = 3,      /* a HIP runtime call failed; see pp_last_error() */
-  PP_ERR_WORKSPACE = 4 /* workspace too small */
+  PP_ERR_WORKSPACE = 4, /* workspace too small */
+  PP_UNSUPPORTED = 5    /* not an error: this optional fused form does not serve the shape, nothing was launched */
 };
 
 /* Library identity / diagnostics.  pp_version: "panoptic_hip <n> gfx950". */
@@ -200,6 +201,15 @@ int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, in
                   const int32_t* row_order /*slot order of a cross-level map (pp_map_order): nbr is slot-major and slot s writes
                                               row row_order[s]; NULL = slot s is row s*/, float* out,
                   pp_stream_t stream);
+/* pp_spconv_fwd with the 1x1 shortcut ("downsample" branch: 1x1 convolution + BatchNorm of the block's input,
+ * api_modules.py:9-82 ResBlock) of a residual block fused into the block's last convolution:
+ *   out[o] = relu?( conv(o) * scale + shift ) + residual[o] + ( ds_in[o] . W_ds ) * ds_scale + ds_shift
+ * ds_in [n_out, ds_c] fp32 (ds_c % 16 == 0), ds_packed = pp_pack_weight of the [1, ds_c, cout] kernel.  Same-level maps on
+ * the unsplit pipelined kernel only: otherwise PP_UNSUPPORTED comes back and nothing has been launched. */
+int pp_spconv_fwd_shortcut(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
+                           const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale, const float* shift,
+                           int32_t relu, const float* residual, float* out, int32_t bf16, const float* ds_in, int32_t ds_c,
+                           const float* ds_packed, const float* ds_scale, const float* ds_shift, pp_stream_t stream);
 /* bfloat16 compute variant (BASELINE.json configs[4], "bf16"): same arguments and fp32 tensors in memory; features and
  * weights are rounded to bfloat16 (nearest even) in registers, products accumulate in fp32 on
  * v_mfma_f32_16x16x16_bf16 -- torch.autocast(bfloat16) semantics for the convolution.  Needs cin % 16 == 0 per source,

@@ -774,9 +774,11 @@ class MinkowskiBroadcastMultiplication(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # fused eval entry point used by the build-owned ResBlock / ResNetDown / ResNetUp
 # ------------------------------------------------------------------------------------------------
-def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None, shortcut=None):
     """Eval-mode  relu?(BN(conv(cat(x, skip)))) + residual  as ONE kernel launch (folded BN in the epilogue,
-    ME.cat fused as a second source).  x/skip/residual are SparseTensors on compatible maps."""
+    ME.cat fused as a second source).  x/skip/residual are SparseTensors on compatible maps.
+    shortcut = (SparseTensor s, 1x1 conv, bn): `+ BN(conv1x1(s))` computed by the same launch (the downsample branch of a
+    residual block); returns None when the library does not serve the shape that way (nothing launched)."""
     ts_out, nbr, _ = conv.out_stride_and_map(x)
     cm = x.coordinate_manager
     n_out = cm.level(ts_out).n
@@ -795,9 +797,18 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, skip=None):
         res = residual.feats
     c0 = x.feats.shape[1]
     c1 = 0 if in1 is None else in1.shape[1]
+    sc = None
+    if shortcut is not None:
+        s_t, s_conv, s_bn = shortcut
+        if getattr(nbr, "pp_order", None) is not None or s_t.tensor_stride != ts_out or s_conv.kernel_volume != 1:
+            return None
+        s_scale, s_shift = s_bn.folded()
+        sc = (s_t.feats, s_conv.packed(), s_scale, s_shift)
     feats = ops.spconv_fwd(x.feats, conv.packed(), nbr, n_out, conv.out_channels, conv.kernel_volume, in1=in1,
                            scale=scale, shift=shift, relu=relu, residual=res, row_order=getattr(nbr, "pp_order", None),
-                           bf16=_CONV_BF16[0])
+                           bf16=_CONV_BF16[0], shortcut=sc)
+    if feats is None:
+        return None
     if conv.bias is not None:
         raise NotImplementedError("fused path assumes bias=False (every conv of the reference network)")
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)

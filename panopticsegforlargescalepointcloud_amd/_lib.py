@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpanoptic_hip.so")
 
 PP_OK = 0
-_STATUS = {1: "PP_ERR_INVALID", 2: "PP_ERR_RANGE", 3: "PP_ERR_HIP", 4: "PP_ERR_WORKSPACE"}
+_STATUS = {1: "PP_ERR_INVALID", 2: "PP_ERR_RANGE", 3: "PP_ERR_HIP", 4: "PP_ERR_WORKSPACE", 5: "PP_UNSUPPORTED"}
+PP_UNSUPPORTED = 5  # an optional fused form does not serve the shape: nothing was launched
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -64,6 +65,7 @@ SIGNATURES = {
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_set_scratch": (C.c_int, [vp, sz]),
+    "pp_spconv_fwd_shortcut": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_fwd_bf16": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_fwd_ex": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "pp_spconv_bwd_weight": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),

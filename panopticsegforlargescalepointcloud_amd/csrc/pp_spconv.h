@@ -34,6 +34,14 @@ struct SpconvArgs {
   // to part[z][row][col]; k_spconv_split_reduce adds them in a fixed order and applies the epilogue
   int split;
   float* part;
+  // fused 1x1 shortcut of a residual block (v3 kernel, same-level maps, unsplit): out += (ds_in @ ds_wp) * ds_scale + ds_shift
+  // after the ReLU -- the block's "downsample" branch (1x1 convolution + BatchNorm of the block's input) computed by the
+  // block's last convolution instead of a launch of its own that writes a tensor this kernel reads back
+  const float* ds_in;
+  const float* ds_wp;
+  const float* ds_scale;
+  const float* ds_shift;
+  int ds_c;
 };
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row

@@ -251,7 +251,9 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
                            const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                            const float* scale, const float* shift, int32_t relu, const float* residual,
                            const int32_t* row_order, float* out, int bf16, int rows_per_wave, int pipeline, int split_k,
-                           pp_stream_t stream) {
+                           pp_stream_t stream, const float* ds_in = nullptr, int32_t ds_c = 0,
+                           const float* ds_packed = nullptr, const float* ds_scale = nullptr,
+                           const float* ds_shift = nullptr) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
@@ -266,6 +268,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.in0 = in0; a.in1 = in1; a.wp = packed_weight; a.nbr = nbr; a.scale = scale; a.shift = shift;
   a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
+  a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
   const int max_ntw = (mode16 || c4) ? 4 : 7;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
@@ -298,10 +301,19 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
         return PP_ERR_WORKSPACE;
       }
     }
+    if (ds_in) {
+      // the fused shortcut rides on the unsplit pipelined kernel over a same-level map; anything else is the caller's
+      // two launches (PP_UNSUPPORTED: nothing was launched)
+      if (a.split > 1 || row_order || n_in != n_out || ds_c % 16 != 0 || ds_c <= 0 ||
+          (double)n_out * ds_c * 4.0 >= 4294967000.0 || rows_per_wave || pipeline)
+        return PP_UNSUPPORTED;
+      a.ds_in = ds_in; a.ds_wp = ds_packed; a.ds_scale = ds_scale; a.ds_shift = ds_shift; a.ds_c = ds_c;
+    }
     int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;
     if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
   } else {
+    if (ds_in) return PP_UNSUPPORTED;
     // first-version kernel: Cin % 16 != 0 other than the 4-channel input layer, and inputs of 4 GiB or more per source
     if (bf16) {
       pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
@@ -331,6 +343,20 @@ extern "C" int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int
                              const int32_t* row_order, float* out, pp_stream_t stream) {
   return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
                          row_order, out, 0, 0, 0, 0, stream);
+}
+/* pp_spconv_fwd with the 1x1 shortcut of a residual block fused in:
+ *   out[o] = relu?( conv(o) * scale + shift ) + residual[o] + ( ds_in[o] . W_ds ) * ds_scale + ds_shift
+ * (ds_in [n_out, ds_c] fp32, ds_packed = pp_pack_weight of the [1, ds_c, cout] kernel).  Served on same-level maps by the
+ * unsplit pipelined kernel; otherwise PP_UNSUPPORTED is returned and NOTHING has been launched (the caller runs the
+ * shortcut as its own 1x1 convolution and passes it as `residual`). */
+extern "C" int pp_spconv_fwd_shortcut(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                                      const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
+                                      const float* scale, const float* shift, int32_t relu, const float* residual,
+                                      float* out, int32_t bf16, const float* ds_in, int32_t ds_c, const float* ds_packed,
+                                      const float* ds_scale, const float* ds_shift, pp_stream_t stream) {
+  PP_REQUIRE(ds_in && ds_packed, "pp_spconv_fwd_shortcut: null shortcut input / weights");
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual, nullptr,
+                         out, bf16 ? 1 : 0, 0, 0, 0, stream, ds_in, ds_c, ds_packed, ds_scale, ds_shift);
 }
 extern "C" int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                                   const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out,

@@ -45,7 +45,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // C4: the 4-channel input layer (rows of 16 bytes).  A step is one kernel offset with ONE fp32 MFMA per tile (k = the four
 // channels): lane (i, q) loads channel q of its row and weight [q][column i] as single dwords.
-template <int NTW, int T, bool BF16, int D, bool C4 = false>
+// DS: fused 1x1 shortcut (SpconvArgs::ds_*): after the offset loop the wave multiplies ITS OWN rows of ds_in (no gather: a
+// same-level map's output row is the input row) with the packed 1x1 weights into a second set of accumulators.
+template <int NTW, int T, bool BF16, int D, bool C4 = false, bool DS = false>
 __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
@@ -252,6 +254,53 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 #undef F3_MFMAS
   }
 
+  f32x4 acc2[DS ? T : 1][DS ? NTW : 1];
+  if constexpr (DS) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) acc2[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int S2 = a.ds_c >> 4;
+    const unsigned ds_row = (unsigned)a.ds_c * 4u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_in, 0, (int)((unsigned)a.n_out * ds_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_wp, 0, (int)((unsigned)S2 * (unsigned)a.NT * 1024u), 0x00020000);
+    unsigned o2[T];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      const int64_t r = row_base + tt * 16 + i;
+      o2[tt] = r < a.n_out ? (unsigned)r * ds_row + (unsigned)q * 16u : F3_MISSING;
+    }
+    const unsigned lane16d = (unsigned)lane * 16u;
+#pragma unroll 1
+    for (int s2 = 0; s2 < S2; ++s2) {
+      f32x4 A2[T], B2[NTW];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        A2[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)o2[tt], s2 * 64, 0));
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt)
+        B2[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdw, (int)(lane16d + jt * 1024u),
+                                                                                 (int)((unsigned)(s2 * a.NT + jt0) * 1024u), 0));
+      if constexpr (BF16) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          const s16x4 ah = pp_bf16x4(A2[tt]);
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pp_bf16x4(B2[jt]), acc2[tt][jt], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[tt][t], B2[jt][t], acc2[tt][jt], 0, 0, 0);
+      }
+    }
+  }
+
   if (a.split > 1) {  // raw partial sums; the epilogue runs in k_spconv_split_reduce
     float* __restrict__ part = a.part + (int64_t)blockIdx.z * a.n_out * a.cout;
 #pragma unroll
@@ -279,6 +328,8 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     if (jt0 + jt < a.NT && col < a.cout) {
       const float sc = a.scale ? a.scale[col] : 1.f;
       const float sh = a.shift ? a.shift[col] : 0.f;
+      const float sc2 = DS && a.ds_scale ? a.ds_scale[col] : 1.f;
+      const float sh2 = DS && a.ds_shift ? a.ds_shift[col] : 0.f;
 #pragma unroll
       for (int rt = 0; rt < T; ++rt) {
 #pragma unroll
@@ -289,6 +340,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
             float v = acc[rt][jt][r] * sc + sh;
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.residual) v += a.residual[row * a.cout + col];
+            if constexpr (DS) v += acc2[rt][jt][r] * sc2 + sh2;
             a.out[row * a.cout + col] = v;
           }
         }
@@ -300,6 +352,16 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+  if (a.ds_in) {  // fused shortcut: the per-shape loop variant only (3 for <= 2 column tiles, 1 otherwise)
+    switch (ntw) {
+      case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
+    }
+    return PP_OK;
+  }
   if constexpr (!BF16) {
     if (a.c0 == 4) {  // the input layer: one column-tile count per launch is enough (cout = 16 in every published model)
       switch (ntw) {

@@ -7,6 +7,7 @@ App. A) and forward semantics as
 In eval mode every conv -> BN -> ReLU (+ residual, + skip concat) chain is ONE fused kernel launch
 (ME.conv_bn_act); in training mode the modules run unfused through autograd Functions.
 """
+import os
 import sys
 
 import torch
@@ -68,6 +69,9 @@ def fused_head(head, x, log_softmax=False, want_argmax=False):
                         log_softmax=log_softmax, want_argmax=want_argmax)
 
 
+FUSE_SHORTCUT = os.environ.get("PP_FUSE_SHORTCUT", "1") != "0"
+
+
 class ResBlock(ME.MinkowskiNetwork):
     """conv3-BN-ReLU-conv3-BN-ReLU, plus (1x1 conv-BN of the input | the input); ReLU BEFORE the add, none after."""
 
@@ -97,8 +101,14 @@ class ResBlock(ME.MinkowskiNetwork):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled():
             b = self.block
-            res = ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False) if self.downsample else x
             h = ME.conv_bn_act(x, b[0], b[1], relu=True)
+            if self.downsample and FUSE_SHORTCUT:
+                # the 1x1 shortcut rides on the block's last convolution (one launch, no intermediate tensor) ...
+                out = ME.conv_bn_act(h, b[3], b[4], relu=True, shortcut=(x, self.downsample[0], self.downsample[1]))
+                if out is not None:
+                    return out
+            # ... unless the library does not serve the shape that way (small split-K launches, 4-GiB inputs)
+            res = ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False) if self.downsample else x
             return ME.conv_bn_act(h, b[3], b[4], relu=True, residual=res)
         out = self.block(x)
         if self.downsample:

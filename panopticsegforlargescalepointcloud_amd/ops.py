@@ -18,7 +18,7 @@ class LaunchProfiler:
     kernel is launched on (bench.py uses it for the roofline object; off by default)."""
 
     def __init__(self, reserve=0):
-        self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual)
+        self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
         # (bench.py: launches per step x steps, counted during the warm-up) so that a timed launch only pays the records
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * int(reserve))]
@@ -32,13 +32,15 @@ class LaunchProfiler:
     def summarize(self):
         torch.cuda.synchronize()
         tot_ms = tot_bytes = tot_flops = map_bytes = 0.0
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res) in self.records:
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c) in self.records:
             map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
             P = n_out if pairs is None else int(pairs.item())
-            # features read once + written once, weights once, one (in,out) int32 pair per map entry
+            # features read once + written once, weights once, one (in,out) int32 pair per map entry;
+            # a fused 1x1 shortcut (ds_c input channels) adds its input rows, its weights and its flops
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
+            b += 4.0 * n_out * ds_c + 4.0 * ds_c * cout
             tot_bytes += b
-            tot_flops += 2.0 * P * cin * cout
+            tot_flops += 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
             tot_ms += e0.elapsed_time(e1)
         return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes}
 
@@ -46,19 +48,20 @@ class LaunchProfiler:
         """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
         torch.cuda.synchronize()
         groups = {}
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res) in self.records:
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c) in self.records:
             P = n_out if pairs is None else int(pairs.item())
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
-            g = groups.setdefault((n_in, n_out, cin, cout, K, P), [0, 0.0, 0.0, 0.0])
+            b += 4.0 * n_out * ds_c + 4.0 * ds_c * cout
+            g = groups.setdefault((n_in, n_out, "%d+%d" % (cin, ds_c) if ds_c else cin, cout, K, P), [0, 0.0, 0.0, 0.0])
             g[0] += 1
             g[1] += e0.elapsed_time(e1)
             g[2] += b
-            g[3] += 2.0 * P * cin * cout
+            g[3] += 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
         lines = ["| rows in | rows out | Cin | Cout | K | pairs/row | launches/step | ms/step | us/launch | alg GB/s | alg TFLOP/s | "
                  "frac HBM | frac MFMA |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
         for (n_in, n_out, cin, cout, K, P), (cnt, ms, b, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
             sec = ms / 1e3
-            lines.append("| %d | %d | %d | %d | %d | %.2f | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f |" % (
+            lines.append("| %d | %d | %s | %d | %d | %.2f | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f |" % (
                 n_in, n_out, cin, cout, K, P / max(n_out, 1), cnt / steps, ms / steps, ms / cnt * 1e3, b / sec / 1e9,
                 fl / sec / 1e12, b / sec / hbm_peak, fl / sec / mfma_peak))
         return "\n".join(lines) + "\n"
@@ -433,10 +436,12 @@ _AB_T4 = tuple(int(v) for v in os.environ["PP_AB_T4"].split(",")) if os.environ.
 
 
 def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
-               row_order=None, bf16=False, variant=None):
+               row_order=None, bf16=False, variant=None, shortcut=None):
     """variant = (rows_per_wave, pipeline, split_k): an explicit variant of the pipelined kernel through
     pp_spconv_fwd_ex (tests / A-B runs); None = the library's per-shape choice.  row_order: slot order of a
-    cross-level map (nbr is slot-major then)."""
+    cross-level map (nbr is slot-major then).  shortcut = (x [n_out, c], packed 1x1 weights, scale, shift): the 1x1
+    shortcut of a residual block fused in (pp_spconv_fwd_shortcut); returns None when the library does not serve the
+    shape that way -- nothing has been launched then and the caller runs the shortcut as its own convolution."""
     lib = _lib.load()
     in0 = _need(in0, torch.float32, "in0")
     in1 = _need(in1, torch.float32, "in1")
@@ -463,7 +468,18 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         groups = (nt + 3) // 4
         ntw = (nt + groups - 1) // groups
         variant = (64 if (ntw <= _AB_T4[0] and n_out >= _AB_T4[1]) else 32, 0, 0)
-    if variant is not None:
+    if shortcut is not None:
+        xs, pks, scs, shs = shortcut
+        xs = _need(xs, torch.float32, "shortcut input")
+        rc = lib.pp_spconv_fwd_shortcut(*args[:14], _ptr(out), int(use_bf16 and xs.shape[1] % 16 == 0), _ptr(xs), xs.shape[1], _ptr(pks),
+                                        _ptr(_need(scs, torch.float32, "shortcut scale")), _ptr(_need(shs, torch.float32, "shortcut shift")),
+                                        _stream())
+        if rc == _lib.PP_UNSUPPORTED:
+            if prof is not None:
+                prof._pool.extend((e0, e1))  # nothing was launched: the events go back
+            return None
+        _lib.check(rc, "pp_spconv_fwd_shortcut")
+    elif variant is not None:
         rpw, pipe, split = variant
         _lib.check(lib.pp_spconv_fwd_ex(*args, int(use_bf16), int(rpw), int(pipe), int(split), _stream()), "pp_spconv_fwd_ex")
     else:
@@ -471,7 +487,8 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         _lib.check(fn(*args, _stream()), "pp_spconv_fwd")
     if prof is not None:
         e1.record()
-        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None))
+        prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None,
+                             shortcut[0].shape[1] if shortcut is not None else 0))
     return out
 
 

@@ -191,3 +191,25 @@ def test_region_growing_properties_on_a_full_batch(ops):
     # deterministic: the fixpoint does not depend on the order the atomics land in
     csr2, pc2 = ops.region_grow_csr(pos, pred, batch, ignore, 200, radius, 10, syn.NPM3D_NUM_CLASSES)
     assert torch.equal(pc2, pc) and torch.equal(csr2.points, pts) and torch.equal(csr2.offsets, csr.offsets)
+
+
+@pytest.mark.parametrize("c,ds_c,bf16", [(16, 64, False), (32, 96, False), (64, 32, False), (48, 128, False), (32, 64, True)])
+def test_fused_shortcut_equals_two_launches(ops, level, c, ds_c, bf16):
+    """the 1x1 shortcut of a residual block fused into the block's last convolution (pp_spconv_fwd_shortcut) is bit-identical
+    to the separate 1x1 convolution + residual add it replaces; small launches (split-K) are not served (None, nothing run)"""
+    nbr, n = level["nbr"], level["n"]
+    g = torch.Generator(device="cuda").manual_seed(c + ds_c)
+    h = torch.randn((n, c), device="cuda", generator=g)
+    x = torch.randn((n, ds_c), device="cuda", generator=g)
+    pk = ops.pack_weight(torch.randn((27, c, c), device="cuda", generator=g) * 0.05)
+    pk1 = ops.pack_weight(torch.randn((ds_c, c), device="cuda", generator=g) * 0.1)
+    sc, sh = torch.rand(c, device="cuda", generator=g) + 0.5, torch.randn(c, device="cuda", generator=g)
+    sc1, sh1 = torch.rand(c, device="cuda", generator=g) + 0.5, torch.randn(c, device="cuda", generator=g)
+    res = ops.spconv_fwd(x, pk1, None, n, c, 1, scale=sc1, shift=sh1, relu=False, bf16=bf16)
+    want = ops.spconv_fwd(h, pk, nbr, n, c, 27, scale=sc, shift=sh, relu=True, residual=res, bf16=bf16)
+    got = ops.spconv_fwd(h, pk, nbr, n, c, 27, scale=sc, shift=sh, relu=True, bf16=bf16, shortcut=(x, pk1, sc1, sh1))
+    assert got is not None and torch.equal(got, want)
+    m = 3000                                                            # a launch this small is split over the offsets
+    small = ops.spconv_fwd(h[:m].contiguous(), pk, nbr[:, :m].clamp(max=m - 1).contiguous(), m, c, 27, scale=sc, shift=sh, relu=True,
+                           shortcut=(x[:m].contiguous(), pk1, sc1, sh1))
+    assert small is None
