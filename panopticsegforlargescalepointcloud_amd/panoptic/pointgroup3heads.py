@@ -169,8 +169,7 @@ class PointGroup3heads(nn.Module):
         return csr
 
     def _embed_clusters(self, pred, emb):
-        ignore = self._stuff_classes.to(pred.device)
-        label_mask = ~torch.isin(pred, ignore)
+        label_mask = ops.not_ignored(pred, self._stuff_classes, self.num_classes)
         local_ind = torch.nonzero(label_mask).view(-1)
         return meanshift_cluster.cluster_single_csr(emb[label_mask], self.input.batch[label_mask], local_ind,
                                                     self.opt.bandwidth)
