@@ -280,6 +280,23 @@ int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_
 int pp_head_mlp(const float* x, int64_t n, int32_t cin, const float* w1, int32_t chid, const float* scale,
                 const float* shift, const float* w2, const float* b2, int32_t cout, int32_t log_softmax,
                 float* y, int64_t* argmax /*may be NULL*/, pp_stream_t stream);
+/* All heads of the model in one pass: x [n_src, c] is read once per output row, index (nullable int64 [n]) names the input
+ * row of output row i -- the backbone's features can stay in the coordinate manager's internal row order and the heads
+ * deliver their outputs in the caller's.  Per head the arithmetic of pp_head_mlp (bit-identical).  c == 16 (hidden width ==
+ * c), 1 to 3 heads; err_flag (device int32) counts index entries outside [0, n_src). */
+typedef struct pp_head_t {
+  const float* w1;    /* [c, c]    Linear without bias */
+  const float* scale; /* [c]       folded BatchNorm */
+  const float* shift; /* [c] */
+  const float* w2;    /* [cout, c] */
+  const float* b2;    /* [cout] or NULL */
+  float* y;           /* [n, cout] */
+  int64_t* argmax;    /* [n] or NULL */
+  int32_t cout;
+  int32_t log_softmax;
+} pp_head_t;
+int pp_heads(const float* x, int64_t n_src, int32_t c, const int64_t* index, int64_t n, const pp_head_t* heads,
+             int32_t n_heads, int32_t* err_flag, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8+K9 region growing            replaces: torch_points_kernels.region_grow (ball_query PARTIAL_DENSE +

@@ -371,12 +371,24 @@ class GatheredRows:
     duplicated backbone rows this way (PointGroup3heads._compute_score)."""
 
     def __init__(self, base, index):
+        if isinstance(base, GatheredRows):  # rows of rows: one index
+            base, index = base.base, base.index[index]
         self.base, self.index = base, index
         self.shape = (index.shape[0], base.shape[1])
         self.device = base.device
 
     def to(self, *args, **kwargs):
         return self
+
+    # (the few tensor operations consumers outside the hot path use: they gather first)
+    def cpu(self):
+        return self.materialise().cpu()
+
+    def contiguous(self):
+        return self.materialise()
+
+    def __getitem__(self, idx):
+        return self.materialise()[idx] if not torch.is_tensor(idx) or idx.dtype != torch.int64 else GatheredRows(self, idx).materialise()
 
     def materialise(self, perm=None):
         index = self.index if perm is None else self.index[perm]

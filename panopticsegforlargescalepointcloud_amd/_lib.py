@@ -77,6 +77,7 @@ SIGNATURES = {
     "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "pp_bn_train_bwd": (C.c_int, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "pp_heads": (C.c_int, [vp, i64, i32, vp, i64, vp, i32, vp, vp]),
     "pp_region_grow_workspace": (sz, [i64, i32]),
     "pp_region_grow_workspace_for": (sz, [i64, i64, i32]),
     "pp_region_grow": (C.c_int, [vp, vp, vp, i64, vp, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
@@ -102,6 +103,11 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+class HeadDesc(C.Structure):  # pp_head_t of include/panoptic_hip.h
+    _fields_ = [("w1", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("y", C.c_void_p), ("argmax", C.c_void_p), ("cout", C.c_int32), ("log_softmax", C.c_int32)]
 
 
 class PanopticHipError(RuntimeError):

@@ -3,6 +3,8 @@
 // References: ME.MinkowskiBatchNorm (= BatchNorm1d on F) torch_points3d/modules/MinkowskiEngine/api_modules.py:40;
 // heads torch_points3d/models/panoptic/PointGroup3heads.py:69-81,106-108 and
 // torch_points3d/core/common_modules/base_modules.py:35-45; torch_scatter.scatter PointGroup3heads.py:419-452.
+#include <string.h>
+
 #include "pp_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -510,6 +512,121 @@ extern "C" int pp_head_mlp(const float* x, int64_t n, int32_t cin, const float* 
     pp_set_error("pp_head_mlp: unsupported (cin,chid)=(%d,%d); built for (16,16) and (32,32)", cin, chid);
     return PP_ERR_INVALID;
   }
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// All heads of the model in one pass over the features: the row is read once (optionally through a row index: the
+// backbone's output stays in the coordinate manager's internal order and index[i] names the row of caller point i, so the
+// un-permuting gather of the features disappears too), every head's two small matrices come from LDS.
+// Same arithmetic per head as k_head_mlp (same summation order: bit-identical outputs).
+// ---------------------------------------------------------------------------------------------
+#define HEADS_MAX 3
+struct HeadDesc {  // device pointers of one head (pp_head_t in the public header)
+  const float* w1;
+  const float* scale;
+  const float* shift;
+  const float* w2;
+  const float* b2;
+  float* y;
+  int64_t* argmax;
+  int32_t cout;
+  int32_t log_softmax;
+};
+struct HeadSet {
+  HeadDesc h[HEADS_MAX];
+};
+template <int C, int COUT_MAX>
+__global__ __launch_bounds__(256) void k_heads(const float* __restrict__ x, const int64_t* __restrict__ index, int64_t n,
+                                               int64_t n_src, int n_heads, HeadSet hs, int32_t* __restrict__ err) {
+  __shared__ float sw1[HEADS_MAX][C * C];
+  __shared__ float sw2[HEADS_MAX][COUT_MAX * C];
+  __shared__ float ssc[HEADS_MAX][C], ssh[HEADS_MAX][C], sb2[HEADS_MAX][COUT_MAX];
+  for (int hh = 0; hh < n_heads; ++hh) {
+    const HeadDesc& d = hs.h[hh];
+    for (int t = threadIdx.x; t < C * C; t += blockDim.x) sw1[hh][t] = d.w1[t];
+    for (int t = threadIdx.x; t < COUT_MAX * C; t += blockDim.x) sw2[hh][t] = t < d.cout * C ? d.w2[t] : 0.f;
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+      ssc[hh][t] = d.scale[t];
+      ssh[hh][t] = d.shift[t];
+    }
+    for (int t = threadIdx.x; t < COUT_MAX; t += blockDim.x) sb2[hh][t] = (d.b2 && t < d.cout) ? d.b2[t] : 0.f;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t r = index ? index[i] : i;
+  if (r < 0 || r >= n_src) {
+    atomicAdd(err, 1);
+    r = 0;
+  }
+  float xi[C];
+#pragma unroll
+  for (int u = 0; u < C / 4; ++u) {
+    const float4 v = *(const float4*)(x + r * C + 4 * u);
+    xi[4 * u] = v.x; xi[4 * u + 1] = v.y; xi[4 * u + 2] = v.z; xi[4 * u + 3] = v.w;
+  }
+#pragma unroll
+  for (int hh = 0; hh < HEADS_MAX; ++hh) {
+    if (hh >= n_heads) break;
+    const HeadDesc& d = hs.h[hh];
+    float h[C];
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < C; ++b) s += sw1[hh][a * C + b] * xi[b];
+      s = s * ssc[hh][a] + ssh[hh][a];
+      h[a] = s < 0.f ? 0.2f * s : s;
+    }
+    float o[COUT_MAX];
+#pragma unroll
+    for (int a = 0; a < COUT_MAX; ++a) {
+      float s = sb2[hh][a];
+#pragma unroll
+      for (int b = 0; b < C; ++b) s += sw2[hh][a * C + b] * h[b];
+      o[a] = s;
+    }
+    const int cout = d.cout;
+    int best = 0;
+    float bv = o[0];
+#pragma unroll
+    for (int a = 1; a < COUT_MAX; ++a)
+      if (a < cout && o[a] > bv) {
+        bv = o[a];
+        best = a;
+      }
+    if (d.log_softmax) {
+      float se = 0.f;
+#pragma unroll
+      for (int a = 0; a < COUT_MAX; ++a)
+        if (a < cout) se += expf(o[a] - bv);
+      const float lse = bv + logf(se);
+#pragma unroll
+      for (int a = 0; a < COUT_MAX; ++a) o[a] -= lse;
+    }
+#pragma unroll
+    for (int a = 0; a < COUT_MAX; ++a)
+      if (a < cout) d.y[i * cout + a] = o[a];
+    if (d.argmax) d.argmax[i] = best;
+  }
+}
+
+extern "C" int pp_heads(const float* x, int64_t n_src, int32_t c, const int64_t* index, int64_t n, const pp_head_t* heads,
+                        int32_t n_heads, int32_t* err_flag, pp_stream_t stream) {
+  PP_REQUIRE(n == 0 || (x && heads && err_flag), "pp_heads: null pointer");
+  PP_REQUIRE(n_heads >= 1 && n_heads <= HEADS_MAX, "pp_heads: 1 to 3 heads");
+  PP_REQUIRE(c == 16, "pp_heads: built for 16 feature channels (hidden width = channels)");
+  static_assert(sizeof(pp_head_t) == sizeof(HeadDesc), "pp_head_t layout");
+  if (n == 0) return PP_OK;
+  HeadSet hs;
+  for (int hh = 0; hh < n_heads; ++hh) {
+    PP_REQUIRE(heads[hh].w1 && heads[hh].scale && heads[hh].shift && heads[hh].w2 && heads[hh].y, "pp_heads: null head tensor");
+    PP_REQUIRE(heads[hh].cout >= 1 && heads[hh].cout <= 16, "pp_heads: cout must be in [1,16]");
+    memcpy(&hs.h[hh], &heads[hh], sizeof(HeadDesc));
+  }
+  hipLaunchKernelGGL((k_heads<16, 16>), dim3(pp_blocks(n, 256)), dim3(256), 0, pp_s(stream), x, index, n, n_src, n_heads, hs, err_flag);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

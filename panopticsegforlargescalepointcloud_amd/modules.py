@@ -53,6 +53,19 @@ def MLP(channels, activation=None, bn_momentum=0.1, bias=True):
     ])
 
 
+def head_spec(head, log_softmax=False, want_argmax=False):
+    """tensors of a head  Seq[ MLP([c, c], bias=False), Linear(c, k) (, LogSoftmax) ]  for ops.heads (eval mode)"""
+    lin1, fbn = head[0][0][0], head[0][0][1]
+    lin2 = head[1]
+    bn = fbn.batch_norm
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+        if lin1.bias is not None:
+            shift = shift + lin1.bias * scale
+    return (lin1.weight, scale.contiguous(), shift.contiguous(), lin2.weight, lin2.bias, log_softmax, want_argmax)
+
+
 def fused_head(head, x, log_softmax=False, want_argmax=False):
     """Eval-mode fused launch of a head  Seq[ MLP([c, c], bias=False), Linear(c, k) (, LogSoftmax) ]
     (PointGroup3heads.py:69-81).  Falls back to the torch modules in training mode (autograd)."""

@@ -587,6 +587,37 @@ def head_mlp(x, w1, scale, shift, w2, b2, log_softmax=False, want_argmax=False):
     return (y, am) if want_argmax else y
 
 
+def heads(x, specs, index=None):
+    """All heads of the model in ONE pass over the features (csrc/pp_dense.hip, k_heads).  specs: up to three tuples
+    (w1, scale, shift, w2, b2, log_softmax, want_argmax); index (int64 [n], optional): output row i reads x[index[i]] --
+    the backbone's features may stay in the coordinate manager's internal order.  Returns [(y, argmax or None), ...]."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    index = _need(index, torch.int64, "index")
+    n = x.shape[0] if index is None else index.shape[0]
+    dev = x.device
+    flag = _GATHER_ERR.get(dev)
+    if flag is None:
+        flag = _GATHER_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    arr = (_lib.HeadDesc * len(specs))()
+    outs, keep = [], []
+    for d, (w1, scale, shift, w2, b2, log_softmax, want_argmax) in zip(arr, specs):
+        w1, scale, shift, w2 = (_need(t, torch.float32, "head tensor") for t in (w1, scale, shift, w2))
+        b2 = _need(b2, torch.float32, "b2")
+        cout = w2.shape[0]
+        y = torch.empty((n, cout), dtype=torch.float32, device=dev)
+        am = torch.empty(n, dtype=torch.int64, device=dev) if want_argmax else None
+        d.w1, d.scale, d.shift, d.w2 = w1.data_ptr(), scale.data_ptr(), shift.data_ptr(), w2.data_ptr()
+        d.b2 = None if b2 is None else b2.data_ptr()
+        d.y, d.argmax = y.data_ptr(), (None if am is None else am.data_ptr())
+        d.cout, d.log_softmax = cout, int(bool(log_softmax))
+        outs.append((y, am))
+        keep.append((w1, scale, shift, w2, b2))
+    _lib.check(lib.pp_heads(_ptr(x), x.shape[0], x.shape[1], _ptr(index), n, C.cast(arr, C.c_void_p), len(specs), _ptr(flag),
+                            _stream()), "pp_heads")
+    return outs
+
+
 # ------------------------------------------------------------------------------------------ clustering
 class ClusterCSR:
     """Proposals as CSR: offsets int32 [n+1] (device), points int64 [total] (device)."""

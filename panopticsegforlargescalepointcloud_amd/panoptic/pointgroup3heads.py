@@ -20,7 +20,7 @@ from torch import nn
 from .. import MinkowskiEngine as ME
 from .. import ops
 from ..applications import Data, Minkowski
-from ..modules import MLP, Seq, fused_head
+from ..modules import MLP, Seq, fused_head, head_spec
 from ..torch_points_kernels import region_grow_csr
 from ..torch_scatter import gather, scatter
 from ..utils import meanshift_cluster
@@ -29,6 +29,7 @@ from .structures import PanopticLabels, PanopticResults
 
 IGNORE_LABEL = -1  # torch_points3d/datasets/segmentation/__init__.py
 MAX_SCORER_BATCH = 60000  # proposals per ScorerUnet launch (batch index must fit the 16-bit key field)
+FUSE_HEADS = os.environ.get("PP_FUSE_HEADS", "1") != "0"  # all heads in one pass over the un-permuted features
 OVERLAP_CLUSTERING = os.environ.get("PP_CLUSTER_OVERLAP", "1") != "0"  # mean shift on a side stream next to region growing
 
 
@@ -113,8 +114,23 @@ class PointGroup3heads(nn.Module):
     def backbone_and_heads(self):
         """Sparse U-Net + the three heads.  Returns (features [N,16], semantic log-probs, offsets, embeddings,
         predicted labels [N] int64)."""
-        feats = self.Backbone(self.input).x
         has_off, has_emb = "Offset" in self.HEADS, "Embed" in self.HEADS
+        if not self.training and not torch.is_grad_enabled() and self.Backbone.output_nc == 16 and FUSE_HEADS:
+            # inference: the backbone's features stay in the coordinate manager's row order and ALL heads run as one pass
+            # that reads row inv_perm[i] for point i -- no un-permuting gather of the features, one read of them instead of
+            # three; `feats` is handed on as "rows inv_perm of the internal matrix" (the scorer composes it with its own
+            # proposal gather)
+            out = self.Backbone(self.input, internal_order=True)
+            cm = self.Backbone.input.coordinate_manager
+            specs = [head_spec(self.Semantic, True, True)] + ([head_spec(self.Offset)] if has_off else []) \
+                + ([head_spec(self.Embed)] if has_emb else [])
+            res = ops.heads(out.x, specs, index=cm.inv_perm)
+            (sem, pred) = res[0]
+            off = res[1][0] if has_off else None
+            emb = res[1 + int(has_off)][0] if has_emb else None
+            feats = out.x if cm.inv_perm is None else ME.GatheredRows(out.x, cm.inv_perm)
+            return feats, sem, off, emb, pred
+        feats = self.Backbone(self.input).x
         if not self.training and not torch.is_grad_enabled():
             sem, pred = fused_head(self.Semantic, feats, log_softmax=True, want_argmax=True)
             off = fused_head(self.Offset, feats) if has_off else None

@@ -55,3 +55,32 @@ for q, v in sorted(by_q.items(), key=lambda kv: -len(kv[1])):
         print("  largest idle gaps (after -> before):")
         for (a, b), (c, g) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:18]:
             print("   %7.2f ms/step %6.1f x/step  %s -> %s" % (g / steps / 1e6, c / steps, a, b))
+
+# the main stream's individual gaps > 50 us in the last step: what ran before / after and what the other streams finished
+# just before the gap closed (the item the main stream was waiting for)
+main = [r for r in by_q[conv_q] if r[0] >= t1 - ms * 1e6]
+others = [r for q, v in by_q.items() if q != conv_q for r in v]
+print("\nmain-stream gaps > 50 us in the last step (start offset ms, gap us, after -> before, last other-stream kernel ending inside the gap):")
+prev = main[0]
+hist = defaultdict(int)
+for r in main[1:]:
+    g = r[0] - prev[1]
+    if g > 5e3:
+        hist[min(int(g / 1e3).bit_length(), 12)] += 1
+    if g > 50e3:
+        inside = [o for o in others if prev[1] <= o[1] <= r[0] + 20e3]
+        last = max(inside, key=lambda o: o[1]) if inside else None
+        print("  %8.2f %7.0f  %s -> %s   | %s" % ((prev[1] - (t1 - ms * 1e6)) / 1e6, g / 1e3, family(prev[2]), family(r[2]),
+                                                 ("%s (+%.0f us before the gap closed)" % (family(last[2]), (r[0] - last[1]) / 1e3)) if last else "-"))
+    if r[1] > prev[1]:
+        prev = r
+print("gap histogram (us, power-of-two buckets):", {("<%d" % (1 << k)): v for k, v in sorted(hist.items())})
+
+# optional: chronological listing of all streams for windows of the last step:  ... <db> <steps> <ms> a0:a1 [b0:b1 ...]  (ms)
+for w in sys.argv[4:]:
+    a, b = (float(v) for v in w.split(":"))
+    base = t1 - ms * 1e6
+    print("\nlast step, %.1f .. %.1f ms: (start, duration us, stream, kernel)" % (a, b))
+    for s, e, n, _, q in win:
+        if base + a * 1e6 <= s <= base + b * 1e6:
+            print("  %8.3f %7.0f  s%s%s %s" % ((s - base) / 1e6, (e - s) / 1e3, q, "*" if q == conv_q else " ", n[:90]))

@@ -323,6 +323,25 @@ def test_bn_pieces_and_heads(ops, oracle):
         got, am = ops.head_mlp(dev(x), dev(w1), dev(sc), dev(sh), dev(w2), dev(b2), log_softmax=ls, want_argmax=True)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         assert (am.cpu().numpy() != wam).mean() < 1e-3  # argmax may flip only on float ties
+    # all heads in one pass (pp_heads), with and without a row index: bit-identical to the one-head launches
+    hs = []
+    for cout, ls, am in [(9, True, True), (3, False, False), (5, False, False)]:
+        hs.append((dev(w1 * (1 + cout)), dev(sc), dev(sh), dev(rng.normal(size=(cout, 16)).astype(np.float32) * 0.3),
+                   dev(rng.normal(size=cout).astype(np.float32)) if cout != 5 else None, ls, am))
+    index = dev(rng.permutation(3000)[:2500].astype(np.int64))
+    for idx in [None, index]:
+        xs = dev(x) if idx is None else dev(x)[idx]
+        for k in (1, 2, 3):
+            res = ops.heads(dev(x), hs[:k], index=idx)
+            for (y, a), h in zip(res, hs[:k]):
+                wy, wa = ops.head_mlp(xs.contiguous(), *h[:5], log_softmax=h[5], want_argmax=True)
+                assert torch.equal(y, wy)
+                assert (a is None) == (not h[6]) and (a is None or torch.equal(a, wa))
+    ops.gather_rows_check()
+    ops.heads(dev(x), hs[:1], index=dev(np.array([0, 3000], np.int64)))
+    with pytest.raises(Exception, match="out of range"):
+        ops.gather_rows_check()
+    assert ops.heads(dev(x[:0]), hs[:2])[1][0].shape == (0, 3)
 
 
 # ------------------------------------------------------------------ region growing
