@@ -214,7 +214,7 @@ __global__ __launch_bounds__(128) void k_ball_query(const float4* __restrict__ s
 
 // Main ball query: one workgroup per occupied cell.
 //   1. the local indices of the same-(batch,class) points of the 27 neighbouring cells are staged in LDS as 27 ascending
-//      runs (48-bit keys: index | run | slot in the run);
+//      runs (50-bit keys: index | run | slot in the run);
 //   2. a tree of pairwise merges (5 levels; every key finds its place with ONE binary search in the sibling run) sorts them
 //      by index;
 //   3. the candidates (x, y, z, position in the cell-sorted order) are gathered into LDS in that order (over the key
@@ -225,9 +225,14 @@ __global__ __launch_bounds__(128) void k_ball_query(const float4* __restrict__ s
 //      early, list writes are coalesced.
 // (The earlier form ranked every candidate against all 26 other runs and walked the list with a query per lane: a median
 // cell holds 5 queries, so 7 % of the lanes had work in the walk.)
-#ifndef BQC_CAP
+// Two instances: CAP = 1536 candidates (24 KiB of LDS, 6 workgroups per CU) serves every cell and lists the cells with more
+// candidates; CAP = 8192 (128 KiB of dynamic LDS, one workgroup per CU) then serves those -- on shifted coordinates the
+// points of an object collapse into a few cells with thousands of candidates and hundreds of queries each, and the
+// per-query kernel pays a full scan plus a bisection over all hits for every one of them where this walk stops after
+// nsample hits.
 #define BQC_CAP 1536
-#endif
+#define BQC_CAP_BIG 8192
+template <int CAP, bool BIG>
 __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                           const uint64_t* __restrict__ keys,
                                                           const int32_t* __restrict__ cell_start,
@@ -235,17 +240,25 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
                                                           float radius, int nsample,
                                                           const int32_t* __restrict__ cell_p0,
                                                           const int32_t* __restrict__ n_cells, int32_t* __restrict__ list,
-                                                          int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count) {
-  __shared__ unsigned long long kbuf[2][BQC_CAP];  // merge ping-pong; the sorted candidates (float4) overlay both
+                                                          int32_t* __restrict__ deg, int32_t* fb_list, int32_t* fb_count,
+                                                          int32_t* big_list, int32_t* big_count) {
+  // merge ping-pong; the sorted candidates (float4) overlay both halves
+  extern __shared__ unsigned long long kdyn[];
+  __shared__ unsigned long long kstat[BIG ? 1 : 2 * CAP];
+  unsigned long long* const kbuf0 = BIG ? kdyn : kstat;
+  unsigned long long* const kbuf1 = kbuf0 + CAP;
   __shared__ int nb_start[27], nb_cnt[27], nb_off[28];
   __shared__ int n_bad;
-  float4* cand = (float4*)&kbuf[0][0];
-  static_assert(sizeof(kbuf) >= BQC_CAP * sizeof(float4), "candidate overlay");
+  float4* cand = (float4*)kbuf0;
+  constexpr int SLOT_BITS = 13, IDX_SHIFT = SLOT_BITS + 5;  // key = index | run (5 bits) | slot in the run
+  static_assert(CAP <= (1 << SLOT_BITS), "slot bits");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float r2 = radius * radius;
   const int ncell = n_cells[0];
-  constexpr int PER = (BQC_CAP + 255) / 256;
-  for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
+  const int nwork = BIG ? big_count[0] : ncell;
+  constexpr int PER = (CAP + 255) / 256;
+  for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const int c = BIG ? big_list[w] : w;
     const int p0 = cell_p0[c], p1 = c + 1 < ncell ? cell_p0[c + 1] : (int)M;
     const float4 q0 = spos[p0];
     const int bc0 = sbc[p0];
@@ -273,7 +286,11 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
     }
     __syncthreads();
     const int total = nb_off[27];
-    bool fallback = total > BQC_CAP;  // too many candidates for the buffer
+    if (!BIG && total > CAP) {  // too many candidates for this instance's buffer: the large one takes the cell
+      if (tid == 0) big_list[atomicAdd(big_count, 1)] = c;
+      continue;
+    }
+    bool fallback = total > CAP;
     if (!fallback) {
       int bad = 0;
       for (int f = tid; f < total; f += 256) {
@@ -284,8 +301,8 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
         }
         const int slot = f - nb_off[lo];
         const int src = nb_start[lo] + slot;
-        kbuf[0][f] = ((unsigned long long)(unsigned)__float_as_int(spos[src].w) << 16) | ((unsigned long long)lo << 11) |
-                     (unsigned long long)slot;
+        kbuf0[f] = ((unsigned long long)(unsigned)__float_as_int(spos[src].w) << IDX_SHIFT) |
+                   ((unsigned long long)lo << SLOT_BITS) | (unsigned long long)slot;
         bad += sbc[src] != bc0 ? 1 : 0;  // another (batch, class) behind an aliased cell key
       }
       if (bad) atomicAdd(&n_bad, bad);
@@ -299,11 +316,11 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
     // merge tree: at level l the runs are the groups of 2^l original runs; run i and run i ^ 1 merge
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
-      const unsigned long long* src = kbuf[l & 1];
-      unsigned long long* dst = kbuf[(l + 1) & 1];
+      const unsigned long long* src = (l & 1) ? kbuf1 : kbuf0;
+      unsigned long long* dst = (l & 1) ? kbuf0 : kbuf1;
       for (int f = tid; f < total; f += 256) {
         const unsigned long long key = src[f];
-        const int i = (int)((key >> 11) & 31u) >> l;
+        const int i = (int)((key >> SLOT_BITS) & 31u) >> l;
         const int a0 = nb_off[min(i << l, 27)];
         const int sib = i ^ 1;
         const int b0 = nb_off[min(sib << l, 27)], b1 = nb_off[min((sib + 1) << l, 27)];
@@ -316,14 +333,14 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
       }
       __syncthreads();
     }
-    {  // sorted keys are in kbuf[1]; gather the candidates through registers, then overlay
+    {  // sorted keys are in the second buffer; gather the candidates through registers, then overlay
       float4 pc[PER];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = tid + 256 * u;
         if (f < total) {
-          const unsigned long long key = kbuf[1][f];
-          const int src = nb_start[(int)((key >> 11) & 31u)] + (int)(key & 2047u);
+          const unsigned long long key = kbuf1[f];
+          const int src = nb_start[(int)((key >> SLOT_BITS) & 31u)] + (int)(key & ((1u << SLOT_BITS) - 1u));
           pc[u] = spos[src];
           pc[u].w = __int_as_float(src);  // the walk needs the position, not the index: the order carries it
         }
@@ -519,18 +536,30 @@ static inline int bits_for(int64_t v) {
 // group-by-key
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gbk_keys(const int32_t* __restrict__ key, int64_t n, int n_groups,
-                                                  uint32_t* ukey, int32_t* hist, int32_t* err) {
+                                                  uint32_t* ukey, int32_t* err) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t k = -1;
+  bool bad = false;
   if (i < n) {
-    k = key[i];
-    if (k >= n_groups) {
-      atomicAdd(err, 1);
-      k = -1;
-    }
-    ukey[i] = k < 0 ? (uint32_t)n_groups : (uint32_t)k;
+    int32_t k = key[i];
+    bad = k >= n_groups;
+    ukey[i] = (k < 0 || bad) ? (uint32_t)n_groups : (uint32_t)k;
   }
-  rg_hist_add_runs(hist, k, k >= 0);
+  const unsigned long long m = __ballot(bad);
+  if (m && (threadIdx.x & 63) == 0) atomicAdd(err, __popcll(m));
+}
+// offsets from the SORTED keys: offsets[g] = number of keys below g, one binary search per group (dropped keys carry
+// n_groups and sort last, so offsets[n_groups] = number of kept elements).  No histogram: one atomic per run of equal
+// keys still serialised on the few hot addresses of large clusters (0.72 ms for 6 M points of the bench scene).
+__global__ __launch_bounds__(256) void k_gbk_bounds(const uint32_t* __restrict__ sorted, int64_t n, int n_groups,
+                                                    int32_t* __restrict__ offsets) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n_groups) return;
+  int64_t lo = 0, hi = n;  // first position with a key >= g
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < (uint32_t)g) lo = mid + 1; else hi = mid;
+  }
+  offsets[g] = (int32_t)lo;
 }
 __global__ __launch_bounds__(256) void k_gbk_emit(const int32_t* __restrict__ sorted_idx, const int64_t* __restrict__ ids,
                                                   const int32_t* __restrict__ total, int64_t n, int64_t* out) {
@@ -558,19 +587,17 @@ extern "C" int pp_group_by_key(const int32_t* key, const int64_t* ids, int64_t n
   uint32_t* ukey2 = ar.take<uint32_t>(m);
   int32_t* idx = ar.take<int32_t>(m);
   int32_t* idx2 = ar.take<int32_t>(m);
-  int32_t* hist = ar.take<int32_t>((size_t)n_groups + 2);
-  PP_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * ((size_t)n_groups + 2), s));
-  int32_t* err = hist + n_groups + 1;
+  int32_t* err = ar.take<int32_t>(1);
+  PP_HIP(hipMemsetAsync(err, 0, sizeof(int32_t), s));
   if (n > 0) {
-    hipLaunchKernelGGL(k_gbk_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, key, n, n_groups, ukey, hist, err);
+    hipLaunchKernelGGL(k_gbk_keys, dim3(pp_blocks(n, 256)), dim3(256), 0, s, key, n, n_groups, ukey, err);
     hipLaunchKernelGGL(k_iota, dim3(pp_blocks(n, 256)), dim3(256), 0, s, idx, n);
     PP_LAUNCH_CHECK();
     int rc = pp_sort_pairs_u32(ukey, ukey2, idx, idx2, n, bits_for(n_groups), ar.cur(), ar.left(), s);
     if (rc) return rc;
   }
-  // offsets[g] = exclusive scan of hist (n_groups+1 entries, the last is 0 -> offsets[n_groups] = total)
-  int rc = pp_exclusive_scan_i32(hist, offsets, (int64_t)n_groups + 1, nullptr, ar.cur(), ar.left(), s);
-  if (rc) return rc;
+  hipLaunchKernelGGL(k_gbk_bounds, dim3(pp_blocks((int64_t)n_groups + 1, 256)), dim3(256), 0, s, ukey2, n, n_groups, offsets);
+  PP_LAUNCH_CHECK();
   PP_HIP(hipMemcpyAsync(total, offsets + n_groups, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   // keys >= n_groups are dropped like negative ones, but they are a caller error: report their number
   if (n_out_of_range) PP_HIP(hipMemcpyAsync(n_out_of_range, err, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -683,8 +710,19 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
   int32_t* Lp = flag;      // labels by cell-sorted position (flag / rank are free from here on)
   int32_t* pos_of = rank;  // cell-sorted position of a local index
   hipLaunchKernelGGL(k_rg_init_labels, dim3(mb), dim3(256), 0, s, spos, M, Lp, pos_of, pushed);
-  hipLaunchKernelGGL(k_ball_query_cells, dim3((unsigned)std::min<int64_t>(M, 8192)), dim3(256), 0, s, spos, sbc, ckeys,
-                     cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg, fb_list, misc + 5);
+  int32_t* big_list = (int32_t*)rkey;  // free until the root keys below
+  hipLaunchKernelGGL((k_ball_query_cells<BQC_CAP, false>), dim3((unsigned)std::min<int64_t>(M, 8192)), dim3(256), 0, s, spos,
+                     sbc, ckeys, cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg, fb_list,
+                     misc + 5, big_list, misc + 6);
+  {
+    constexpr size_t big_lds = 2 * (size_t)BQC_CAP_BIG * sizeof(unsigned long long);
+    // > 64 KiB of LDS per workgroup has to be asked for (per device; a host-side call)
+    PP_HIP(hipFuncSetAttribute((const void*)k_ball_query_cells<BQC_CAP_BIG, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)big_lds));
+    hipLaunchKernelGGL((k_ball_query_cells<BQC_CAP_BIG, true>), dim3((unsigned)std::min<int64_t>(M, 1024)), dim3(256), big_lds,
+                       s, spos, sbc, ckeys, cell_start, cell_end, cap, M, radius, nsample, cell_p0, misc + 4, list, deg,
+                       fb_list, misc + 5, big_list, misc + 6);
+  }
   hipLaunchKernelGGL(k_ball_query, dim3((unsigned)std::min<int64_t>(pp_blocks(M, 2), 4096)), dim3(128), 0, s, spos, sbc,
                      ckeys, cell_start, cell_end, cap, M, radius, nsample, fb_list, misc + 5, list, deg);
   PP_LAUNCH_CHECK();

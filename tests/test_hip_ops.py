@@ -369,17 +369,20 @@ def test_region_grow_bit_exact(ops, oracle, nsample, sigma):
 
 
 def test_region_grow_pileup_overflows_lds_buffer(ops, oracle):
-    """> 4096 hits per query exercises the global re-scan selection path (blob 1), 2600 hits the LDS bisection (blob 2)."""
+    """dense pile-ups: 2600 and 5000 candidates per cell go to the large-buffer instance of the cell kernel (1536 < n <= 8192),
+    9000 to the per-query kernel's global re-scan selection (> 4096 hits per query; its LDS bisection is exercised by the
+    aliased cells below)."""
     rng = np.random.default_rng(9)
-    n = 7600
+    n = 16600
     pos = rng.normal(0, 0.01, size=(n, 3)).astype(np.float32)
-    pos[5000:] += 5.0
+    pos[5000:7600] += 5.0
+    pos[7600:] += 10.0
     labels = np.ones(n, np.int64)
     batch = np.zeros(n, np.int64)
     want, _ = oracle.region_grow(pos, labels, batch, [], nsample=200, radius=0.2, min_cluster_size=10)
     csr, _ = ops.region_grow_csr(dev(pos), dev(labels), dev(batch), torch.zeros(0, dtype=torch.int64), 200, 0.2, 10, 2)
     got = [c.cpu().numpy() for c in csr.to_list()]
-    assert len(got) == len(want) == 2
+    assert len(got) == len(want) == 3
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
 
