@@ -409,11 +409,29 @@ __global__ __launch_bounds__(256) void k_rg_init_labels(const float4* __restrict
   pos_of[a] = (int32_t)p;
   pushed[p] = 0x7FFFFFFF;  // ... and has told nobody yet
 }
-// back to local-index space for the cluster bookkeeping
+// histogram add with one atomic per run of equal keys inside a wave (cell-sorted points carry long runs of the same
+// cluster id; one atomic per element on a few hot addresses serialises in L2)
+__device__ __forceinline__ void rg_hist_add_runs(int32_t* hist, int k, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const int kk = valid ? k : -1;
+  const int prev = __shfl_up(kk, 1);
+  const bool lead = lane == 0 || prev != kk;
+  const unsigned long long lm = __ballot(lead);
+  if (lead && kk >= 0) {
+    const unsigned long long higher = lane < 63 ? (lm >> (lane + 1)) : 0ull;
+    const int next = higher ? lane + 1 + __builtin_ctzll(higher) : 64;
+    atomicAdd(&hist[kk], next - lane);  // lanes past the end of the data carry kk = -1 and start their own run
+  }
+}
+
+// back to local-index space for the cluster bookkeeping, and the cluster sizes (points per root label): counted in the
+// cell-sorted order, where the points of a cell -- mostly one cluster -- are consecutive, so the runs are long
 __global__ __launch_bounds__(256) void k_rg_labels_by_index(const float4* __restrict__ spos, const int32_t* __restrict__ Lp, int64_t M,
-                                                            int32_t* L) {
+                                                            int32_t* L, int32_t* size) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < M) L[__float_as_int(spos[p].w)] = Lp[p];
+  const int l = p < M ? Lp[p] : -1;
+  if (p < M) L[__float_as_int(spos[p].w)] = l;
+  rg_hist_add_runs(size, l, p < M);
 }
 
 __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict__ list, const int32_t* __restrict__ deg,
@@ -473,25 +491,6 @@ __global__ __launch_bounds__(256) void k_rg_propagate(const int32_t* __restrict_
   if (ch) changed[0] = 1;
 }
 
-// histogram add with one atomic per run of equal keys inside a wave (cell-sorted points carry long runs of the same
-// cluster id; one atomic per element on a few hot addresses serialises in L2)
-__device__ __forceinline__ void rg_hist_add_runs(int32_t* hist, int k, bool valid) {
-  const int lane = threadIdx.x & 63;
-  const int kk = valid ? k : -1;
-  const int prev = __shfl_up(kk, 1);
-  const bool lead = lane == 0 || prev != kk;
-  const unsigned long long lm = __ballot(lead);
-  if (lead && kk >= 0) {
-    const unsigned long long higher = lane < 63 ? (lm >> (lane + 1)) : 0ull;
-    const int next = higher ? lane + 1 + __builtin_ctzll(higher) : 64;
-    atomicAdd(&hist[kk], next - lane);  // lanes past the end of the data carry kk = -1 and start their own run
-  }
-}
-
-__global__ __launch_bounds__(256) void k_rg_sizes(const int32_t* __restrict__ L, int64_t M, int32_t* size) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  rg_hist_add_runs(size, v < M ? L[v] : -1, v < M);
-}
 __global__ __launch_bounds__(256) void k_rg_rootkeys(const int32_t* __restrict__ L, const int32_t* __restrict__ size,
                                                      const int32_t* __restrict__ bc, int64_t M, int min_size,
                                                      uint32_t* key, int32_t* n_clusters) {
@@ -745,10 +744,9 @@ extern "C" int pp_region_grow(const float* pos, const int64_t* labels, const int
     pp_set_error("pp_region_grow: label propagation did not converge in 4096 x 4 rounds (%lld selected points)", (long long)M);
     return PP_ERR_INVALID;
   }
-  hipLaunchKernelGGL(k_rg_labels_by_index, dim3(mb), dim3(256), 0, s, spos, Lp, M, L);
   // clusters: valid roots ordered by (class, root index)
   PP_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)M, s));
-  hipLaunchKernelGGL(k_rg_sizes, dim3(mb), dim3(256), 0, s, L, M, size);
+  hipLaunchKernelGGL(k_rg_labels_by_index, dim3(mb), dim3(256), 0, s, spos, Lp, M, L, size);
   hipLaunchKernelGGL(k_rg_rootkeys, dim3(mb), dim3(256), 0, s, L, size, bc, M, min_cluster_size, rkey, misc + 3);
   PP_LAUNCH_CHECK();
   rc = pp_sort_pairs_u32(rkey, rkey2, local, roots2, M, 9, ar.cur(), ar.left(), s);

@@ -11,6 +11,7 @@
 //   E  labels         nearest surviving centre per point
 // All samples (cylinders) of the batch are processed together.
 #include "pp_common.h"
+#include <vector>
 
 #define MS_STRIDE 8  // padded floats per point / centre
 
@@ -51,14 +52,21 @@ __device__ inline void ms_bin_of(const MSParams& P, int64_t i, int* k) {
 __global__ __launch_bounds__(256) void k_ms_bins(MSParams P, const int32_t* __restrict__ sample, int32_t* table,
                                                  int64_t cap, int32_t* is_rep, int32_t* reps_in_sample) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.m) return;
-  int s = sample[i];
-  if (s < 0) {
+  const bool in = i < P.m;
+  int s = in ? sample[i] : -1;
+  int k[MS_STRIDE];
+  for (int d = 0; d < MS_STRIDE; ++d) k[d] = 0;
+  if (s >= 0) ms_bin_of(P, i, k);
+  // neighbours in the input order mostly share their bin (points of one object): only the first lane of a run of equal
+  // (sample, bin) probes the table -- the others cannot be the bin's representative unless that lane is, and one
+  // representative per bin is all that is needed
+  bool same = (threadIdx.x & 63) != 0 && s >= 0 && __shfl_up(s, 1) == s;
+  for (int d = 0; d < MS_STRIDE; ++d) same = (__shfl_up(k[d], 1) == k[d]) && same;
+  if (!in) return;
+  if (s < 0 || same) {
     is_rep[i] = 0;
     return;
   }
-  int k[MS_STRIDE];
-  ms_bin_of(P, i, k);
   uint64_t h = pp_mix64((uint64_t)(uint32_t)s + 0x9E3779B97F4A7C15ull);
   for (int d = 0; d < MS_STRIDE; ++d) h = pp_mix64(h ^ (uint64_t)(uint32_t)k[d]);
   uint64_t mask = (uint64_t)cap - 1, slot = h & mask;
@@ -247,6 +255,56 @@ __global__ __launch_bounds__(256) void k_ms_segments(const uint32_t* __restrict_
   if (s >= (uint32_t)ns) return;
   if (p == 0 || skey[p - 1] != s) seg_start[s] = (int32_t)p;
   if (p == S - 1 || skey[p + 1] != s) seg_end[s] = (int32_t)(p + 1);
+}
+
+// The same order for samples with few seeds, in one launch: seeds come in point order, so those of a sample are a
+// contiguous range of the seed list already; one workgroup per sample ranks each of its seeds against the others under
+// the comparator of the radix passes (count descending, coordinates 0..dim-1 descending, original position) with the
+// keys in LDS.  The seven stable sorts above are 25 radix passes = ~150 launches of a few microseconds of work each.
+#define MS_SORT_SMALL 1024
+__global__ __launch_bounds__(256) void k_ms_sort_small(const float* __restrict__ cen, const int32_t* __restrict__ cnt,
+                                                       const int32_t* __restrict__ reps_in_sample, int dim,
+                                                       int32_t* __restrict__ perm, int32_t* seg_start, int32_t* seg_end) {
+  __shared__ uint32_t key[MS_STRIDE + 1][MS_SORT_SMALL];
+  __shared__ int red[4];
+  __shared__ int nvalid;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  int part = 0;
+  for (int t = tid; t < s; t += 256) part += reps_in_sample[t];
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  if (tid == 0) nvalid = 0;
+  __syncthreads();
+  const int r0 = red[0] + red[1] + red[2] + red[3];
+  const int n = reps_in_sample[s];
+  int valid = 0;
+  for (int p = tid; p < n; p += 256) {
+    const int c = cnt[r0 + p];
+    key[0][p] = c > 0 ? ~(uint32_t)c : 0xFFFFFFFFu;  // seeds without neighbours rank last (and stay outside the segment)
+    valid += c > 0 ? 1 : 0;
+    for (int d = 0; d < MS_STRIDE; ++d) key[1 + d][p] = d < dim ? ms_ord_desc(cen[(int64_t)(r0 + p) * MS_STRIDE + d]) : 0u;
+  }
+  if (valid) atomicAdd(&nvalid, valid);
+  __syncthreads();
+  for (int p = tid; p < n; p += 256) {
+    uint32_t mine[MS_STRIDE + 1];
+    for (int d = 0; d <= MS_STRIDE; ++d) mine[d] = key[d][p];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      int before = j < p ? 1 : 0;  // equal tuples keep their order
+#pragma unroll
+      for (int d = MS_STRIDE; d >= 0; --d) {
+        const uint32_t kj = key[d][j];
+        before = kj < mine[d] ? 1 : (kj > mine[d] ? 0 : before);
+      }
+      rank += before;
+    }
+    perm[r0 + rank] = r0 + p;
+  }
+  if (tid == 0) {
+    seg_start[s] = r0;
+    seg_end[s] = r0 + nvalid;
+  }
 }
 
 // one workgroup per sample; sorted centres of the sample are perm[seg_start..seg_end)
@@ -473,9 +531,13 @@ extern "C" int pp_meanshift(const float* x, int64_t m, int32_t dim, const int64_
                      cell_end, xs, ssample);
   PP_LAUNCH_CHECK();
   int32_t S32 = 0;
+  std::vector<int32_t> h_reps((size_t)n_samples);
   PP_HIP(hipMemcpyAsync(&S32, misc, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PP_HIP(hipMemcpyAsync(h_reps.data(), reps_in_sample, sizeof(int32_t) * (size_t)n_samples, hipMemcpyDeviceToHost, s));
   PP_HIP(hipStreamSynchronize(s));
   const int64_t S = S32;
+  int32_t max_reps = 0;
+  for (int32_t r : h_reps) max_reps = std::max(max_reps, r);
   PP_HIP(hipMemsetAsync(n_clusters, 0, sizeof(int32_t) * n_samples, s));
   if (S == 0) {
     hipLaunchKernelGGL(k_ms_fill_i32, dim3(msfb(m)), dim3(256), 0, s, labels, -1, m);
@@ -504,7 +566,14 @@ extern "C" int pp_meanshift(const float* x, int64_t m, int32_t dim, const int64_
   hipLaunchKernelGGL(k_ms_iota, dim3(sb), dim3(256), 0, s, perm, S);
   int32_t* pa = perm;
   int32_t* pb = perm2;
-  for (int pass = 0; pass < dim + 2; ++pass) {
+  const bool small = max_reps <= MS_SORT_SMALL;
+  if (small) {
+    hipLaunchKernelGGL(k_ms_sort_small, dim3((unsigned)n_samples), dim3(256), 0, s, cen, cnt, reps_in_sample, dim, perm2,
+                       seg_start, seg_end);
+    PP_LAUNCH_CHECK();
+    pa = perm2;
+  }
+  for (int pass = 0; pass < (small ? 0 : dim + 2); ++pass) {
     int what = pass < dim ? (dim - 1 - pass) : (pass == dim ? -1 : -2);
     hipLaunchKernelGGL(k_ms_sort_key, dim3(sb), dim3(256), 0, s, cen, cnt, seed_point, sample, pa, S, what, n_samples,
                        skey);
@@ -514,10 +583,11 @@ extern "C" int pp_meanshift(const float* x, int64_t m, int32_t dim, const int64_
     if (rc) return rc;
     int32_t* t = pa; pa = pb; pb = t;
   }
-  // skey2 now holds the sorted sample ids
-  PP_HIP(hipMemsetAsync(seg_start, 0, sizeof(int32_t) * ((size_t)n_samples + 2), s));
-  PP_HIP(hipMemsetAsync(seg_end, 0, sizeof(int32_t) * ((size_t)n_samples + 2), s));
-  hipLaunchKernelGGL(k_ms_segments, dim3(sb), dim3(256), 0, s, skey2, S, n_samples, seg_start, seg_end);
+  if (!small) {  // skey2 now holds the sorted sample ids
+    PP_HIP(hipMemsetAsync(seg_start, 0, sizeof(int32_t) * ((size_t)n_samples + 2), s));
+    PP_HIP(hipMemsetAsync(seg_end, 0, sizeof(int32_t) * ((size_t)n_samples + 2), s));
+    hipLaunchKernelGGL(k_ms_segments, dim3(sb), dim3(256), 0, s, skey2, S, n_samples, seg_start, seg_end);
+  }
   int32_t* alive = is_rep;  // reuse
   int32_t* arank = rank;    // reuse
   PP_HIP(hipMemsetAsync(alive, 0, sizeof(int32_t) * (size_t)S, s));

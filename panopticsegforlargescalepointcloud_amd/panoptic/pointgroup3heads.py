@@ -187,7 +187,8 @@ class PointGroup3heads(nn.Module):
     def _embed_clusters(self, pred, emb):
         label_mask = ops.not_ignored(pred, self._stuff_classes, self.num_classes)
         local_ind = torch.nonzero(label_mask).view(-1)
-        return meanshift_cluster.cluster_single_csr(emb[label_mask], self.input.batch[label_mask], local_ind,
+        # (rows by index: a boolean mask costs another compaction pass and host synchronisation per use)
+        return meanshift_cluster.cluster_single_csr(emb[local_ind], self.input.batch[local_ind], local_ind,
                                                     self.opt.bandwidth)
 
     @staticmethod

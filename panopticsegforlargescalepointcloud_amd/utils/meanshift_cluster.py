@@ -28,27 +28,37 @@ def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_po
     m = embed_logits_u.shape[0]
     if m == 0:
         return ops.ClusterCSR(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), 0)
-    # samples must be contiguous; PyG batches are sorted, but do not rely on it
-    if bool((label_batch[1:] < label_batch[:-1]).any()):
+    # samples must be contiguous; PyG batches are sorted, but do not rely on it: the run heads of a sorted batch vector
+    # are strictly increasing (checked on the host from the one read that also brings the run lengths)
+    uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
+    heads, runs = torch.stack([uniq, counts]).tolist()
+    if any(b <= a for a, b in zip(heads, heads[1:])):
         order = torch.sort(label_batch, stable=True)[1]
         embed_logits_u, label_batch, local_ind = embed_logits_u[order], label_batch[order], local_ind[order]
-    uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
-    offs = [0] + torch.cumsum(counts, 0).tolist()
+        uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
+        runs = counts.tolist()
+    offs = [0]
+    for r in runs:
+        offs.append(offs[-1] + r)
     labels, ncl, _ = ops.meanshift(embed_logits_u.detach().float().contiguous(), offs, bandwidth,
                                    min_points_exclusive=min_points_exclusive)
     # global cluster id = (clusters of earlier samples) + label ; samples ascending, labels ascending
-    base = torch.cumsum(ncl, 0) - ncl
-    sample_of_point = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), counts)
+    csum = torch.cumsum(ncl, 0)
+    base = csum - ncl
+    sample_of_point = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), counts, output_size=m)
     key = torch.where(labels >= 0, labels + base[sample_of_point].to(torch.int32), labels)
-    n_groups = int(ncl.sum().item())
+    n_groups = int(csum[-1].item())
     goffs, out, total = ops.group_by_key(key.contiguous(), n_groups, ids=local_ind.contiguous())
     # sklearn can leave a centre without points; torch.unique in the reference wrapper skips such labels
     sizes = goffs[1:] - goffs[:-1]
     keep = sizes > 0
-    if bool(keep.all()):
-        return ops.ClusterCSR(goffs, out[: ops.group_by_key_check(total)], n_groups)
+    n_keep, kept, bad = torch.cat([keep.sum().view(1).to(torch.int32), total]).tolist()  # one read for all three
+    if bad:
+        raise ops._lib.PanopticHipError("group_by_key: %d keys outside [0, n_groups)" % bad)
+    if n_keep == n_groups:
+        return ops.ClusterCSR(goffs, out[:kept], n_groups)
     new_offs = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), torch.cumsum(sizes[keep], 0).to(torch.int32)])
-    return ops.ClusterCSR(new_offs, out[: ops.group_by_key_check(total)], int(keep.sum().item()))
+    return ops.ClusterCSR(new_offs, out[:kept], n_keep)
 
 
 def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, type, bandwidth):

@@ -447,6 +447,22 @@ def test_meanshift_batched_matches_oracle(ops, oracle):
     np.testing.assert_allclose(centers.cpu().numpy(), wc, atol=2e-3)
 
 
+def test_meanshift_many_seeds_per_sample(ops, oracle):
+    """> 1024 bin seeds in a sample take the radix-sort ordering of the centres, fewer the one-launch rank sort: a spread-out
+    sample (thousands of occupied bins) next to compact ones, in both positions"""
+    rng = np.random.default_rng(12)
+    wide = rng.uniform(-5, 5, size=(5000, 3)).astype(np.float32)
+    cen = rng.normal(0, 3.0, size=(12, 3))
+    tight = (cen[rng.integers(0, 12, size=2500)] + rng.normal(0, 0.1, size=(2500, 3))).astype(np.float32)
+    for parts in ([tight, wide, tight[:900]], [tight, tight[:1200]]):
+        x = np.concatenate(parts)
+        offs = np.concatenate([[0], np.cumsum([len(q) for q in parts])]).tolist()
+        wl, wn, _ = oracle.meanshift(x, offs, 0.6)
+        labels, ncl, _ = ops.meanshift(dev(x), offs, 0.6)
+        assert np.array_equal(ncl.cpu().numpy(), wn)
+        assert np.array_equal(labels.cpu().numpy(), wl)
+
+
 def test_hdbscan_matches_goldens(ops):
     z = np.load(os.path.join(GOLD, "hdbscan_cases.npz"))
     for name in z["names"].tolist():
