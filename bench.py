@@ -16,6 +16,7 @@ events on the launch stream, algorithmic bytes/flops per SURVEY.md 8d) and `cpu_
 MeanShift on a bounded sample; N == 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -75,6 +76,42 @@ def build_model(device, voxel):
     return model.to(device).eval(), cfg, DS
 
 
+def host_cpu_state():
+    """(process CPU seconds, cgroup throttled microseconds, throttled periods) -- diagnostics for bench.py's config.host"""
+    t = time.process_time()
+    usec = n = 0
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k == "throttled_usec":
+                usec = int(v)
+            elif k == "nr_throttled":
+                n = int(v)
+    except Exception:
+        pass
+    return t, usec, n
+
+
+def host_threads():
+    """(threads the OpenMP oracle runs with, CPUs the container's cgroup quota allows or None) -- the oracle is throttled,
+    not sped up, by more threads than the quota"""
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(period))))
+    except Exception:
+        pass
+    import ctypes
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        if "OMP_NUM_THREADS" not in os.environ and quota is not None and quota < (os.cpu_count() or 1):
+            gomp.omp_set_num_threads(quota)
+        return int(gomp.omp_get_max_threads()), quota
+    except Exception:
+        return os.cpu_count(), quota
+
+
 def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=3):
     """Oracle (C/OpenMP restatement) U-Net + heads + region growing + scorer, with the reference's real dependency
     (sklearn MeanShift) for the embedding clustering, on ONE median-size tile: one warm-up pass, then the median of
@@ -93,6 +130,7 @@ def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=3):
         use_sk = True
     except Exception:
         use_sk = False
+    threads, quota = host_threads()
     runs = []
     for it in range(repeats + 1):
         timings = {}
@@ -105,7 +143,8 @@ def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=3):
     runs = sorted(runs[1:], key=lambda r: r[0])  # drop the warm-up pass
     dt, timings, conv = runs[len(runs) // 2]
     n = len(b["pos"])
-    res = {"value": n / dt, "unit": "points/sec", "cores": os.cpu_count(), "kind": "port",
+    res = {"value": n / dt, "unit": "points/sec", "cores": threads, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
+           "kind": "port",
            "sample": "1 of %d tiles (%d voxels, median of %d passes after 1 warm-up: %.2f s): C/OpenMP oracle "
                      "U-Net+heads+region_grow+scorer, %s MeanShift" % (len(tiles), n, repeats, dt, "sklearn" if use_sk else "oracle"),
            "stages_s": {k: round(v, 3) for k, v in timings.items()}}
@@ -170,8 +209,8 @@ def self_check(runner, batches, device, oracle_case):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=env_int("PP_BENCH_POINTS", 10_000_000))
     ap.add_argument("--grid", type=int, default=env_int("PP_BENCH_GRID", 8))
     ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 64))
@@ -255,12 +294,23 @@ def main():
         step()
     # per-launch HIP events for the roofline object: created here, only recorded inside the timed region
     ops.PROFILER = ops.LaunchProfiler(reserve=launches_per_step * args.steps + 16)
+    # a serving process freezes the objects of its set-up and keeps the cyclic collector out of the request path: a
+    # generation-2 pass over the model / scene object graph is a 20 - 40 ms stall at an arbitrary point of a step
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     sync()
+    host0 = host_cpu_state()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
-        result = step()
+        ts = time.perf_counter()
+        result = step()          # (ends with the host read of the per-tile instance counts: the step's own sync point)
+        step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
     sync()
     dt = time.perf_counter() - t0
+    host1 = host_cpu_state()
+    gc.enable()
     prof = ops.PROFILER.summarize()
     if args.layer_table and rank == 0:
         with open(args.layer_table, "w") as f:
@@ -340,7 +390,12 @@ def main():
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
-                       "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms},
+                       "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms,
+                       # the host side of the timed region (the step has ~25 host reads of data-dependent sizes): CPU time
+                       # this process used, and how long the container's CPU quota throttled it
+                       "host": {"cpu_s": round(host1[0] - host0[0], 3), "wall_s": round(dt, 3), "step_ms": step_ms,
+                                "cgroup_throttled_ms": round((host1[1] - host0[1]) / 1e3, 1),
+                                "cgroup_throttled_periods": host1[2] - host0[2], "torch_threads": torch.get_num_threads()}},
             "roofline": roof,
         }
         oracle_case = None
