@@ -13,6 +13,41 @@ from . import _lib
 _REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 
+class _TimingEvent:
+    """HIP event for timing only, created with hipEventDisableSystemFence: recording a default event makes the queue write
+    back and invalidate its caches at system scope (what torch.cuda.Event does; ~6.6 us per record on the launch stream,
+    1.2 ms per bench step for the two records around each of its 91 convolutions); a timing event does not need that."""
+    _FLAGS = 0x20000000  # hipEventDisableSystemFence (hip_runtime_api.h)
+
+    def __init__(self):
+        rt = _lib.load()  # (the HIP runtime's symbols resolve through the library that links it)
+        self.h = C.c_void_p()
+        rt.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        rt.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        rt.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        rt.hipEventDestroy.argtypes = [C.c_void_p]
+        if rt.hipEventCreateWithFlags(C.byref(self.h), self._FLAGS) != 0:
+            raise _lib.PanopticHipError("hipEventCreateWithFlags failed")
+        self._rt = rt
+
+    def record(self):
+        if self._rt.hipEventRecord(self.h, _stream()) != 0:
+            raise _lib.PanopticHipError("hipEventRecord failed")
+
+    def elapsed_time(self, end):
+        ms = C.c_float()
+        rc = self._rt.hipEventElapsedTime(C.byref(ms), self.h, end.h)
+        if rc != 0:
+            raise _lib.PanopticHipError("hipEventElapsedTime failed (%d)" % rc)
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self._rt.hipEventDestroy(self.h)
+        except Exception:
+            pass
+
+
 class LaunchProfiler:
     """Optional per-launch timing of the dominant kernel (pp_spconv_fwd) with HIP events recorded on the stream the
     kernel is launched on (bench.py uses it for the roofline object; off by default)."""
@@ -21,13 +56,13 @@ class LaunchProfiler:
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
         # (bench.py: launches per step x steps, counted during the warm-up) so that a timed launch only pays the records
-        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * int(reserve))]
+        self._pool = [_TimingEvent() for _ in range(2 * int(reserve))]
 
     def events(self):
         pool = self._pool
         if len(pool) >= 2:
             return pool.pop(), pool.pop()
-        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        return _TimingEvent(), _TimingEvent()
 
     def summarize(self):
         torch.cuda.synchronize()
