@@ -77,7 +77,8 @@ def build_model(device, voxel):
 
 
 def host_cpu_state():
-    """(process CPU seconds, cgroup throttled microseconds, throttled periods) -- diagnostics for bench.py's config.host"""
+    """(process CPU seconds, cgroup throttled microseconds, throttled periods, hipMalloc calls of the caching allocator) --
+    diagnostics for bench.py's config.host"""
     t = time.process_time()
     usec = n = 0
     try:
@@ -89,7 +90,8 @@ def host_cpu_state():
                 n = int(v)
     except Exception:
         pass
-    return t, usec, n
+    segs = torch.cuda.memory_stats().get("segment.all.allocated", 0) if torch.cuda.is_available() else 0
+    return t, usec, n, segs
 
 
 def host_threads():
@@ -401,7 +403,7 @@ def main():
                        # this process used, and how long the container's CPU quota throttled it
                        "host": {"cpu_s": round(host1[0] - host0[0], 3), "wall_s": round(dt, 3), "step_ms": step_ms,
                                 "cgroup_throttled_ms": round((host1[1] - host0[1]) / 1e3, 1),
-                                "cgroup_throttled_periods": host1[2] - host0[2], "torch_threads": torch.get_num_threads()}},
+                                "cgroup_throttled_periods": host1[2] - host0[2], "device_mallocs": host1[3] - host0[3], "torch_threads": torch.get_num_threads()}},
             "roofline": roof,
         }
         oracle_case = None
