@@ -64,12 +64,18 @@ class LaunchProfiler:
             return pool.pop(), pool.pop()
         return _TimingEvent(), _TimingEvent()
 
+    def _pair_counts(self):
+        """number of map pairs of every record, with ONE host read for all the device counters"""
+        dev = [r[7] for r in self.records if r[7] is not None]
+        vals = iter(torch.stack([d.reshape(()).to(torch.int64) for d in dev]).tolist()) if dev else iter(())
+        return [r[3] if r[7] is None else int(next(vals)) for r in self.records]
+
     def summarize(self):
         torch.cuda.synchronize()
         tot_ms = tot_bytes = tot_flops = map_bytes = 0.0
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c) in self.records:
+        counts = self._pair_counts()
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P in zip(self.records, counts):
             map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
-            P = n_out if pairs is None else int(pairs.item())
             # SURVEY.md 8(d): features read once + written once, weights once, one (in,out) int32 pair per map entry;
             # a fused 1x1 shortcut (ds_c input channels) adds its input rows, its weights and its flops
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
@@ -83,8 +89,7 @@ class LaunchProfiler:
         """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
         torch.cuda.synchronize()
         groups = {}
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c) in self.records:
-            P = n_out if pairs is None else int(pairs.item())
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P in zip(self.records, self._pair_counts()):
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
             b += 4.0 * n_out * ds_c + 4.0 * ds_c * cout
             g = groups.setdefault((n_in, n_out, "%d+%d" % (cin, ds_c) if ds_c else cin, cout, K, P), [0, 0.0, 0.0, 0.0])
