@@ -47,7 +47,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // channels): lane (i, q) loads channel q of its row and weight [q][column i] as single dwords.
 // DS: fused 1x1 shortcut (SpconvArgs::ds_*): after the offset loop the wave multiplies ITS OWN rows of ds_in (no gather: a
 // same-level map's output row is the input row) with the packed 1x1 weights into a second set of accumulators.
-template <int NTW, int T, bool BF16, int D, bool C4 = false, bool DS = false>
+// S1: the input has ONE 16-channel step (c0 == 16, no second source): a step is a kernel offset, the source descriptor is
+// loop-invariant and the step bookkeeping shrinks to the offset mask (the general loop carries (offset, channel step) state
+// and rebuilds the descriptor every step: ~25 scalar instructions per step that the 16-channel layers -- 16 MFMAs per step
+// at most -- do not hide).
+template <int NTW, int T, bool BF16, int D, bool C4 = false, bool DS = false, bool S1 = false>
 __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
@@ -209,7 +213,47 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     int more = 1;  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
     // The loads are unconditional: after the last step the load side simply re-reads a valid step.  (A branch around
     // them makes hipcc merge the two paths' outstanding-load counts and wait for the NEW loads before the MFMAs.)
-    if constexpr (D == 1) {
+    if constexpr (S1) {
+      static_assert(!C4 && D == 3, "S1 is the depth-3 loop of the 16-channel layers");
+      const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)a_bytes, 0x00020000);
+#define S1_LOADS(AX, BX, KK)                                                                                     \
+  {                                                                                                              \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                             \
+        AX[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra1, (int)vo[tt], 0, 0));       \
+    const unsigned wso_ = (unsigned)(KK) * w_step + w_jt0;                                                       \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                           \
+        BX[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(lane16 + jt * WT), (int)wso_, 0)); \
+  }
+      // kn / vo name the next offset, or stay on the current one when none is left (have = 0)
+#define S1_ADV()                                                                                 \
+  {                                                                                              \
+    have = r != 0u ? 1 : 0;                                                                      \
+    kn = have ? __builtin_ctz(r) : kn;                                                           \
+    r &= r - 1u;                                                                                 \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) vo[tt] = off[kn][tt * 16 + i] | q16;        \
+  }
+      unsigned r = rem & (rem - 1u);
+      int kc = kl, kn = kl, have = 0;
+      S1_LOADS(A0, B0, kc);
+      S1_ADV();
+      for (;;) {
+        S1_LOADS(A1, B1, kn);
+        const int k0 = kc, d0 = !have;
+        kc = kn;
+        S1_ADV();
+        F3_MFMAS(A0, B0, k0);
+        if (d0) break;
+        S1_LOADS(A0, B0, kn);
+        const int k1 = kc, d1 = !have;
+        kc = kn;
+        S1_ADV();
+        F3_MFMAS(A1, B1, k1);
+        if (d1) break;
+      }
+#undef S1_LOADS
+#undef S1_ADV
+      (void)more; (void)sl;
+    } else if constexpr (D == 1) {
       F3_LOADS(A0, B0);
       int kc = kl;
       F3_ADVANCE(more);
@@ -352,7 +396,13 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 template <int T, bool BF16>
 static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+  const bool s1 = a.c0 == 16 && a.c1 == 0;
   if (a.ds_in) {  // fused shortcut: the per-shape loop variant only (3 for <= 2 column tiles, 1 otherwise)
+    if (s1 && ntw <= 2) {
+      if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+      else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+      return PP_OK;
+    }
     switch (ntw) {
       case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
       case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
@@ -377,6 +427,11 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
   // depth: 1 = one step in flight; 3 = one step in flight with the load side advanced (LDS read of the next offsets)
   // before the MFMAs of the current step -- pays on launches with <= 2 column tiles per wave (16->16 at 2.5 M rows:
   // 374 -> 343 us), nothing on wider ones
+  if (s1 && depth == 3 && ntw <= 2) {
+    if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+    else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+    return PP_OK;
+  }
 #define F3_CASE(N, D) \
   case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
   switch (10 * depth + ntw) {
