@@ -1,0 +1,58 @@
+// What does a buffer load cost when all of its lanes are out of range?  k_spconv_fwd3 issues the A gather of every 16-row
+// tile of the wave for every offset of the wave's union; tiles that lack the offset carry the byte offset 0xFFFFFFFF in all
+// lanes (hardware bounds check -> zeros).  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 profiles/microbench/oob_load.hip -o /tmp/oob && /tmp/oob
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>  // 0: in-range 64 B rows (16 rows per load, like the gather), 1: all lanes out of range, 2: half of the loads out of range
+__global__ __launch_bounds__(256) void k(const float* src, unsigned bytes, const unsigned* offs, int iters, float* out) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)bytes, 0x00020000);
+  const int lane = threadIdx.x & 63;
+  const unsigned q16 = (unsigned)(lane >> 4) * 16u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  unsigned o[4];
+  for (int t = 0; t < 4; ++t) o[t] = offs[(blockIdx.x * 4 + t) * 16 + (lane & 15)] | q16;
+  for (int it = 0; it < iters; ++it) {
+    f32x4 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned off = o[t] + (unsigned)it * 64u * 1024u;  // walk through the buffer
+      if (MODE == 1 || (MODE == 2 && (t & 1))) off = 0xFFFFFFFFu;
+      v[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc += v[t];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = 1.f;
+}
+
+int main() {
+  const size_t bytes = 256u << 20;
+  float* src; float* out; unsigned* offs;
+  hipMalloc(&src, bytes); hipMemset(src, 0, bytes); hipMalloc(&out, 4);
+  const int blocks = 256 * 16;
+  std::vector<unsigned> h(blocks * 64);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned)((i * 2654435761u) % (1u << 20)) * 64u;  // scattered 64 B rows in the first 64 MB
+  hipMalloc(&offs, h.size() * 4); hipMemcpy(offs, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  const int iters = 2000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const char* names[3] = {"in range (scattered 64 B rows)", "all lanes out of range", "every second load out of range"};
+  for (int mode = 0; mode < 3; ++mode) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, src, (unsigned)bytes, offs, iters, out);
+      if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, src, (unsigned)bytes, offs, iters, out);
+      if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, src, (unsigned)bytes, offs, iters, out);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double loads = (double)blocks * 4 * iters * 4;  // wave-level load instructions
+      if (rep) printf("%-34s %8.3f ms  %.2f ns per wave load per CU  (%.1f cycles at 2.4 GHz)\n", names[mode], ms,
+                      ms * 1e6 / (loads / 256), ms * 1e6 / (loads / 256) * 2.4);
+    }
+  }
+  return 0;
+}
