@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libpanoptic_hip.so")
 
 PP_OK = 0
 _STATUS = {1: "PP_ERR_INVALID", 2: "PP_ERR_RANGE", 3: "PP_ERR_HIP", 4: "PP_ERR_WORKSPACE", 5: "PP_UNSUPPORTED"}
+PP_ERR_WORKSPACE = 4
 PP_UNSUPPORTED = 5  # an optional fused form does not serve the shape: nothing was launched
 
 vp = C.c_void_p

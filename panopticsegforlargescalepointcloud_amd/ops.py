@@ -677,7 +677,7 @@ class ClusterCSR:
         offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sz, 0)])
         starts = self.offsets[:-1].long()[ids]
         rep = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), sz)
-        within = torch.arange(int(offs[-1].item()), device=dev) - offs[rep]
+        within = torch.arange(rep.numel(), device=dev) - offs[rep]  # (rep already has the total length: no second host read)
         return ClusterCSR(offs.to(torch.int32), self.points[starts[rep] + within], int(ids.numel()))
 
     def to_list(self):
@@ -850,12 +850,22 @@ def block_merge_check(state):
         raise _lib.PanopticHipError("block_merge: table overflow %d, bad ids / labels %d" % (st[4], st[5]))
 
 
+_NOT_IGNORED_LUT = {}
+
+
 def not_ignored(labels, ignore_labels, num_classes):
     """bool [n]: labels[i] is none of ignore_labels.  A table lookup (labels lie in [-1, num_classes)): one gather pass where
     torch.isin compares every element with every ignored label and reduces (0.43 ms for the bench scene's 9.8 M points)."""
-    lut = torch.ones(int(num_classes) + 2, dtype=torch.bool, device=labels.device)
-    ign = ignore_labels.to(labels.device).long()
-    lut[(ign[(ign >= -1) & (ign < num_classes)] + 1)] = False
+    # (keyed by the VALUES: a host list costs nothing to read; a device tensor is read once per call, like before)
+    key = (tuple(int(v) for v in ignore_labels.tolist()), int(num_classes), labels.device)
+    lut = _NOT_IGNORED_LUT.get(key)
+    if lut is None:  # built once per (ignore list, device): the boolean-mask indexing below synchronises the stream
+        lut = torch.ones(int(num_classes) + 2, dtype=torch.bool, device=labels.device)
+        ign = ignore_labels.to(labels.device).long()
+        lut[(ign[(ign >= -1) & (ign < num_classes)] + 1)] = False
+        if len(_NOT_IGNORED_LUT) > 64:
+            _NOT_IGNORED_LUT.clear()
+        _NOT_IGNORED_LUT[key] = lut
     return lut[(labels + 1).clamp_(0, int(num_classes) + 1)]
 
 
@@ -871,13 +881,24 @@ def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_clus
     offs = torch.empty(n + 2, dtype=torch.int32, device=dev)
     pts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
-    # the neighbour lists dominate the workspace and scale with the number of non-ignored points: count them first
-    n_sel = int(not_ignored(labels, ign, num_classes).sum().item()) if n else 0
-    wsb = lib.pp_region_grow_workspace_for(n, n_sel, int(nsample))
-    ws = _ws(wsb, dev, tag="region_grow")
-    _lib.check(lib.pp_region_grow(_ptr(pos), _ptr(labels), _ptr(batch), n, _ptr(ign), ign.numel(), int(num_classes),
+    def run(ws, wsb):
+        return lib.pp_region_grow(_ptr(pos), _ptr(labels), _ptr(batch), n, _ptr(ign), ign.numel(), int(num_classes),
                                   int(nsample), float(radius), int(min_cluster_size), _ptr(pc), _ptr(offs), _ptr(pts),
-                                  _ptr(counts), _ptr(ws), wsb, _stream()), "pp_region_grow")
+                                  _ptr(counts), _ptr(ws), wsb, _stream())
+
+    # The neighbour lists dominate the workspace and scale with the number of non-ignored points, which the library
+    # counts itself before it carves them: try the kept workspace first (steady state: no extra pass, no extra host read)
+    # and size it exactly -- one counting pass -- only when the library says it is too small.
+    kept = _WS_CACHE.get(("region_grow", str(dev)))
+    rc = _lib.PP_ERR_WORKSPACE
+    if kept is not None and kept.numel() >= lib.pp_region_grow_workspace_for(n, 0, int(nsample)):
+        rc = run(kept, kept.numel())
+    if rc == _lib.PP_ERR_WORKSPACE:
+        n_sel = int(not_ignored(labels, ignore_labels, num_classes).sum().item()) if n else 0
+        wsb = lib.pp_region_grow_workspace_for(n, n_sel, int(nsample))
+        ws = _ws(max(wsb, 64 << 20), dev, tag="region_grow")
+        rc = run(ws, ws.numel())
+    _lib.check(rc, "pp_region_grow")
     nc, npts = counts.tolist()
     return ClusterCSR(offs[: nc + 1], pts[:npts], nc), pc[:n]
 

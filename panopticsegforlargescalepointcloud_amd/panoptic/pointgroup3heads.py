@@ -299,9 +299,12 @@ class PointGroup3heads(nn.Module):
         scores = []
         for lo in range(0, csr.n, MAX_SCORER_BATCH):
             hi = min(lo + MAX_SCORER_BATCH, csr.n)
-            p0, p1 = int(offsets[lo].item()), int(offsets[hi].item())
+            if lo == 0 and hi == csr.n:  # one chunk: all entries, no host read of the offsets
+                p0, p1 = 0, int(csr.points.numel())
+            else:
+                p0, p1 = (int(v) for v in offsets[[lo, hi]].tolist())
             pts = csr.points[p0:p1]
-            b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi])
+            b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi], output_size=p1 - p0)
             # one gather for "rows of the proposals" + "internal row order", none for the way back (the max is order-free)
             batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
             out = self.ScorerUnet(batch_cluster, internal_order=True)
