@@ -388,7 +388,9 @@ class GatheredRows:
         return self.materialise()
 
     def __getitem__(self, idx):
-        return self.materialise()[idx] if not torch.is_tensor(idx) or idx.dtype != torch.int64 else GatheredRows(self, idx).materialise()
+        if torch.is_tensor(idx) and idx.dtype == torch.int64 and idx.dim() == 1:
+            return GatheredRows(self, idx).materialise()  # rows of rows: still one gather
+        return self.materialise()[idx]
 
     def materialise(self, perm=None):
         index = self.index if perm is None else self.index[perm]
