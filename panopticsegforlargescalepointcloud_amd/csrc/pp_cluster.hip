@@ -231,7 +231,9 @@ __global__ __launch_bounds__(128) void k_ball_query(const float4* __restrict__ s
 // per-query kernel pays a full scan plus a bisection over all hits for every one of them where this walk stops after
 // nsample hits.
 #define BQC_CAP 1536
+#ifndef BQC_CAP_BIG
 #define BQC_CAP_BIG 8192
+#endif
 template <int CAP, bool BIG>
 __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restrict__ spos, const int32_t* __restrict__ sbc,
                                                           const uint64_t* __restrict__ keys,
