@@ -16,6 +16,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TA_BUFFER_TOTAL_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum TCP_TCP_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
          "FETCH_SIZE" "WRITE_SIZE" ; do
   i=$((i+1))
+  [ $i -gt ${PMC_PASSES:-7} ] && break   # PMC_PASSES=2: the two SQ passes only (the TCC / TCP passes take minutes each)
   rm -rf /tmp/pm_$i
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pm_$i -o p -- python $R/profiles/conv_one.py "$@" 2 > /dev/null 2>&1
   python $R/profiles/rocpd_summary.py --pmc /tmp/pm_$i/p_results.db $O/pass$i.md > /dev/null 2>&1 || echo "pass $i failed ($C)" >> $O/time.txt
