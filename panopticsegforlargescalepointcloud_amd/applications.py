@@ -7,6 +7,7 @@ BN weight 1 / bias 0 (applications/minkowski.py:104-111), the forward order with
 (applications/minkowski.py:160-196) and the row-order guarantee: output row i belongs to input row i.
 """
 import copy
+import os
 
 import torch
 from torch import nn
@@ -18,6 +19,7 @@ from .modules import MLP, Identity
 from . import ops
 
 SPECIAL_NAMES = ["radius", "max_num_neighbors", "block_names"]
+EARLY_PREFETCH = os.environ.get("PP_EARLY_PREFETCH", "1") != "0"  # builder thread started inside the coordinate manager's constructor
 
 
 class Data:
@@ -158,7 +160,9 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
     def _set_input(self, data):
         dev = self.device
         coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
-        self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev)
+        # (inference: the previous pass's request log lets the coordinate manager start building the coarser levels at once)
+        plan = getattr(self, "_map_plan", None) if (ME.MAP_PREFETCH and EARLY_PREFETCH and not torch.is_grad_enabled()) else None
+        self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev, prefetch_plan=plan)
         self.xyz = data.pos.to(dev) if getattr(data, "pos", None) is not None else data.coords.to(dev)
 
 
