@@ -177,7 +177,7 @@ def self_check(runner, batches, device, oracle_case):
     (instance labels bit-exact, semantic / embedding outputs 1e-4); (2) the median tile run alone equals the CPU oracle
     pipeline (proposals bit-exact, scores 1e-3, instance labels equal after canonicalisation)."""
     checks = {}
-    ids, dev_b, override, starts = batches[0]
+    ids, dev_b, override, starts, _ = batches[0]
     labels, res, counts = runner.run(dev_b, len(ids), override=override)
     j = int(np.argsort(np.diff(starts))[len(ids) // 2])
     lo, hi = int(starts[j]), int(starts[j + 1])
@@ -260,7 +260,7 @@ def main():
         dev_b = {k: torch.from_numpy(v).to(device) for k, v in b.items()}
         override = (torch.from_numpy(cls).to(device), torch.from_numpy(off).to(device), torch.from_numpy(emb).to(device))
         starts = np.concatenate([[0], np.cumsum([len(tiles[t]) for t in ids])])
-        batches.append((ids, dev_b, override, starts))
+        batches.append((ids, dev_b, override, starts, [int(len(tiles[t])) for t in ids]))
     t_gen = time.perf_counter() - t_gen
 
     stats = {"proposals": 0, "instances": 0}
@@ -268,14 +268,14 @@ def main():
     def step(profile=False):
         local = {}
         stats["proposals"] = stats["instances"] = 0
-        for ids, dev_b, override, starts in batches:
+        for ids, dev_b, override, starts, sizes in batches:
             labels, res, counts = runner.run(dev_b, len(ids), override=override)
             stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
             stats["instances"] += sum(counts)
-            for j, t in enumerate(ids):
-                # what the scene assembly needs from a cylinder: origin ids, instance labels, semantic vote contributions
-                local[t] = (dev_b["origin_id"][starts[j]: starts[j + 1]], labels[starts[j]: starts[j + 1]],
-                            res.semantic_logits[starts[j]: starts[j + 1]])
+            # what the scene assembly needs from a cylinder: origin ids, instance labels, semantic vote contributions
+            # (views of the batch tensors, one split per tensor)
+            for t, o, l, v in zip(ids, dev_b["origin_id"].split(sizes), labels.split(sizes), res.semantic_logits.split(sizes)):
+                local[t] = (o, l, v)
         return exchange_tile_results(local) if world > 1 else local
 
     def sync():

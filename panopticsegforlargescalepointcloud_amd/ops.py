@@ -715,9 +715,10 @@ class ProposalPairs:
         self.a, self.b, self.inter, self.n_pairs, self.capacity = a, b, inter, n_pairs, capacity
         self.prop_of_entry, self.info = prop_of_entry, info
 
-    def check(self):
-        """one host read of the error counters (call where the host synchronises anyway)"""
-        over, full, bad_pt, bad_grp = self.info.tolist()
+    def check(self, values=None):
+        """one host read of the error counters (call where the host synchronises anyway); `values`: the four counters
+        when the caller has already read them together with its own numbers"""
+        over, full, bad_pt, bad_grp = self.info.tolist() if values is None else values
         if over:
             raise NotImplementedError("%d points belong to more than 8 proposals" % over)
         if full:
@@ -1009,10 +1010,16 @@ def gather_rows(src, index):
     return out
 
 
-def gather_rows_check():
-    """raises if any gather_rows call since the last check saw an out-of-range index (one synchronisation)"""
+def gather_rows_flag(device):
+    """the device counter behind gather_rows_check (int32 [1]) or None: for callers that read it with their own numbers"""
+    return _GATHER_ERR.get(device)
+
+
+def gather_rows_check(values=None):
+    """raises if any gather_rows call since the last check saw an out-of-range index (one synchronisation); `values`:
+    {device: count} already read by the caller"""
     for dev, flag in _GATHER_ERR.items():
-        bad = int(flag.item())
+        bad = int(flag.item()) if values is None or dev not in values else int(values[dev])
         if bad:
             flag.zero_()
             raise _lib.PanopticHipError("gather_rows: %d indices out of range" % bad)

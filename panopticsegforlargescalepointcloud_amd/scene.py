@@ -29,12 +29,20 @@ def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster
     n = batch.shape[0]
     csr = res.clusters_csr
     if csr is None or csr.n == 0:
+        ops.gather_rows_check()
         return torch.full((n,), -1, dtype=torch.int32, device=batch.device), [0] * n_tiles
     labels, counts, _, pairs = ops.nms_paint(csr, n, batch, n_tiles, res.cluster_scores, nms_threshold, min_cluster_points,
                                              min_score)
-    counts_h = counts.tolist()  # the synchronisation point of the step
-    pairs.check()
-    return labels, counts_h
+    # the synchronisation point of the step: ONE host read brings the per-tile counts, the pair table's error counters and
+    # the row-gather index check (three reads in a row used to leave the GPU idle between two steps)
+    flag = ops.gather_rows_flag(batch.device)
+    parts = [counts.to(torch.int32).view(-1), pairs.info.view(-1)] + ([flag.view(-1)] if flag is not None else [])
+    vals = torch.cat(parts).tolist()
+    nt = counts.numel()
+    pairs.check(vals[nt: nt + 4])
+    if flag is not None:
+        ops.gather_rows_check({batch.device: vals[nt + 4]})
+    return labels, vals[:nt]
 
 
 # ------------------------------------------------------------------------------------------------ scene assembly
@@ -295,8 +303,7 @@ class TileRunner:
         res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred, timer=self._tick if self.stage_timing else None,
                                          t0=t0)
         t0 = self._tick("(group+score total marker)", time.perf_counter()) if False else (time.perf_counter() if self.stage_timing else 0.0)
-        labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)
-        ops.gather_rows_check()  # row gathers trust their indices on the device; one flag read per batch
+        labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)  # (reads the row-gather flag too)
         self._tick("nms+paint", t0)
         return labels, res, counts
 
