@@ -284,3 +284,34 @@ def test_side_stream_overlap_does_not_change_results(setup):
         for a, b in zip(got[:5], off[:5]):
             assert torch.equal(a, b)
         assert got[5] == off[5]
+
+
+def test_inference_switches_do_not_change_results(setup, monkeypatch):
+    """The inference-path fusions and the early start of the map builder are pure scheduling: with each of them off the step
+    returns bit-identical network outputs, proposals, scores and labels (fused heads vs one launch per head on
+    caller-ordered features, fused 1x1 shortcuts vs their own launches, builder thread started in the coordinate
+    manager's constructor vs at the first layer, mean shift next to region growing vs after it)."""
+    from panopticsegforlargescalepointcloud_amd import applications, modules
+    from panopticsegforlargescalepointcloud_amd.panoptic import pointgroup3heads as pg
+    s = setup
+    dev = torch.device("cuda")
+    ov = tuple(torch.from_numpy(a).to(dev) for a in s["override"])
+
+    def run():
+        outs = []
+        for _ in range(2):  # the second pass replays the map plan of the first (prefetch on the side stream)
+            labels, res, counts = s["runner"].run(s["b"], len(s["ids"]), override=ov)
+            outs.append((labels.clone(), res.semantic_logits.clone(), res.offset_logits.clone(), res.embed_logits.clone(),
+                         res.cluster_scores.clone(), res.clusters_csr.offsets.clone(), res.clusters_csr.points.clone(), list(counts)))
+        return outs
+
+    ref = run()
+    for mod, name in [(pg, "FUSE_HEADS"), (modules, "FUSE_SHORTCUT"), (applications, "EARLY_PREFETCH"), (pg, "OVERLAP_CLUSTERING")]:
+        assert getattr(mod, name) is True
+        monkeypatch.setattr(mod, name, False)
+        got = run()
+        monkeypatch.setattr(mod, name, True)
+        for r, g in zip(ref, got):
+            for a, b in zip(r[:-1], g[:-1]):
+                assert torch.equal(a, b), name
+            assert r[-1] == g[-1], name
