@@ -45,6 +45,6 @@ def report(name, order):
 
 ident = torch.arange(n, device=dev)
 report("Morton blocks", ident)
-for W in (256, 1024, 8192):
+for W in (256, 1024, 8192, 32768, 131072, 1 << 30):
     key = (ident // W) * (1 << 27) + mask
     report("mask-sorted inside %d-row windows" % W, torch.sort(key, stable=True)[1])
