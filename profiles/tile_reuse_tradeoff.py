@@ -48,3 +48,22 @@ report("Morton blocks", ident)
 for W in (256, 1024, 8192, 32768, 131072, 1 << 30):
     key = (ident // W) * (1 << 27) + mask
     report("mask-sorted inside %d-row windows" % W, torch.sort(key, stable=True)[1])
+
+# bit significance inside 8192-row windows: raw offset index (above), the product's class order (centre < faces < edges <
+# corners), and a per-window order by frequency (the rarest offset of THAT window most significant)
+W = 8192
+bits = ((mask[:, None] >> torch.arange(K, device=dev)[None, :]) & 1)  # [n, 27]
+corner = [0, 2, 6, 8, 18, 20, 24, 26]
+face = [4, 10, 12, 14, 16, 22]
+edge = [k for k in range(27) if k not in corner + face + [13]]
+cls = [13] + face + edge + corner
+key = (ident // W) * (1 << 27) + (bits[:, cls] << torch.arange(K, device=dev)[None, :]).sum(1)
+report("class order (product), 8192-row windows", torch.sort(key, stable=True)[1])
+nw = (n + W - 1) // W
+freq = torch.zeros(nw, K, device=dev).index_add_(0, ident // W, bits.float())
+for name, score in [("per-window frequency order (rarest highest)", -freq),
+                    ("per-window order (closest to half highest)", -(freq - W / 2).abs() * -1.0)]:
+    rank = torch.argsort(torch.argsort(score, dim=1, descending=False), dim=1)  # position of bit k in the key: low score -> low position
+    pos = rank[ident // W]                                                      # [n, 27]
+    key = (ident // W) * (1 << 27) + (bits << pos).sum(1)
+    report(name, torch.sort(key, stable=True)[1])

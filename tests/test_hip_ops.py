@@ -708,13 +708,19 @@ def test_sort_pairs(ops, n, dtype, end_bit):
     assert torch.equal(vo.long(), order) and torch.equal(ko, keys[order])
 
 
-def _mask_sort_rank(mask):
-    """numpy restatement of mo_remap (csrc/pp_maporder.hip): centre lowest, then faces, edges, corners (most significant)"""
-    cls = np.array([(k % 3 != 1) + ((k // 3) % 3 != 1) + (k // 9 != 1) for k in range(27)])
-    order = [k for c in (0, 1, 2, 3) for k in range(27) if cls[k] == c]
+def _mask_sort_rank(mask, window):
+    """numpy restatement of the sort key of csrc/pp_maporder.hip: per window of `window` consecutive rows the offset most rows
+    have is the least significant bit, the rarest the most significant (ties: lower offset index lower).  `mask` in the
+    ORIGINAL row order; returns the keys in that order."""
     out = np.zeros(len(mask), np.int64)
-    for pos, k in enumerate(order):
-        out |= ((mask >> k) & 1) << pos
+    for w0 in range(0, len(mask), window):
+        m = mask[w0: w0 + window]
+        freq = np.array([int(((m >> k) & 1).sum()) for k in range(27)])
+        pos = [sum(1 for j in range(27) if freq[j] > freq[k] or (freq[j] == freq[k] and j < k)) for k in range(27)]
+        o = np.zeros(len(m), np.int64)
+        for k in range(27):
+            o |= ((m >> k) & 1) << pos[k]
+        out[w0: w0 + window] = o
     return out
 
 
@@ -738,7 +744,7 @@ def test_map_order_and_slot_ordered_maps(ops, oracle):
         o = order.cpu().numpy().astype(np.int64)
         assert np.array_equal(np.sort(o), np.arange(n))
         assert np.array_equal(o // lib_window, np.arange(n) // lib_window)          # rows never leave their window
-        key = ((np.arange(n) // lib_window) << 50) | (_mask_sort_rank(mask[o]) << 13) | (o % lib_window)
+        key = ((np.arange(n) // lib_window) << 50) | (_mask_sort_rank(mask, lib_window)[o] << 13) | (o % lib_window)
         assert np.all(np.diff(key) > 0)
         # renumbered level + same-level map in physical ids
         coords_p, phys_of = ops.level_permute(dev(fine), order)
