@@ -62,7 +62,7 @@ report("class order (product), 8192-row windows", torch.sort(key, stable=True)[1
 nw = (n + W - 1) // W
 freq = torch.zeros(nw, K, device=dev).index_add_(0, ident // W, bits.float())
 for name, score in [("per-window frequency order (rarest highest)", -freq),
-                    ("per-window order (closest to half highest)", -(freq - W / 2).abs() * -1.0)]:
+                    ("per-window order (closest to half of the rows highest)", -(freq - W / 2).abs())]:
     rank = torch.argsort(torch.argsort(score, dim=1, descending=False), dim=1)  # position of bit k in the key: low score -> low position
     pos = rank[ident // W]                                                      # [n, 27]
     key = (ident // W) * (1 << 27) + (bits << pos).sum(1)
