@@ -67,3 +67,15 @@ for name, score in [("per-window frequency order (rarest highest)", -freq),
     pos = rank[ident // W]                                                      # [n, 27]
     key = (ident // W) * (1 << 27) + (bits << pos).sum(1)
     report(name, torch.sort(key, stable=True)[1])
+
+# one more level of the same idea: after the 8192-row sort, every 1024-row chunk of the result is sorted again by ITS OWN
+# frequency order (a two-level approximation of a per-window decision tree)
+rank = torch.argsort(torch.argsort(-freq, dim=1), dim=1)
+key = (ident // W) * (1 << 27) + (bits << rank[ident // W]).sum(1)
+o1 = torch.sort(key, stable=True)[1]
+for W2 in (2048, 1024, 256):
+    b2 = bits[o1]
+    f2 = torch.zeros((n + W2 - 1) // W2, K, device=dev).index_add_(0, ident // W2, b2.float())
+    r2 = torch.argsort(torch.argsort(-f2, dim=1), dim=1)
+    k2 = (ident // W2) * (1 << 27) + (b2 << r2[ident // W2]).sum(1)
+    report("frequency order, 8192 then %d-row chunks" % W2, o1[torch.sort(k2, stable=True)[1]])
