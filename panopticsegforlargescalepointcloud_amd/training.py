@@ -106,12 +106,15 @@ class GradientReducer:
         if self.world == 1:
             self._reset()
             return 0
-        has = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
-                           device=self.params[0].device if self.params else "cpu")
-        has_work = dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if self.params else None
         while self._next < len(self.buckets):
             self._launch(self._next)
             self._next += 1
+        # the has-gradient mask goes out AFTER the last bucket: how many buckets backward already launched differs between
+        # ranks (a rank whose batch gave no proposals completes fewer buckets in backward), so any earlier position would
+        # interleave the mask with the buckets differently per rank -- mismatched collectives (gloo aborts, RCCL hangs)
+        has = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32,
+                           device=self.params[0].device if self.params else "cpu")
+        has_work = dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group, async_op=True) if self.params else None
         if has_work is not None:
             has_work.wait()
         anywhere = {id(p): bool(h) for p, h in zip(self.params, has.tolist())}

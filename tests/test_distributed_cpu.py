@@ -212,3 +212,64 @@ def test_gradient_allreduce_world2():
             grads2.append(torch.cat([p.grad.reshape(-1) for p in list(m.parameters())[:-2]]))
         np.testing.assert_allclose(np.frombuffer(blob, np.float32), ((grads2[0] + grads2[1]) / 2).numpy(), rtol=1e-6, atol=1e-7)
         assert len(np.frombuffer(blob, np.float32)) == n_used
+
+
+# ---------------------------------------------------------------- hook-based reducer with asymmetric gradients
+def _asym_worker(rank, world, port, q):
+    """rank 1 does not use the middle layer (the scorer of a rank whose batch produced no proposals): it completes fewer
+    buckets during backward than rank 0, so the collectives finish() adds must sit at a rank-independent position."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from panopticsegforlargescalepointcloud_amd.training import GradientReducer
+    torch.manual_seed(9)
+    a, mid, c = torch.nn.Linear(30, 200), torch.nn.Linear(200, 200), torch.nn.Linear(200, 5)
+    params = list(a.parameters()) + list(mid.parameters()) + list(c.parameters())
+    reducer = GradientReducer(params, bucket_bytes=100_000)  # >= 3 buckets: c | mid | a (reverse registration order)
+    g = torch.Generator().manual_seed(70 + rank)
+    x, y = torch.randn(32, 30, generator=g), torch.randn(32, 5, generator=g)
+    launched = []
+    for step in range(2):  # second step: the bucket layout has been re-sorted by the reduced mask
+        for p in params:
+            p.grad = None
+        before = reducer.launched_in_backward
+        h = torch.relu(a(x))
+        if rank == 0:
+            h = torch.relu(mid(h))
+        torch.nn.functional.mse_loss(c(h), y).backward()
+        launched.append(reducer.launched_in_backward - before)
+        reducer.finish()
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    q.put((rank, launched, flat.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_hooks_asymmetric_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_asym_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # both ranks end with the same averaged gradients; rank 0 launched more buckets inside backward than rank 1 did
+    assert msgs[0][2] == msgs[1][2]
+    assert msgs[0][1][0] > msgs[1][1][0], msgs
+    grads = []
+    for rank in range(world):
+        torch.manual_seed(9)
+        a, mid, c = torch.nn.Linear(30, 200), torch.nn.Linear(200, 200), torch.nn.Linear(200, 5)
+        g = torch.Generator().manual_seed(70 + rank)
+        x, y = torch.randn(32, 30, generator=g), torch.randn(32, 5, generator=g)
+        h = torch.relu(a(x))
+        if rank == 0:
+            h = torch.relu(mid(h))
+        torch.nn.functional.mse_loss(c(h), y).backward()
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                for p in list(a.parameters()) + list(mid.parameters()) + list(c.parameters())]))
+    np.testing.assert_allclose(np.frombuffer(msgs[0][2], np.float32), ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-6, atol=1e-7)
