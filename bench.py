@@ -114,17 +114,27 @@ def host_threads():
         return os.cpu_count(), quota
 
 
-def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=3):
-    """Oracle (C/OpenMP restatement) U-Net + heads + region growing + scorer, with the reference's real dependency
-    (sklearn MeanShift) for the embedding clustering, on ONE median-size tile: one warm-up pass, then the median of
-    `repeats` passes.  Reported baseline only.  Also returns what the self-check needs to compare the GPU
-    path with the oracle on that tile."""
+def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=5, warmups=2, n_tiles=16):
+    """CPU baseline per SURVEY.md 8d on a batch of `n_tiles` tiles around the median size (reported baseline only):
+      (1) embedding clustering = the reference's own dependency and fan-out: sklearn MeanShift(bin_seeding) on ONE sample
+          per process, min(n_tiles, cores) SPAWNED processes, `pool.map` over the batch's samples exactly as
+          torch_points3d/utils/meanshift_cluster.py:9-18,96-101 does (the pool persists across passes: process start-up is
+          not charged);
+      (2) sparse U-Net + heads + region growing + ScorerUnet = the C/OpenMP restatement (oracle/) on all the threads the
+          container's CPU quota grants, timed on the batch's median tile and scaled by the batch's point count (the
+          restatement is parallel over rows, so a 16-tile batch costs 16 tiles' worth of the same passes).
+    Both parts: `warmups` untimed passes, then the median of `repeats`.  value = points of the batch / (network time for
+    the batch + mean-shift fan-out time) -- the reference runs the two one after the other inside forward().
+    Also returns what the self-check needs to compare the GPU path with the oracle on the median tile."""
     from oracle import pipeline as opipe
     from panopticsegforlargescalepointcloud_amd import synthetic as syn
-    t = int(np.argsort([len(x) for x in tiles])[len(tiles) // 2])  # median-size tile
-    b = syn.tile_batch(scene, tiles, [t])
-    rng = np.random.default_rng(99)
-    cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, rng)
+    order = np.argsort([len(x) for x in tiles])
+    mid = len(tiles) // 2
+    lo = max(0, min(mid - n_tiles // 2, len(tiles) - n_tiles))
+    chosen = [int(t) for t in order[lo: lo + n_tiles]]
+    t_med = int(order[mid])  # median-size tile
+    b = syn.tile_batch(scene, tiles, [t_med])
+    cls, off, emb = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(99))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     opt = {"cluster_radius_search": cfg.cluster_radius_search, "cluster_type": cfg.cluster_type, "bandwidth": cfg.bandwidth}
     try:
@@ -133,22 +143,57 @@ def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=3):
     except Exception:
         use_sk = False
     threads, quota = host_threads()
+    ignore = [-1] + [int(c) for c in syn.NPM3D_STUFF]
+    # ---- (1) the embedding clustering of the batch, fanned out over processes
+    samples, n_batch = [], 0
+    for t in chosen:
+        bt = b if t == t_med else syn.tile_batch(scene, tiles, [t])
+        c_t, _, e_t = (cls, off, emb) if t == t_med else syn.synthetic_head_outputs(scene, bt["origin_id"], 0.0, np.random.default_rng(99))
+        samples.append((np.ascontiguousarray(e_t[~np.isin(c_t, ignore)]), float(cfg.bandwidth)))
+        n_batch += len(bt["pos"])
+    procs = max(1, min(len(samples), threads))
+    ms_times, ms_labels = [], None
+    if use_sk:
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(processes=procs) as pool:
+            for it in range(warmups + repeats):
+                t0 = time.perf_counter()
+                ms_labels = pool.map(opipe.sklearn_meanshift_labels, samples)
+                ms_times.append(time.perf_counter() - t0)
+    else:  # no sklearn on the box: the oracle's own mean shift, one sample after the other
+        from oracle import oracle as O
+        for it in range(warmups + repeats):
+            t0 = time.perf_counter()
+            ms_labels = [O.meanshift(x, [0, len(x)], bw)[0] for x, bw in samples]
+            ms_times.append(time.perf_counter() - t0)
+    t_ms = float(np.median(ms_times[warmups:]))
+    # mean-shift proposals of the median tile, in the reference's order (labels ascending), for the network passes
+    j = chosen.index(t_med)
+    li = np.nonzero(~np.isin(cls, ignore))[0]
+    ms_clusters = [li[ms_labels[j] == l] for l in np.unique(ms_labels[j]) if l != -1] if len(li) > 3 else []
+    # ---- (2) U-Net + heads + region growing + scorer on the median tile
     runs = []
-    for it in range(repeats + 1):
+    for it in range(warmups + repeats):
         timings = {}
         opipe.CONV_STATS["flops"] = opipe.CONV_STATS["seconds"] = 0.0
         t0 = time.perf_counter()
         out = opipe.forward(sd, b, opt, DS.num_classes, syn.NPM3D_STUFF, override=(cls, off, emb), use_sklearn_meanshift=use_sk,
-                            timings=timings)
+                            timings=timings, ms_clusters=ms_clusters)
         want_labels = opipe.instance_labels(out, len(b["pos"]), b["batch"])
         runs.append((time.perf_counter() - t0, timings, dict(opipe.CONV_STATS)))
-    runs = sorted(runs[1:], key=lambda r: r[0])  # drop the warm-up pass
+    runs = sorted(runs[warmups:], key=lambda r: r[0])
     dt, timings, conv = runs[len(runs) // 2]
     n = len(b["pos"])
-    res = {"value": n / dt, "unit": "points/sec", "cores": threads, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
-           "kind": "port",
-           "sample": "1 of %d tiles (%d voxels, median of %d passes after 1 warm-up: %.2f s): C/OpenMP oracle "
-                     "U-Net+heads+region_grow+scorer, %s MeanShift" % (len(tiles), n, repeats, dt, "sklearn" if use_sk else "oracle"),
+    t_net_batch = dt * n_batch / n
+    timings = dict(timings)
+    timings["meanshift"] = t_ms  # the fan-out over the whole batch (the per-tile passes reuse its result)
+    res = {"value": n_batch / (t_net_batch + t_ms), "unit": "points/sec", "cores": threads, "host_cpus": os.cpu_count(),
+           "cgroup_cpu_quota": quota, "kind": "port", "tiles_timed": len(chosen), "meanshift_processes": procs,
+           "sample": "batch of %d of %d tiles around the median size (%d voxels): %s MeanShift one sample per spawned process on %d "
+                     "processes (pool.map, %.2f s per batch) + C/OpenMP oracle U-Net+heads+region_grow+scorer on %d threads "
+                     "(median tile of %d voxels: %.2f s per pass, scaled by points to the batch: %.1f s); %d warm-ups, median "
+                     "of %d passes each" % (len(chosen), len(tiles), n_batch, "sklearn" if use_sk else "oracle", procs, t_ms,
+                                            threads, n, dt, t_net_batch, warmups, repeats),
            "stages_s": {k: round(v, 3) for k, v in timings.items()}}
     res["conv_GFLOPs"] = round(conv["flops"] / max(conv["seconds"], 1e-9) / 1e9, 1)  # sparse convolutions of both U-Nets
     return res, (b, (cls, off, emb), out, want_labels)
@@ -171,11 +216,19 @@ def _canonical(labels):
     return out
 
 
+def _scaled_err(a, b):
+    """max |a - b| as a fraction of b's magnitude (>= 1): the 1e-4 fp32 bar of north_star"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if a.size else 0.0
+
+
 def self_check(runner, batches, device, oracle_case):
     """Untimed correctness checks of the benchmark's own run (the 10 M-row kernel variants are not reachable from the
     unit tests' sizes): (1) batch invariance -- a tile of the 64-tile batch gives the same result as that tile run alone
     (instance labels bit-exact, semantic / embedding outputs 1e-4); (2) the median tile run alone equals the CPU oracle
-    pipeline (proposals bit-exact, scores 1e-3, instance labels equal after canonicalisation)."""
+    pipeline (proposals bit-exact, scores / embeddings / semantic log-probabilities within 1e-4 of their magnitude,
+    instance labels equal after canonicalisation -- the oracle's own scores, no substitution).  The measured errors are
+    reported in `checks["max_err"]`."""
     checks = {}
     ids, dev_b, override, starts, _ = batches[0]
     labels, res, counts = runner.run(dev_b, len(ids), override=override)
@@ -185,11 +238,13 @@ def self_check(runner, batches, device, oracle_case):
     ov1 = tuple(o[lo:hi] for o in override)
     l1, r1, c1 = runner.run(one, 1, override=ov1)
     ok_lab = bool(torch.equal(labels[lo:hi], l1)) and counts[j] == c1[0]
-    ok_sem = _close(res.semantic_logits[lo:hi].cpu().numpy(), r1.semantic_logits.cpu().numpy(), 1e-4, 1e-4)
-    ok_emb = _close(res.embed_logits[lo:hi].cpu().numpy(), r1.embed_logits.cpu().numpy(), 1e-4, 1e-4)
+    e_sem = _scaled_err(res.semantic_logits[lo:hi].cpu().numpy(), r1.semantic_logits.cpu().numpy())
+    e_emb = _scaled_err(res.embed_logits[lo:hi].cpu().numpy(), r1.embed_logits.cpu().numpy())
+    ok_sem, ok_emb = e_sem < 1e-4, e_emb < 1e-4
     checks["batch_invariance"] = "pass" if (ok_lab and ok_sem and ok_emb) else \
         "FAIL(labels=%s sem=%s emb=%s)" % (ok_lab, ok_sem, ok_emb)
     checks["batch_invariance_tile"] = {"tile": int(ids[j]), "rows": hi - lo, "instances": int(c1[0])}
+    checks["max_err"] = {"batch_vs_alone_semantic": e_sem, "batch_vs_alone_embeddings": e_emb}
     if oracle_case is None:
         checks["oracle"] = "skipped (--no-cpu-baseline)"
     else:
@@ -198,12 +253,15 @@ def self_check(runner, batches, device, oracle_case):
         lg, rg, cg = runner.run(dev_one, 1, override=tuple(torch.from_numpy(a).to(device) for a in ov))
         got = [c.cpu().numpy() for c in rg.clusters_csr.to_list()]
         ok_prop = len(got) == len(want["clusters"]) and all(np.array_equal(g, np.sort(w)) for g, w in zip(got, want["clusters"]))
-        ok_score = ok_prop and _close(rg.cluster_scores.cpu().numpy(), want["cluster_scores"], 1e-3, 1e-4)
-        ok_feat = _close(rg.embed_logits.cpu().numpy(), want["embed_logits"], 1e-3, 1e-4)
+        e_score = _scaled_err(rg.cluster_scores.cpu().numpy(), want["cluster_scores"]) if ok_prop else float("nan")
+        e_feat = _scaled_err(rg.embed_logits.cpu().numpy(), want["embed_logits"])
+        e_seml = _scaled_err(rg.semantic_logits.cpu().numpy(), want["semantic_logits"])
+        ok_score, ok_feat = ok_prop and e_score < 1e-4, e_feat < 1e-4 and e_seml < 1e-4
         ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()), _canonical(want_labels)))
         checks["oracle"] = "pass" if (ok_prop and ok_score and ok_feat and ok_inst) else \
             "FAIL(proposals=%s scores=%s embeddings=%s instances=%s)" % (ok_prop, ok_score, ok_feat, ok_inst)
         checks["oracle_tile"] = {"rows": len(b["pos"]), "proposals": len(got), "instances": int(cg[0])}
+        checks["max_err"].update({"oracle_scores": e_score, "oracle_embeddings": e_feat, "oracle_semantic": e_seml})
     checks["all"] = "pass" if all(not str(v).startswith("FAIL") for v in checks.values()) else "FAIL"
     return checks
 

@@ -123,17 +123,30 @@ def nms(ious, scores, threshold):
     return pick
 
 
-def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False):
-    """cluster_single of torch_points3d/utils/meanshift_cluster.py:72-123 (one MeanShift per batch element)."""
+def sklearn_meanshift_labels(args):
+    """the reference's worker (torch_points3d/utils/meanshift_cluster.py:9-18): one sample, sklearn MeanShift with bin
+    seeding.  Module-level so that a spawned multiprocessing.Pool can import it (the reference maps this function over the
+    samples of a batch, one process per sample, :96-101)."""
+    x, bandwidth = args
+    from sklearn.cluster import MeanShift
+    return MeanShift(bandwidth=bandwidth, bin_seeding=True).fit(x).labels_
+
+
+def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False, pool=None):
+    """cluster_single of torch_points3d/utils/meanshift_cluster.py:72-123 (one MeanShift per batch element; pool: the
+    samples are mapped over a multiprocessing.Pool as the reference does, :96-101)."""
     out = []
-    for s in np.unique(batch):
+    samples = [s for s in np.unique(batch) if (batch == s).sum() > 3]
+    pooled = None
+    if use_sklearn and pool is not None:
+        pooled = pool.map(sklearn_meanshift_labels, [(emb[batch == s], bandwidth) for s in samples])
+    for j, s in enumerate(samples):
         m = batch == s
-        if m.sum() <= 3:
-            continue
         x = emb[m]
-        if use_sklearn:
-            from sklearn.cluster import MeanShift
-            labels = MeanShift(bandwidth=bandwidth, bin_seeding=True).fit(x).labels_
+        if pooled is not None:
+            labels = pooled[j]
+        elif use_sklearn:
+            labels = sklearn_meanshift_labels((x, bandwidth))
         else:
             labels, _, _ = O.meanshift(x, [0, len(x)], bandwidth)
         li = local_ind[m]
@@ -144,7 +157,7 @@ def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False):
     return out
 
 
-def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=False, timings=None):
+def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=False, timings=None, ms_clusters=None):
     """Proposal generation of PointGroup3heads (PointGroup3heads.py:163-390): cluster_type 1 = region growing on the shifted
     points (nsample 200), 2 = on the raw positions (torch-points-kernels' default nsample 16) then on the shifted points,
     5 = shifted points then mean shift on the embeddings of the thing points, 6 = raw, shifted, mean shift.  Returns
@@ -164,7 +177,10 @@ def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=
     if ct in (5, 6):
         t0 = time.perf_counter()
         mask = ~np.isin(pred, ignore)
-        ms = meanshift_clusters(emb[mask], batch[mask], np.nonzero(mask)[0], float(opt["bandwidth"]), use_sklearn=use_sklearn_meanshift)
+        # ms_clusters: the mean-shift proposals of an earlier pass on the same inputs (bench.py times the embedding
+        # clustering separately, fanned out over processes as the reference does)
+        ms = list(ms_clusters) if ms_clusters is not None else meanshift_clusters(
+            emb[mask], batch[mask], np.nonzero(mask)[0], float(opt["bandwidth"]), use_sklearn=use_sklearn_meanshift)
         T["meanshift"] = time.perf_counter() - t0
     if ct == 1:
         return list(votes), [0] * len(votes)
@@ -177,7 +193,7 @@ def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=
     raise NotImplementedError("cluster_type %d" % ct)
 
 
-def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None):
+def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None, ms_clusters=None):
     """Eval forward of PointGroup3heads (setting IV / cluster_type 5 or type 1) on CPU.
     data: dict with pos [N,3], coords [N,3], batch [N], x [N,4].  Returns dict of outputs."""
     T = {} if timings is None else timings
@@ -192,7 +208,7 @@ def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklear
     T["heads"] = time.perf_counter() - t0
     if override is not None:
         pred, off, emb = override
-    clusters, ctype = group(data["pos"], data["batch"], pred, off, emb, opt, stuff_classes, use_sklearn_meanshift, T)
+    clusters, ctype = group(data["pos"], data["batch"], pred, off, emb, opt, stuff_classes, use_sklearn_meanshift, T, ms_clusters)
     clusters, ctype = list(clusters), list(ctype)
     scores = None
     if clusters:

@@ -65,8 +65,9 @@ def read_ply(path):
         return data
 
 
-def write_ply(path, fields, names):
-    """fields: list of arrays ([n] or [n, k], k columns get consecutive names); binary_little_endian, like the reference."""
+def write_ply(path, fields, names, text=False):
+    """fields: list of arrays ([n] or [n, k], k columns get consecutive names); binary_little_endian like the reference's
+    `write_ply` (models/panoptic/ply.py:116-315), or ascii (text=True) like its PlyData(..., text=True) writers."""
     cols = []
     for a in fields:
         a = np.asarray(a)
@@ -90,11 +91,24 @@ def write_ply(path, fields, names):
     if not path.endswith(".ply"):
         path += ".ply"
     with open(path, "wb") as f:
-        head = ["ply", "format binary_little_endian 1.0", "element vertex %d" % n]
+        head = ["ply", "format %s 1.0" % ("ascii" if text else "binary_little_endian"), "element vertex %d" % n]
         head += ["property %s %s" % (_PLY_NAMES[t[1:]], name) for name, t in dt]
         f.write(("\n".join(head) + "\nend_header\n").encode())
-        rec.tofile(f)
+        if text:
+            fmt = " ".join("%.9g" if t[1] == "f" else "%d" for _, t in dt)
+            np.savetxt(f, np.stack([rec[name].astype(np.float64) for name, _ in dt], 1), fmt=fmt)
+        else:
+            rec.tofile(f)
     return path
+
+
+def to_eval_ply(pos, pre_label, gt, path):
+    """The evaluation cloud `final_eval` reads back (torch_points3d/datasets/panoptic/npm3d.py:70-85): x, y, z float32 and
+    `preds` / `gt` int16, written as an ascii PLY like the reference's PlyData(..., text=True)."""
+    pos, pre_label, gt = np.asarray(pos, np.float32), np.asarray(pre_label), np.asarray(gt)
+    if pre_label.ndim != 1 or gt.ndim != 1 or len(pre_label) != len(pos) or len(gt) != len(pos):
+        raise ValueError("to_eval_ply: pos [n,3], pre_label [n], gt [n] expected")
+    return write_ply(path, [pos, pre_label.astype(np.int16), gt.astype(np.int16)], ["x", "y", "z", "preds", "gt"], text=True)
 
 
 def read_npm3d(path, with_labels=True):

@@ -145,15 +145,18 @@ _WS_CACHE = {}
 
 
 def _ws(nbytes, device, tag=None):
-    """Scratch buffer.  Large tagged workspaces are kept (grow-only) per device: re-allocating multi-GB blocks every call
-    makes the caching allocator split / re-hipMalloc them (measured: +270 ms per region_grow call)."""
+    """Scratch buffer.  Large tagged workspaces are kept (grow-only) per device AND stream: re-allocating multi-GB blocks
+    every call makes the caching allocator split / re-hipMalloc them (measured: +270 ms per region_grow call); the stream
+    is part of the key because worker threads launch the same tagged ops on side streams (map prefetch, mean shift next to
+    region growing) and nothing orders two streams' use of one scratch block."""
     nbytes = max(int(nbytes), 256)
     if tag is None or nbytes < (64 << 20):
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
-    key = (tag, str(device))
+    key = (tag, str(device), _stream().value)
     buf = _WS_CACHE.get(key)
     if buf is None or buf.numel() < nbytes:
-        _WS_CACHE[key] = buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _WS_CACHE[key] = buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
     return buf
 
 
@@ -781,17 +784,25 @@ def nms_paint(csr, n_points, batch, n_groups, scores, nms_threshold=0.3, min_clu
     return labels[: int(n_points)], counts[: int(n_groups)], rank[:P], pairs
 
 
-def histogram2d(a, b, na, nb):
+def histogram2d(a, b, na, nb, allow_skipped=True):
     """int64 [na, nb]: out[a[i], b[i]] += 1 over the rows with a >= 0 and b >= 0 (confusion matrix, instance x class
-    tables).  Labels outside [0, na) x [0, nb) raise (one host read of the error counters)."""
+    tables).  Returns the table on the HOST (numpy): the error counters travel in the same device->host copy, and labels
+    outside [0, na) x [0, nb) raise -- the NumPy form's bincount fails on them too, silently dropping them would change
+    the metrics.  allow_skipped=False: rows with a < 0 or b < 0 raise as well (a confusion matrix has none)."""
     lib = _lib.load()
     a = _need(a, torch.int64, "a")
     b = _need(b, torch.int64, "b")
-    out = torch.empty((int(na), int(nb)), dtype=torch.int64, device=a.device)
-    info = torch.zeros(2, dtype=torch.int32, device=a.device)
-    _lib.check(lib.pp_histogram2d(_ptr(a), _ptr(b), a.shape[0], int(na), int(nb), _ptr(out), _ptr(info), _stream()), "pp_histogram2d")
-    out.pp_info = info
-    return out
+    na, nb = int(na), int(nb)
+    buf = torch.empty(na * nb + 1, dtype=torch.int64, device=a.device)  # table + {skipped, out of range} as 2 x int32
+    info = buf[na * nb:].view(torch.int32)
+    _lib.check(lib.pp_histogram2d(_ptr(a), _ptr(b), a.shape[0], na, nb, _ptr(buf), _ptr(info), _stream()), "pp_histogram2d")
+    host = buf.cpu().numpy()
+    skipped, bad = (int(v) for v in host[na * nb:].view("int32"))
+    if bad:
+        raise _lib.PanopticHipError("histogram2d: %d labels outside [0, %d) x [0, %d)" % (bad, na, nb))
+    if skipped and not allow_skipped:
+        raise _lib.PanopticHipError("histogram2d: %d rows with a negative label" % skipped)
+    return host[: na * nb].reshape(na, nb)
 
 
 def pair_counts(a, b, nb, capacity=None):

@@ -166,7 +166,7 @@ def panoptic_evaluation_device(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes
     things = np.asarray(thing_classes, np.int64) + 1
     stuff = np.asarray(stuff_classes, np.int64) + 1
     # ---- semantic part: one confusion matrix (ground truth x prediction)
-    conf = ops.histogram2d(gs_all, ps_all, C, C).cpu().numpy().astype(np.float64)
+    conf = ops.histogram2d(gs_all, ps_all, C, C, allow_skipped=False).astype(np.float64)  # raises on labels < -1 or >= num_classes
     gt_cnt, pr_cnt, tp_cnt = conf.sum(1), conf.sum(0), np.diag(conf).copy()
     have = gt_cnt > 0
     iou = np.where(have, tp_cnt / np.maximum(gt_cnt + pr_cnt - tp_cnt, 1), 0.0)
@@ -187,7 +187,7 @@ def panoptic_evaluation_device(pred_sem, pred_ins, gt_sem, gt_ins, thing_classes
         k = int(u.numel())
         if k == 0:
             return full, np.zeros(0, np.int64), np.zeros(0, np.int64)
-        table = ops.histogram2d(full, sem, k, C).cpu().numpy()      # rows with full == -1 are skipped by the kernel
+        table = ops.histogram2d(full, sem, k, C)      # rows with full == -1 are skipped by the kernel
         return full, table.sum(1), table.argmax(1)
     pid, p_size, p_cls = groups(pi, ps)
     gid, g_size, g_cls = groups(gi, gs)

@@ -112,7 +112,9 @@ class SceneAssembler:
 class SceneAssemblerGPU:
     """SceneAssembler with every per-point array resident on the device: votes / prediction counts are index_add_'s, the
     order-dependent block merging is ops.block_merge (csrc/pp_eval.hip) chained on the stream -- no host round trip per
-    block; `finish()` reads the error counters once.  Results equal SceneAssembler's bit for bit."""
+    block; `finish()` reads the error counters once.  Results equal SceneAssembler's bit for bit PROVIDED the origin ids of
+    a block are distinct (a cylinder's points are distinct scene points; `finish()` checks it): both forms ACCUMULATE
+    repeated ids (np.add.at / index_add_), but the device adds them with float atomics in no fixed order."""
 
     def __init__(self, n_scene_points, num_classes, device):
         self.votes = torch.zeros((n_scene_points, num_classes), dtype=torch.float32, device=device)
@@ -120,12 +122,16 @@ class SceneAssemblerGPU:
         self.ins_pre = torch.full((n_scene_points,), -1, dtype=torch.int64, device=device)
         self._max_instance = torch.zeros(1, dtype=torch.int64, device=device)
         self._states = []
+        self._dup = torch.zeros((), dtype=torch.bool, device=device)
 
     def add_block(self, origin_ids, labels, semantic_logits=None):
         origin_ids = origin_ids.to(self.ins_pre.device).long()
         if semantic_logits is not None:
             self.votes.index_add_(0, origin_ids, semantic_logits.to(self.votes.device).float())
+        before = self.prediction_count[origin_ids]
         self.prediction_count.index_add_(0, origin_ids, torch.ones_like(origin_ids, dtype=torch.int32))
+        # a repeated id inside the block raises its count by more than one (device flag, read once in finish())
+        self._dup = self._dup | ((self.prediction_count[origin_ids] - before) != 1).any()
         self._states.append(ops.block_merge(origin_ids, labels.to(self.ins_pre.device).to(torch.int32), self.ins_pre,
                                             self._max_instance))
 
@@ -133,6 +139,8 @@ class SceneAssemblerGPU:
         for st in self._states:
             ops.block_merge_check(st)
         self._states = []
+        if bool(self._dup):
+            raise ValueError("SceneAssemblerGPU: a block repeated an origin id (votes would depend on the atomic order)")
         return self
 
     @property

@@ -105,3 +105,42 @@ def canon_partition(labels):
 def canon_clusters(clusters):
     cl = [np.sort(np.asarray(c, np.int64)) for c in clusters]
     return sorted([c.tolist() for c in cl], key=lambda c: (c[0], len(c)))
+
+
+def scaled_err(name, got, want):
+    """measured parity of a float output: max |got - want| as a fraction of the output's magnitude (north_star: 1e-4 fp32);
+    printed so that the GPU test log carries the numbers"""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want)
+    scale = max(1.0, float(np.abs(want).max()))
+    print("parity %-26s max abs err %.3e  output magnitude %.3f  -> %.3e of it   (rms err %.2e)" % (
+        name, err.max(), scale, err.max() / scale, np.sqrt((err ** 2).mean())))
+    return err.max() / scale
+
+
+class spread_scorer_head:
+    """with spread_scorer_head(lin, scores): ... -- rescales the ScorerHead's Linear layer from the scores of a first pass so
+    that the proposals' logits spread to mean 2.1 / unit variance (scores over roughly (0.55, 0.99)): a random-init head
+    squeezes all scores into a ~1e-3 band where float rounding decides the NMS / paint order.  Restores the layer on exit."""
+
+    def __init__(self, lin, scores):
+        import torch
+        self.lin, self.w0, self.b0 = lin, lin.weight.detach().clone(), lin.bias.detach().clone()
+        sc = scores.detach().double().clamp(1e-9, 1 - 1e-9)
+        z = torch.log(sc / (1 - sc)) - float(self.b0[0])  # w . f of every proposal
+        self.alpha = 1.0 / max(float(z.std()), 1e-9)
+        self.beta = 2.1 - self.alpha * float(z.mean())
+
+    def __enter__(self):
+        import torch
+        with torch.no_grad():
+            self.lin.weight.copy_(self.w0 * self.alpha)
+            self.lin.bias.fill_(self.beta)
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        with torch.no_grad():
+            self.lin.weight.copy_(self.w0)
+            self.lin.bias.copy_(self.b0)
+        return False

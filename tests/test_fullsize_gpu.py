@@ -213,3 +213,102 @@ def test_fused_shortcut_equals_two_launches(ops, level, c, ds_c, bf16):
     small = ops.spconv_fwd(h[:m].contiguous(), pk, nbr[:, :m].clamp(max=m - 1).contiguous(), m, c, 27, scale=sc, shift=sh, relu=True,
                            shortcut=(x[:m].contiguous(), pk1, sc1, sh1))
     assert small is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# numeric parity at full size: general weights, fp64 evaluation of SAMPLED output rows from the same map
+# (api_modules.py:9-82: convolution + BatchNorm + ReLU (+ residual, + cat) as ONE launch; north_star bar 1e-4)
+# ---------------------------------------------------------------------------------------------------------------------
+def _rows_fp64(x0, w, nbr, rows, x1=None, scale=None, shift=None, relu=False, residual=None, out_rows=None, bf16=False):
+    """out[rows] = epilogue(sum_k concat(x0, x1)[nbr[k][slot]] @ w[k]) in float64.  rows index the map's columns (slots);
+    out_rows = the physical output rows those slots write (residual rows).  bf16: operands rounded as the kernel rounds."""
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if bf16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    idx = nbr[:, rows].long()                                            # [27, S]
+    g = x[idx.clamp(min=0)].double() * (idx >= 0)[..., None]             # [27, S, Cin]
+    out = torch.einsum("ksc,kcd->sd", g, w.double())
+    if scale is not None:
+        out = out * scale.double() + shift.double()
+    if relu:
+        out = out.clamp(min=0)
+    if residual is not None:
+        out = out + residual[rows if out_rows is None else out_rows].double()
+    return out
+
+
+def _report(name, got, want):
+    err = (got.double() - want).abs()
+    scale = max(1.0, float(want.abs().max()))
+    mx, rel = float(err.max()), float((err / want.abs().clamp(min=1e-3)).max())
+    print("fullsize parity %-34s max abs err %.3e  (scale %.2f -> %.3e of it)  max rel err %.3e" % (name, mx, scale, mx / scale, rel))
+    return mx / scale
+
+
+@pytest.mark.parametrize("cin,cout,cat,bf16", [(16, 16, False, False), (32, 32, False, False), (64, 48, False, False),
+                                               (48, 48, True, False), (4, 16, False, False), (32, 32, False, True),
+                                               (64, 64, True, True)])
+def test_general_weight_convolution_vs_fp64_on_sampled_rows(ops, level, cin, cout, cat, bf16):
+    """same-level convolution with the fused epilogue (cat + BN + ReLU + residual) at the size where the 64-rows-per-wave /
+    unsplit variants are selected, against a float64 evaluation of 20 k sampled output rows; 1e-4 of the output magnitude"""
+    nbr, n = level["nbr"], level["n"]
+    g = torch.Generator(device="cuda").manual_seed(100 + cin + cout)
+    x0 = torch.randn((n, cin), device="cuda", generator=g)
+    x1 = torch.randn((n, cin), device="cuda", generator=g) if cat else None
+    w = torch.randn((27, cin * (2 if cat else 1), cout), device="cuda", generator=g) * (0.5 / np.sqrt(cin * (2 if cat else 1)))
+    sc, sh = torch.rand(cout, device="cuda", generator=g) + 0.5, torch.randn(cout, device="cuda", generator=g) * 0.3
+    res = torch.randn((n, cout), device="cuda", generator=g)
+    rows = torch.randint(0, n, (20_000,), device="cuda", generator=g)
+    got = ops.spconv_fwd(x0, ops.pack_weight(w), nbr, n, cout, 27, in1=x1, scale=sc, shift=sh, relu=True, residual=res, bf16=bf16)
+    want = _rows_fp64(x0, w, nbr, rows, x1=x1, scale=sc, shift=sh, relu=True, residual=res, bf16=bf16)
+    assert _report("same %d%s->%d%s" % (cin, "+%d" % cin if cat else "", cout, " bf16" if bf16 else ""), got[rows], want) < 1e-4
+
+
+@pytest.mark.parametrize("c,bf16", [(32, False), (64, False), (64, True)])
+def test_strided_and_transposed_convolutions_vs_fp64_on_sampled_rows(ops, level, c, bf16):
+    """strided (fine -> coarse) and transposed (coarse -> fine, slot-ordered map with row_order) launches of this size"""
+    coords, index, n = level["coords"], level["index"], level["n"]
+    cidx, cc = ops.block_index_coarsen(index, n)
+    nc = cc.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(7 + c)
+    w = torch.randn((27, c, c), device="cuda", generator=g) * (0.5 / np.sqrt(c))
+    xf, xc = torch.randn((n, c), device="cuda", generator=g), torch.randn((nc, c), device="cuda", generator=g)
+    down = ops.kernel_map_bi(cc, index, 3, 1, 1)
+    rows = torch.randint(0, nc, (20_000,), device="cuda", generator=g)
+    got = ops.spconv_fwd(xf, ops.pack_weight(w), down, nc, c, 27, relu=True, bf16=bf16)
+    assert _report("strided %d->%d%s" % (c, c, " bf16" if bf16 else ""), got[rows],
+                   _rows_fp64(xf, w, down, rows, relu=True, bf16=bf16)) < 1e-4
+    up = ops.kernel_map_transpose(down, n)                                # physical fine rows
+    order = ops.map_order(ops.map_mask(up))                               # its own slot order, as the coordinate manager builds it
+    up_s = ops.map_permute(up, order)
+    slots = torch.randint(0, n, (20_000,), device="cuda", generator=g)
+    got = ops.spconv_fwd(xc, ops.pack_weight(w), up_s, n, c, 27, row_order=order, bf16=bf16)
+    want = _rows_fp64(xc, w, up_s, slots, bf16=bf16)
+    assert _report("transposed %d->%d%s" % (c, c, " bf16" if bf16 else ""), got[order[slots].long()], want) < 1e-4
+
+
+def test_region_growing_tile_inside_full_batch_equals_oracle(ops, oracle):
+    """one tile of the 2 M-point batch through the literal sequential oracle: the batched launch must give that tile the
+    same clusters (bit-exact) as the CPU restatement run on the tile alone"""
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    import bench
+    scene, tiles, _ = bench.build_scene(2_000_000, 4, 0.05, 2022)
+    b = syn.tile_batch(scene, tiles, list(range(len(tiles))))
+    cls, off, _ = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(1))
+    shifted = (b["pos"] + off).astype(np.float32)
+    pos, pred, batch = torch.from_numpy(shifted).cuda(), torch.from_numpy(cls).cuda(), torch.from_numpy(b["batch"]).cuda()
+    ignore = torch.tensor(syn.NPM3D_STUFF)
+    csr, pc = ops.region_grow_csr(pos, pred, batch, ignore, 200, 0.075, 10, syn.NPM3D_NUM_CLASSES)
+    sizes = np.bincount(b["batch"])
+    t = int(np.argsort(sizes)[len(sizes) // 2])                           # the median tile
+    m = b["batch"] == t
+    local = np.nonzero(m)[0]
+    want, _ = oracle.region_grow(shifted[m], cls[m].astype(np.int64), np.zeros(int(m.sum()), np.int64),
+                                 ignore_labels=syn.NPM3D_STUFF, nsample=200, radius=0.075, min_cluster_size=10)
+    got = [c.cpu().numpy() for c in csr.to_list()]
+    got_t = [c for c in got if m[c[0]]]
+    assert len(got_t) == len(want) and len(want) > 3
+    for gc, wc in zip(got_t, want):
+        assert np.array_equal(gc, local[np.sort(np.asarray(wc))])
+    print("fullsize parity region growing: tile %d (%d points, %d clusters) inside a %d-point batch = oracle" % (
+        t, int(m.sum()), len(want), len(m)))
