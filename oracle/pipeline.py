@@ -97,6 +97,38 @@ def unet_forward(sd, prefix, down_strides, up_strides, n_blocks, coords, feats):
     return x
 
 
+def encoder_forward(sd, prefix, down_strides, n_blocks, coords, feats):
+    """MinkowskiEncoder (applications/minkowski.py:129-156): the down modules, then the innermost GlobalBaseModule -- a
+    Linear + BatchNorm + LeakyReLU(0.2) MLP per point and a per-batch-element maximum (core/base_conv/message_passing.py:
+    132-151).  Returns f32 [n_batch, C] in batch order."""
+    maps = Maps(coords)
+    x, ts = np.ascontiguousarray(feats, np.float32), 1
+    for i, st in enumerate(down_strides):
+        x, ts = _level(sd, "%s.down_modules.%d" % (prefix, i), maps, x, ts, st, False, n_blocks)
+    x = mlp_forward(sd, prefix + ".inner_modules.0.nn", x)
+    b = maps.levels[ts][:, 0].astype(np.int64)
+    out, _ = O.segment_reduce(x, b, int(coords[:, 0].max()) + 1, "max")
+    return out
+
+
+def mlp_forward(sd, p, x, slope=0.2):
+    """core/common_modules/base_modules.py:35-45: [Linear(bias) -> BatchNorm1d (eval) -> LeakyReLU(0.2)] per layer."""
+    i = 0
+    x = np.asarray(x, np.float32)
+    while "%s.%d.0.weight" % (p, i) in sd:
+        q = "%s.%d" % (p, i)
+        y = x.astype(np.float64) @ _np(sd[q + ".0.weight"]).astype(np.float64).T
+        if q + ".0.bias" in sd:
+            y = y + _np(sd[q + ".0.bias"]).astype(np.float64)
+        bn = q + ".1.batch_norm"
+        w, b = _np(sd[bn + ".weight"]).astype(np.float64), _np(sd[bn + ".bias"]).astype(np.float64)
+        m, v = _np(sd[bn + ".running_mean"]).astype(np.float64), _np(sd[bn + ".running_var"]).astype(np.float64)
+        y = (y - m) / np.sqrt(v + 1e-5) * w + b
+        x = np.where(y > 0, y, slope * y).astype(np.float32)
+        i += 1
+    return x
+
+
 def _head(sd, p, x, log_softmax=False):
     bn = p + ".0.0.1.batch_norm"
     w, b = _np(sd[bn + ".weight"]), _np(sd[bn + ".bias"])
@@ -160,6 +192,7 @@ def meanshift_clusters(emb, batch, local_ind, bandwidth, use_sklearn=False, pool
 def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=False, timings=None, ms_clusters=None):
     """Proposal generation of PointGroup3heads (PointGroup3heads.py:163-390): cluster_type 1 = region growing on the shifted
     points (nsample 200), 2 = on the raw positions (torch-points-kernels' default nsample 16) then on the shifted points,
+    3 = mean shift on the embeddings of the thing points alone, 4 = raw positions then mean shift,
     5 = shifted points then mean shift on the embeddings of the thing points, 6 = raw, shifted, mean shift.  Returns
     (clusters, cluster_type codes) in the reference's order; _cluster2 marks the votes as type 1 only when there are
     position clusters (:208-210).  Pinned on the reference's own functions: tests/golden/proposal_cases.npz."""
@@ -168,13 +201,15 @@ def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=
     ignore = [-1] + [int(c) for c in stuff_classes]
     radius = float(opt["cluster_radius_search"])
     pos_cl = []
-    if ct in (2, 6):
+    if ct in (2, 4, 6):
         pos_cl, _ = O.region_grow(pos, pred, batch, ignore, nsample=16, radius=radius, min_cluster_size=10)
-    t0 = time.perf_counter()
-    votes, _ = O.region_grow(pos + off, pred, batch, ignore, nsample=200, radius=radius, min_cluster_size=10)
-    T["region_grow"] = time.perf_counter() - t0
+    votes = []
+    if ct in (1, 2, 5, 6):
+        t0 = time.perf_counter()
+        votes, _ = O.region_grow(pos + off, pred, batch, ignore, nsample=200, radius=radius, min_cluster_size=10)
+        T["region_grow"] = time.perf_counter() - t0
     ms = []
-    if ct in (5, 6):
+    if ct in (3, 4, 5, 6):
         t0 = time.perf_counter()
         mask = ~np.isin(pred, ignore)
         # ms_clusters: the mean-shift proposals of an earlier pass on the same inputs (bench.py times the embedding
@@ -186,6 +221,10 @@ def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=
         return list(votes), [0] * len(votes)
     if ct == 2:
         return list(pos_cl) + list(votes), [0] * len(pos_cl) + [1 if len(pos_cl) else 0] * len(votes)
+    if ct == 3:  # mean shift on the embeddings alone (PointGroup3heads.py:213-243)
+        return ms, [0] * len(ms)
+    if ct == 4:  # raw positions (default nsample) + mean shift (:246-289)
+        return list(pos_cl) + ms, [0] * len(pos_cl) + [1] * len(ms)
     if ct == 5:
         return list(votes) + ms, [0] * len(votes) + [1] * len(ms)
     if ct == 6:
@@ -193,7 +232,8 @@ def group(pos, batch, pred, off, emb, opt, stuff_classes, use_sklearn_meanshift=
     raise NotImplementedError("cluster_type %d" % ct)
 
 
-def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None, ms_clusters=None):
+def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklearn_meanshift=False, timings=None, ms_clusters=None,
+            scorer_type="unet"):
     """Eval forward of PointGroup3heads (setting IV / cluster_type 5 or type 1) on CPU.
     data: dict with pos [N,3], coords [N,3], batch [N], x [N,4].  Returns dict of outputs."""
     T = {} if timings is None else timings
@@ -216,8 +256,13 @@ def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklear
         pts = np.concatenate(clusters)
         b = np.concatenate([np.full(len(c), i) for i, c in enumerate(clusters)])
         sc_coords = np.concatenate([b[:, None], data["coords"][pts]], 1).astype(np.int32)
-        sf = unet_forward(sd, "ScorerUnet", [2, 2], [2, 2], 2, sc_coords, feats[pts])
-        cf, _ = O.segment_reduce(sf, b, len(clusters), "max")
+        if scorer_type == "MLP":      # PointGroup3heads.py:419-423
+            cf, _ = O.segment_reduce(mlp_forward(sd, "ScorerMLP", feats[pts]), b, len(clusters), "max")
+        elif scorer_type == "encoder":  # :424-426
+            cf = encoder_forward(sd, "ScorerEncoder", [2, 2], 2, sc_coords, feats[pts])
+        else:
+            sf = unet_forward(sd, "ScorerUnet", [2, 2], [2, 2], 2, sc_coords, feats[pts])
+            cf, _ = O.segment_reduce(sf, b, len(clusters), "max")
         w, bb = _np(sd["ScorerHead.0.weight"]), _np(sd["ScorerHead.0.bias"])
         scores = 1.0 / (1.0 + np.exp(-(cf @ w.T + bb)[:, 0]))
         T["scorer"] = time.perf_counter() - t0

@@ -2,8 +2,8 @@
 U-Net, region growing / mean shift proposals, ScorerUnet), on the MI355X kernels.
 
 Mirrors torch_points3d/models/panoptic/PointGroup3heads.py: constructor arguments and sub-module names
-(=> state_dict keys of SURVEY.md App. A), set_input :95-99, forward :101-157, _cluster/_cluster2/_cluster5/_cluster6
-:163-210,291-391, _compute_score :393-454, _compute_loss :552-634, backward :636-639.
+(=> state_dict keys of SURVEY.md App. A), set_input :95-99, forward :101-157, _cluster/_cluster2/_cluster3/_cluster4/
+_cluster5/_cluster6 :163-391, _compute_score :393-454, _compute_loss :552-634, backward :636-639.
 
 What is different by design (MI355X-first, results unchanged): everything stays device-resident -- proposals travel
 as CSR (ops.ClusterCSR) instead of Python lists until the caller asks for lists; mean shift runs for all cylinders of
@@ -175,7 +175,7 @@ class PointGroup3heads(nn.Module):
 
     # ------------------------------------------------------------------ proposal generators
     def _cluster_fns(self):
-        return {1: self._cluster, 2: self._cluster2, 5: self._cluster5, 6: self._cluster6}
+        return {1: self._cluster, 2: self._cluster2, 3: self._cluster3, 4: self._cluster4, 5: self._cluster5, 6: self._cluster6}
 
     def _grow(self, pos, pred, nsample):
         kw = {} if nsample is None else {"nsample": nsample}  # reference leaves the default (16) for raw coordinates
@@ -204,6 +204,19 @@ class PointGroup3heads(nn.Module):
         votes = self._grow(self.raw_pos + off, pred, 200)
         # (the reference marks the votes as type 1 only when there are position clusters: PointGroup3heads.py:208-210)
         return ops.ClusterCSR.concat([pos, votes]), self._types([(pos, 0), (votes, 1 if pos.n else 0)], pred.device)
+
+    def _cluster3(self, pred, off, emb):
+        """mean shift on the embeddings of the thing points alone (reference :213-243; `off` is unused: the reference's
+        signature is (semantic_logits, embed_logits))"""
+        embed = self._embed_clusters(pred, emb)
+        return embed, self._types([(embed, 0)], pred.device)
+
+    def _cluster4(self, pred, off, emb):
+        """region growing on the raw positions (library-default nsample) + mean shift on the embeddings (reference :246-289)"""
+        pending = self._embed_clusters_async(pred, emb)
+        pos = self._grow(self.raw_pos, pred, None)
+        embed = pending() if pending is not None else self._embed_clusters(pred, emb)
+        return ops.ClusterCSR.concat([pos, embed]), self._types([(pos, 0), (embed, 1)], pred.device)
 
     def _lap(self, name):
         if getattr(self, "_timer", None) is not None:
@@ -265,8 +278,8 @@ class PointGroup3heads(nn.Module):
                 b = torch.repeat_interleave(torch.arange(csr.n, device=sizes.device), sizes)
                 mean_sem = scatter(semantic_logits[csr.points], b, dim=0, reduce="mean", dim_size=csr.n)
                 return torch.max(torch.exp(mean_sem), 1)[0], None
-        if self._scorer_type not in ("unet",):
-            raise NotImplementedError("scorer_type %s (published settings use 'unet')" % self._scorer_type)
+        if self._scorer_type not in ("unet", "MLP", "encoder"):
+            raise NotImplementedError("scorer_type %s (the reference knows 'unet', 'MLP' and 'encoder')" % self._scorer_type)
         if self.dedupe_proposals and not torch.is_grad_enabled() and csr.n > 1:
             # Region growing and mean shift often return the SAME point set for a well-separated instance; identical
             # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set
@@ -306,9 +319,21 @@ class PointGroup3heads(nn.Module):
             pts = csr.points[p0:p1]
             b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi], output_size=p1 - p0)
             # one gather for "rows of the proposals" + "internal row order", none for the way back (the max is order-free)
-            batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
-            out = self.ScorerUnet(batch_cluster, internal_order=True)
-            cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo)
+            if self._scorer_type == "MLP":
+                # per-point MLP on the proposals' backbone rows, then the per-proposal maximum (reference :419-423)
+                rows = backbone_features[pts] if not isinstance(backbone_features, ME.GatheredRows) \
+                    else ME.GatheredRows(backbone_features, pts).materialise()
+                cluster_feats = scatter(self.ScorerMLP(rows), b, dim=0, reduce="max", dim_size=hi - lo)
+            elif self._scorer_type == "encoder":
+                # sparse encoder with a global max-pool head: one feature row per proposal, in batch order (:424-426)
+                batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
+                cluster_feats = self.ScorerEncoder(batch_cluster).x
+                if cluster_feats.shape[0] != hi - lo:
+                    raise RuntimeError("ScorerEncoder returned %d rows for %d proposals" % (cluster_feats.shape[0], hi - lo))
+            else:
+                batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
+                out = self.ScorerUnet(batch_cluster, internal_order=True)
+                cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo)
             # Linear(16, 1) + Sigmoid written as a reduction: a [P,16]x[16,1] GEMM goes through hipBLASLt, whose
             # dispatch costs milliseconds of host time per call for 0.1 ms of work
             lin = self.ScorerHead[0]

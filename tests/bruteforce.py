@@ -144,3 +144,32 @@ class spread_scorer_head:
             self.lin.weight.copy_(self.w0)
             self.lin.bias.copy_(self.b0)
         return False
+
+
+def near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5):
+    """Points whose instance label is decided by a score comparison closer than `eps`: two overlapping proposals
+    (IoU > nms_threshold; region growing and mean shift often return NEARLY the same point set for one object, whose
+    max-pooled scorer features -- hence scores -- then agree to the last bits whatever the scorer head's scale) with
+    |score_i - score_j| < eps, or a score within eps of the `min_score` filter.  Which of such a pair survives the NMS is
+    decided by float rounding, legitimately differently in two correct implementations; everything else must agree."""
+    amb = np.zeros(n_points, bool)
+    if not clusters:
+        return amb
+    scores = np.asarray(scores, np.float64)
+    owner = [[] for _ in range(n_points)]
+    for i, c in enumerate(clusters):
+        for p in np.asarray(c).tolist():
+            owner[p].append(i)
+    pairs = {}
+    for lst in owner:
+        for a in range(len(lst)):
+            for b in range(a + 1, len(lst)):
+                pairs[(lst[a], lst[b])] = pairs.get((lst[a], lst[b]), 0) + 1
+    for (i, j), inter in pairs.items():
+        iou = inter / (len(clusters[i]) + len(clusters[j]) - inter)
+        if iou > nms_threshold and abs(scores[i] - scores[j]) < eps:
+            amb[np.asarray(clusters[i])] = True
+            amb[np.asarray(clusters[j])] = True
+    for i in np.nonzero(np.abs(scores - min_score) < eps)[0]:
+        amb[np.asarray(clusters[i])] = True
+    return amb

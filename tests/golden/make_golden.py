@@ -438,8 +438,8 @@ def make_block_merging():
 
 
 def make_proposals():
-    """Proposal generation of the reference model: PointGroup3heads._cluster / _cluster2 / _cluster5 / _cluster6
-    (torch_points3d/models/panoptic/PointGroup3heads.py:163-390) extracted with `ast` and executed here, with the
+    """Proposal generation of the reference model: PointGroup3heads._cluster / _cluster2 / _cluster3 / _cluster4 / _cluster5 /
+    _cluster6 (torch_points3d/models/panoptic/PointGroup3heads.py:163-390) extracted with `ast` and executed here, with the
     reference's OWN utils/meanshift_cluster.py (sklearn MeanShift workers) behind them.  torch_points_kernels.region_grow
     (absent library) is the one stand-in: the CPU oracle's restatement with tpk's defaults (nsample 16) -- its own output is
     part of the fixture only through these functions.  Pins: which coordinates / nsample every call uses, the order in which
@@ -454,7 +454,7 @@ def make_proposals():
     path = os.path.join(REF, "torch_points3d/models/panoptic/PointGroup3heads.py")
     tree = ast.parse(open(path).read())
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PointGroup3heads"][0]
-    wanted = ("_cluster", "_cluster2", "_cluster5", "_cluster6")
+    wanted = ("_cluster", "_cluster2", "_cluster3", "_cluster4", "_cluster5", "_cluster6")
     fns = [m for m in cls.body if isinstance(m, ast.FunctionDef) and m.name in wanted]
 
     def region_grow(pos, labels, batch, ignore_labels=[], radius=0.02, nsample=16, min_cluster_size=32):
@@ -488,7 +488,10 @@ def make_proposals():
             cases["%s_%s" % (k, name)] = v
         cases["radius_" + name], cases["bandwidth_" + name] = np.float64(0.3), np.float64(0.6)
         for fn_name in wanted:
-            args = [torch.from_numpy(sem), torch.from_numpy(off)] + ([torch.from_numpy(emb)] if fn_name in ("_cluster5", "_cluster6") else [])
+            if fn_name in ("_cluster3", "_cluster4"):   # (semantic_logits, embed_logits): mean shift alone / raw positions + mean shift
+                args = [torch.from_numpy(sem), torch.from_numpy(emb)]
+            else:
+                args = [torch.from_numpy(sem), torch.from_numpy(off)] + ([torch.from_numpy(emb)] if fn_name in ("_cluster5", "_cluster6") else [])
             cl, ct = ns[fn_name](me, *args)
             tag = "%s%s" % (name, fn_name)
             cases["offsets_" + tag] = np.cumsum([0] + [len(c) for c in cl]).astype(np.int64)

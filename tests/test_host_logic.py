@@ -196,14 +196,14 @@ def test_oracle_painting_matches_the_reference_tracker(oracle):
 @pytest.mark.parametrize("use_sklearn", [True, False])
 def test_oracle_proposal_generation_matches_the_reference_model(oracle, use_sklearn):
     """oracle/pipeline.group (the checker of the model's _cluster* functions) vs the proposals the reference's OWN
-    PointGroup3heads._cluster / _cluster2 / _cluster5 / _cluster6 produce (tests/golden/proposal_cases.npz, generated by
+    PointGroup3heads._cluster / _cluster2 / _cluster3 / _cluster4 / _cluster5 / _cluster6 produce (tests/golden/proposal_cases.npz, generated by
     executing those methods with the reference's mean-shift module; make_golden.py): same proposals in the same order, same
     cluster_type codes, with sklearn's MeanShift and with the oracle's own mean shift behind it."""
     from oracle import pipeline as opipe
     z = np.load(os.path.join(ROOT, "tests", "golden", "proposal_cases.npz"))
     for name in z["names"].tolist():
         pos, off, emb, pred, batch = (z["%s_%s" % (k, name)] for k in ("pos", "off", "emb", "pred", "batch"))
-        for fn, ct in (("_cluster", 1), ("_cluster2", 2), ("_cluster5", 5), ("_cluster6", 6)):
+        for fn, ct in (("_cluster", 1), ("_cluster2", 2), ("_cluster3", 3), ("_cluster4", 4), ("_cluster5", 5), ("_cluster6", 6)):
             opt = {"cluster_type": ct, "cluster_radius_search": float(z["radius_" + name]), "bandwidth": float(z["bandwidth_" + name])}
             clusters, types = opipe.group(pos, batch, pred, off, emb, opt, [0, 1, 5], use_sklearn_meanshift=use_sklearn)
             tag = name + fn

@@ -103,7 +103,7 @@ def test_pointgroupembed_setting_i_and_hdbscan(oracle):
 
 
 def test_cluster_functions_match_the_reference_model():
-    """PointGroup3heads._cluster / _cluster2 / _cluster5 / _cluster6 on the device vs the proposals the reference's OWN
+    """PointGroup3heads._cluster / _cluster2 / _cluster3 / _cluster4 / _cluster5 / _cluster6 on the device vs the proposals the reference's OWN
     functions produce on the same inputs (tests/golden/proposal_cases.npz: the reference's methods + its mean-shift module
     executed by make_golden.py, torch-points-kernels' region_grow stood in by the CPU oracle): same proposals, same order,
     same cluster_type codes -- incl. the case where the raw positions give no cluster and _cluster2 labels the votes 0."""
@@ -118,7 +118,7 @@ def test_cluster_functions_match_the_reference_model():
         model.set_input(Data(pos=pos, coords=coords, batch=batch, x=torch.zeros((n, 4), device="cuda")), torch.device("cuda"))
         model.opt.cluster_radius_search = float(z["radius_" + name])
         model.opt.bandwidth = float(z["bandwidth_" + name])
-        for fn in ("_cluster", "_cluster2", "_cluster5", "_cluster6"):
+        for fn in ("_cluster", "_cluster2", "_cluster3", "_cluster4", "_cluster5", "_cluster6"):
             with torch.no_grad():
                 csr, types = getattr(model, fn)(pred, off, emb)
             tag = name + fn
