@@ -22,13 +22,77 @@ def offset_loss(pred_offsets, gt_offsets, total_instance_points):
     return {"offset_norm_loss": l1.sum() / denom, "offset_dir_loss": (-cosine).sum() / denom}
 
 
+def _proposal_rows(predicted_clusters, clusters_csr, device):
+    """(points int64 [R], proposal id int64 [R], n_proposals): the proposals' rows concatenated in proposal order"""
+    if clusters_csr is not None:
+        sizes = clusters_csr.sizes().long()
+        return clusters_csr.points.long(), torch.repeat_interleave(torch.arange(clusters_csr.n, device=device), sizes), clusters_csr.n
+    pts = torch.cat([c.to(device) for c in predicted_clusters]).long()
+    pid = torch.cat([torch.full((len(c),), i, dtype=torch.int64, device=device) for i, c in enumerate(predicted_clusters)])
+    return pts, pid, len(predicted_clusters)
+
+
+def _gt_layout(instance_labels, batch):
+    """per batch element: number of ground-truth instances (= its largest id) and the offset of its first column"""
+    nb = int(batch[-1]) + 1
+    k = scatter(instance_labels.long(), batch.long(), dim=0, reduce="max", dim_size=nb)
+    off = torch.cumsum(k, 0) - k
+    return k, off, int(k.sum())
+
+
+def mask_instance_ious(predicted_clusters, instance_labels, batch, mask_scores_sigmoid, clusters_csr=None):
+    """IoU of every proposal's MASKED points (mask score > 0.5) with every ground-truth instance of its batch element
+    (panoptic_losses.py:35-88): intersection / (masked proposal points + instance size - intersection + 1e-5); columns of
+    other batch elements stay 0.  One scatter instead of the reference's proposals x instances Python loop."""
+    dev = instance_labels.device
+    if batch is None:
+        batch = torch.zeros_like(instance_labels)
+    pts, pid, n_prop = _proposal_rows(predicted_clusters, clusters_csr, dev)
+    k, off, total = _gt_layout(instance_labels, batch)
+    inst, b = instance_labels.long(), batch.long()
+    col_all = off[b] + inst - 1                                   # column of every point's own instance (inst >= 1)
+    gt_size = torch.zeros(total, dtype=torch.float32, device=dev).index_add_(0, col_all[inst > 0], torch.ones(int((inst > 0).sum()), device=dev))
+    keep = mask_scores_sigmoid.reshape(-1) > 0.5
+    prop_total = torch.zeros(n_prop, dtype=torch.float32, device=dev).index_add_(0, pid[keep], torch.ones(int(keep.sum()), device=dev))
+    hit = keep & (inst[pts] > 0)
+    inter = torch.zeros(n_prop * max(total, 1), dtype=torch.float32, device=dev)
+    inter.index_add_(0, pid[hit] * total + col_all[pts[hit]], torch.ones(int(hit.sum()), device=dev))
+    inter = inter[: n_prop * total].view(n_prop, total)
+    # the reference fills only the columns of the proposal's own batch element (of its first point)
+    sample = b[pts[torch.cat([torch.zeros(1, dtype=torch.bool, device=dev), pid[1:] == pid[:-1]]).logical_not()]]
+    cols = torch.arange(total, device=dev)
+    own = (cols[None, :] >= off[sample][:, None]) & (cols[None, :] < (off[sample] + k[sample])[:, None])
+    ious = inter / (prop_total[:, None] + gt_size[None, :] - inter + 1e-5)
+    return torch.where(own, ious, torch.zeros_like(ious))
+
+
 def instance_ious(predicted_clusters, cluster_scores, instance_labels, batch, mask_scores_sigmoid=None,
                   cal_iou_based_on_mask=False, clusters_csr=None):
     if cal_iou_based_on_mask:
-        raise NotImplementedError("mask-based IoU (mask_supervise) is not enabled by any published setting")
+        assert mask_scores_sigmoid is not None
+        return mask_instance_ious(predicted_clusters, instance_labels, batch, mask_scores_sigmoid, clusters_csr)
     if clusters_csr is not None:
         return instance_iou_csr(clusters_csr, instance_labels, batch)
     return instance_iou(predicted_clusters, instance_labels, batch)
+
+
+def mask_loss(ious, predicted_clusters, mask_scores_sigmoid, instance_labels, batch, clusters_csr=None):
+    """BCE of the per-point mask scores of the proposals whose best IoU exceeds 0.5: target 1 on the points of that
+    best-matching ground-truth instance, 0 on the proposal's other points; points of all other proposals get weight 0
+    (their target value 0.5 is irrelevant); mean over ALL proposal points (panoptic_losses.py:156-201)."""
+    dev = instance_labels.device
+    pts, pid, n_prop = _proposal_rows(predicted_clusters, clusters_csr, dev)
+    k, off, total = _gt_layout(instance_labels, batch)
+    best, col = ious.max(1)
+    # column -> instance id inside its batch element: col + 1 - (largest offset strictly below col + 1)
+    idx1 = col + 1
+    below = off[None, :] < idx1[:, None]
+    base = torch.where(below, off[None, :], torch.full_like(off[None, :], -1)).max(1)[0]
+    local_id = idx1 - base
+    supervised = best > 0.5
+    w = supervised[pid].float()
+    target = torch.where(supervised[pid], (instance_labels.long()[pts] == local_id[pid]).float(), torch.full((pts.shape[0],), 0.5, device=dev))
+    return torch.nn.functional.binary_cross_entropy(mask_scores_sigmoid.reshape(-1), target, weight=w)
 
 
 def instance_iou_loss(ious, predicted_clusters, cluster_scores, instance_labels, batch, min_iou_threshold=0.25,

@@ -24,7 +24,7 @@ from ..modules import MLP, Seq, fused_head, head_spec
 from ..torch_points_kernels import region_grow_csr
 from ..torch_scatter import gather, scatter
 from ..utils import meanshift_cluster
-from .losses import discriminative_loss, instance_iou_loss, instance_ious, offset_loss
+from .losses import discriminative_loss, instance_iou_loss, instance_ious, mask_loss, offset_loss
 from .structures import PanopticLabels, PanopticResults
 
 IGNORE_LABEL = -1  # torch_points3d/datasets/segmentation/__init__.py
@@ -56,6 +56,9 @@ class PointGroup3heads(nn.Module):
             self.MaskScore = (Seq().append(nn.Linear(self.ScorerUnet.output_nc, self.ScorerUnet.output_nc))
                               .append(nn.ReLU()).append(nn.Linear(self.ScorerUnet.output_nc, 1)))
         self.use_score_net = option.get("use_score_net", True)
+        self.use_mask_filter_score_feature = option.get("use_mask_filter_score_feature", False)
+        self.use_mask_filter_score_feature_start_epoch = option.get("use_mask_filter_score_feature_start_epoch", 200)
+        self.mask_filter_score_feature_thre = option.get("mask_filter_score_feature_thre", 0.5)
         self.dedupe_proposals = True  # eval-only optimisation with identical results, see _compute_score
         self._side_streams = {}        # device -> HIP stream of the overlapped mean shift (see _embed_clusters_async)
         self.cal_iou_based_on_mask = option.get("cal_iou_based_on_mask", False)
@@ -280,7 +283,7 @@ class PointGroup3heads(nn.Module):
                 return torch.max(torch.exp(mean_sem), 1)[0], None
         if self._scorer_type not in ("unet", "MLP", "encoder"):
             raise NotImplementedError("scorer_type %s (the reference knows 'unet', 'MLP' and 'encoder')" % self._scorer_type)
-        if self.dedupe_proposals and not torch.is_grad_enabled() and csr.n > 1:
+        if self.dedupe_proposals and not torch.is_grad_enabled() and csr.n > 1 and not self.mask_supervise:
             # Region growing and mean shift often return the SAME point set for a well-separated instance; identical
             # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set
             # (results unchanged; the overlap pairs are reused by NMS).
@@ -304,12 +307,12 @@ class PointGroup3heads(nn.Module):
                 pos_of[uniq_ids] = torch.arange(uniq_ids.numel(), device=sz.device)
                 scores_u, _ = self._score_unique(csr.select(uniq_ids), backbone_features)
                 return scores_u[pos_of[rep]], None
-        return self._score_unique(csr, backbone_features)
+        return self._score_unique(csr, backbone_features, epoch)
 
-    def _score_unique(self, csr, backbone_features):
+    def _score_unique(self, csr, backbone_features, epoch=-1):
         sizes = csr.sizes()
         offsets = csr.offsets.long()
-        scores = []
+        scores, masks = [], []
         for lo in range(0, csr.n, MAX_SCORER_BATCH):
             hi = min(lo + MAX_SCORER_BATCH, csr.n)
             if lo == 0 and hi == csr.n:  # one chunk: all entries, no host read of the offsets
@@ -330,6 +333,17 @@ class PointGroup3heads(nn.Module):
                 cluster_feats = self.ScorerEncoder(batch_cluster).x
                 if cluster_feats.shape[0] != hi - lo:
                     raise RuntimeError("ScorerEncoder returned %d rows for %d proposals" % (cluster_feats.shape[0], hi - lo))
+            elif self.mask_supervise:
+                # mask-supervised scorer (reference :427-436): one mask logit per proposal ROW, in the order the proposals
+                # were concatenated (losses and trackers slice it by proposal) -- so the U-Net output is un-permuted here
+                batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
+                out = self.ScorerUnet(batch_cluster)
+                mask = self.MaskScore(out.x)
+                masks.append(mask)
+                x = out.x
+                if self.use_mask_filter_score_feature and epoch > self.use_mask_filter_score_feature_start_epoch:
+                    x = x * (torch.sigmoid(mask) >= self.mask_filter_score_feature_thre).to(x.dtype)
+                cluster_feats = scatter(x, b, dim=0, reduce="max", dim_size=hi - lo)
             else:
                 batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
                 out = self.ScorerUnet(batch_cluster, internal_order=True)
@@ -338,7 +352,8 @@ class PointGroup3heads(nn.Module):
             # dispatch costs milliseconds of host time per call for 0.1 ms of work
             lin = self.ScorerHead[0]
             scores.append(torch.sigmoid((cluster_feats * lin.weight[0]).sum(1) + lin.bias[0]))
-        return (scores[0] if len(scores) == 1 else torch.cat(scores)), None
+        mask_scores = None if not masks else (masks[0] if len(masks) == 1 else torch.cat(masks))
+        return (scores[0] if len(scores) == 1 else torch.cat(scores)), mask_scores
 
     # ------------------------------------------------------------------ losses / backward
     def _compute_loss(self, epoch):
@@ -357,13 +372,19 @@ class PointGroup3heads(nn.Module):
                 setattr(self, name, loss)
                 if name == "ins_loss":
                     self.loss = self.loss + self.opt.loss_weights.embedding_loss * loss
+        mask_sigmoid = None if out.mask_scores is None else torch.sigmoid(out.mask_scores).reshape(-1)
         if out.cluster_scores is not None and self._scorer_type and epoch > self.opt.prepare_epoch and self.use_score_net:
-            ious = instance_ious(out.clusters, out.cluster_scores, inp.instance_labels, inp.batch, None, False,
+            on_mask = bool(self.cal_iou_based_on_mask and epoch > self.cal_iou_based_on_mask_start_epoch)  # reference :592-611
+            ious = instance_ious(out.clusters, out.cluster_scores, inp.instance_labels, inp.batch, mask_sigmoid, on_mask,
                                  clusters_csr=out.clusters_csr)
             self.score_loss = instance_iou_loss(ious, out.clusters, out.cluster_scores, inp.instance_labels, inp.batch,
                                                 min_iou_threshold=self.opt.min_iou_threshold,
                                                 max_iou_threshold=self.opt.max_iou_threshold)
             self.loss = self.loss + self.score_loss * self.opt.loss_weights["score_loss"]
+            if mask_sigmoid is not None and self.mask_supervise:  # reference :626-634
+                self.mask_loss = mask_loss(ious, out.clusters, mask_sigmoid, inp.instance_labels, inp.batch,
+                                           clusters_csr=out.clusters_csr)
+                self.loss = self.loss + self.mask_loss * self.opt.loss_weights["mask_loss"]
 
     def backward(self, epoch):
         self._compute_loss(epoch)

@@ -26,6 +26,19 @@ def non_max_suppression(ious, scores, threshold):
     return kept
 
 
+def masked_csr(csr, mask_scores):
+    """proposals restricted to the points whose mask logit exceeds -0.5 (structure_3heads.py:36-54, the mask-supervised
+    scorer): same proposals, fewer points each.  mask_scores: one logit per proposal ROW ([R] or [R, 1])."""
+    if mask_scores is None:
+        return csr
+    keep = mask_scores.reshape(-1) > -0.5
+    sizes = csr.sizes().long()
+    pid = torch.repeat_interleave(torch.arange(csr.n, device=keep.device), sizes, output_size=keep.shape[0])
+    kept = torch.zeros(csr.n, dtype=torch.int64, device=keep.device).index_add_(0, pid[keep], torch.ones(int(keep.sum()), dtype=torch.int64, device=keep.device))
+    offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=keep.device), torch.cumsum(kept, 0)]).to(torch.int32)
+    return ops.ClusterCSR(offsets, csr.points[keep], csr.n)
+
+
 class PanopticResults(NamedTuple):
     semantic_logits: torch.Tensor
     offset_logits: torch.Tensor
@@ -49,7 +62,7 @@ class PanopticResults(NamedTuple):
             return [], []
         if self.cluster_scores is None:
             return None, self.clusters if self.clusters is not None else self._csr().to_list()
-        csr = self._csr()
+        csr = masked_csr(self._csr(), self.mask_scores)
         n_points = self.semantic_logits.shape[0]
         _, _, rank, pairs = ops.nms_paint(csr, n_points, None, 1, self.cluster_scores, nms_threshold, min_cluster_points,
                                           min_score)
@@ -57,7 +70,7 @@ class PanopticResults(NamedTuple):
         pairs.check()
         kept = np.nonzero(rank >= 0)[0]
         valid_pick_ids = [int(i) for i in kept[np.argsort(-rank[kept], kind="stable")]]  # pick order = descending score
-        clusters = self.clusters if self.clusters is not None else csr.to_list()
+        clusters = self.clusters if (self.clusters is not None and self.mask_scores is None) else csr.to_list()
         return valid_pick_ids, [clusters[i] for i in valid_pick_ids]
 
 

@@ -28,6 +28,9 @@ def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster
     Returns int32 labels [N] (-1 = none; ids restart at 0 in every tile) and the number of instances per tile."""
     n = batch.shape[0]
     csr = res.clusters_csr
+    if csr is not None and csr.n and res.mask_scores is not None:
+        from .panoptic.structures import masked_csr
+        csr = masked_csr(csr, res.mask_scores)  # mask-supervised scorer: points with mask logit <= -0.5 leave their proposal
     if csr is None or csr.n == 0:
         ops.gather_rows_check()
         return torch.full((n,), -1, dtype=torch.int32, device=batch.device), [0] * n_tiles

@@ -151,6 +151,43 @@ def make_losses():
     print("losses:", float(ol["offset_norm_loss"]), float(ol["offset_dir_loss"]), float(dl["ins_loss"]), float(sl))
 
 
+def make_mask_losses():
+    """The mask-supervised branch of the reference's losses (core/losses/panoptic_losses.py:25-90 with
+    cal_iou_based_on_mask=True, mask_loss :156-201), executed here on seeded inputs -> mask_loss_cases.npz."""
+    _stub_modules()
+    L = _load(os.path.join(REF, "torch_points3d/core/losses/panoptic_losses.py"), "ref_panoptic_losses")
+    g = torch.Generator().manual_seed(4)
+    n = 1200
+    batch = torch.cat([torch.zeros(n // 3), torch.ones(n // 3), 2 * torch.ones(n - 2 * (n // 3))]).long()
+    inst = torch.randint(0, 5, (n,), generator=g)  # 0 = no instance, 1..4 in every batch element
+    clusters = []
+    for p in range(15):
+        b = p % 3
+        pool = torch.nonzero(batch == b).view(-1)
+        if p < 9:   # mostly one ground-truth instance (IoU > 0.5 -> supervised mask), plus a few strangers
+            own = pool[inst[pool] == 1 + p % 4]
+            other = pool[inst[pool] != 1 + p % 4]
+            sel = torch.cat([own[torch.randperm(own.numel(), generator=g)[: int(0.9 * own.numel())]],
+                             other[torch.randperm(other.numel(), generator=g)[: 5 + p]]])
+        else:       # random subsets (IoU < 0.5 -> weight 0)
+            sel = pool[torch.randperm(pool.numel(), generator=g)[: 40 + 3 * p]]
+        clusters.append(torch.sort(sel)[0])
+    n_rows = sum(len(c) for c in clusters)
+    # mask logits of a half-trained MaskScore: positive on the proposal's dominant instance, negative elsewhere, noisy
+    dom = torch.cat([(inst[c] == torch.mode(inst[c])[0]).float() for c in clusters])
+    mask_logits = ((dom * 2 - 1) * 1.5 + torch.randn(n_rows, generator=g) * 1.5).unsqueeze(1)
+    scores = torch.rand(15, generator=g)
+    sig = torch.sigmoid(mask_logits).squeeze(-1)
+    ious = L.instance_ious(clusters, scores, inst, batch, sig, True)
+    ml = L.mask_loss(ious.clone(), clusters, sig, inst, batch)
+    sl = L.instance_iou_loss(ious.clone(), clusters, scores, inst, batch, 0.25, 0.75)
+    np.savez_compressed(os.path.join(OUT, "mask_loss_cases.npz"), batch=batch.numpy(), inst=inst.numpy(),
+                        cluster_offsets=np.cumsum([0] + [len(c) for c in clusters]), cluster_points=torch.cat(clusters).numpy(),
+                        mask_logits=mask_logits.numpy(), scores=scores.numpy(), ious=ious.numpy(), mask_loss=ml.numpy(),
+                        score_loss=sl.numpy())
+    print("mask losses: ious max per proposal", ious.max(1)[0].numpy().round(3).tolist(), "mask_loss", float(ml), "score_loss", float(sl))
+
+
 def make_nms():
     _stub_modules()
     S = _load(os.path.join(REF, "torch_points3d/models/panoptic/structure_3heads.py"), "ref_structure_3heads")
@@ -512,6 +549,9 @@ if __name__ == "__main__":
                                                                          OPENBLAS_NUM_THREADS="1"))
         make_proposals()
         sys.exit(0)
+    if "--mask-losses-only" in sys.argv:
+        make_mask_losses()
+        sys.exit(0)
     if "--nms-only" in sys.argv:
         make_nms()
         sys.exit(0)
@@ -526,6 +566,7 @@ if __name__ == "__main__":
         sys.exit(0)
     make_meanshift()
     make_losses()
+    make_mask_losses()
     make_nms()
     make_final_eval()
     make_grid_cylinders()
