@@ -335,23 +335,27 @@ __global__ __launch_bounds__(256) void k_ball_query_cells(const float4* __restri
       }
       __syncthreads();
     }
-    {  // sorted keys are in the second buffer; gather the candidates through registers, then overlay
-      float4 pc[PER];
+    {  // sorted keys are in the second buffer; gather the candidates through registers, then overlay.  The loads are
+       // unconditional (lanes past `total` re-read the cell's first point) and the components live in scalar arrays: a
+       // conditionally written float4 array is not promoted to registers (it cost 96 B / 512 B of scratch per lane)
+      float px[PER], py[PER], pz[PER];
+      int ps[PER];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = tid + 256 * u;
-        if (f < total) {
-          const unsigned long long key = kbuf1[f];
-          const int src = nb_start[(int)((key >> SLOT_BITS) & 31u)] + (int)(key & ((1u << SLOT_BITS) - 1u));
-          pc[u] = spos[src];
-          pc[u].w = __int_as_float(src);  // the walk needs the position, not the index: the order carries it
-        }
+        const unsigned long long key = kbuf1[f < total ? f : 0];
+        const int src = f < total ? nb_start[(int)((key >> SLOT_BITS) & 31u)] + (int)(key & ((1u << SLOT_BITS) - 1u)) : p0;
+        const float4 p = spos[src];
+        px[u] = p.x;
+        py[u] = p.y;
+        pz[u] = p.z;
+        ps[u] = src;  // the walk needs the position, not the index: the order carries it
       }
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = tid + 256 * u;
-        if (f < total) cand[f] = pc[u];
+        if (f < total) cand[f] = make_float4(px[u], py[u], pz[u], __int_as_float(ps[u]));
       }
       __syncthreads();
     }
