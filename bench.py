@@ -321,11 +321,12 @@ def main():
         batches.append((ids, dev_b, override, starts, [int(len(tiles[t])) for t in ids]))
     t_gen = time.perf_counter() - t_gen
 
-    stats = {"proposals": 0, "instances": 0}
+    stats = {"proposals": 0, "instances": 0, "local_ms": [], "exchange_events": []}
 
     def step(profile=False):
         local = {}
         stats["proposals"] = stats["instances"] = 0
+        t_local = time.perf_counter()
         for ids, dev_b, override, starts, sizes in batches:
             labels, res, counts = runner.run(dev_b, len(ids), override=override)
             stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
@@ -334,7 +335,16 @@ def main():
             # (views of the batch tensors, one split per tensor)
             for t, o, l, v in zip(ids, dev_b["origin_id"].split(sizes), labels.split(sizes), res.semantic_logits.split(sizes)):
                 local[t] = (o, l, v)
-        return exchange_tile_results(local) if world > 1 else local
+        # (the per-tile instance counts were just read on the host: the local part of the step is complete here)
+        stats["local_ms"].append(1e3 * (time.perf_counter() - t_local))
+        if world == 1:
+            return local
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        full = exchange_tile_results(local)
+        e1.record()
+        stats["exchange_events"].append((e0, e1))
+        return full
 
     def sync():
         if world > 1:
@@ -363,6 +373,7 @@ def main():
     gc.disable()
     sync()
     host0 = host_cpu_state()
+    stats["local_ms"], stats["exchange_events"] = [], []
     t0 = time.perf_counter()
     step_ms = []
     profiler = ops.PROFILER
@@ -383,7 +394,24 @@ def main():
             f.write("# pp_spconv_fwd launches of the timed steps grouped by shape (HIP events on the launch stream)\n\n")
             f.write(ops.PROFILER.table(event_steps))
     ops.PROFILER = None
+    multi = None
     if world > 1:
+        # what every rank did, so that a scaling record explains itself: this rank's wall time for the K steps, the local
+        # part of a step (everything before the exchange), the exchange itself (HIP events around the all-gathers) and bytes
+        ex_ms = [a.elapsed_time(b) for a, b in stats["exchange_events"]]
+        n_mine = float(sum(len(tiles[t]) for t in mine))
+        row = torch.tensor([1e3 * dt / args.steps, float(np.mean(stats["local_ms"])), float(np.mean(ex_ms)) if ex_ms else 0.0,
+                            n_mine, float(len(mine))], dtype=torch.float64, device=device)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        rows = torch.stack(rows).cpu().numpy()
+        bpp = 8 + 4 * DS.num_classes  # origin id + instance label + C semantic log-probabilities (int32 / float32)
+        multi = {"per_rank_step_ms": [round(v, 3) for v in rows[:, 0]], "per_rank_local_ms": [round(v, 3) for v in rows[:, 1]],
+                 "per_rank_exchange_ms": [round(v, 3) for v in rows[:, 2]], "per_rank_points": [int(v) for v in rows[:, 3]],
+                 "per_rank_tiles": [int(v) for v in rows[:, 4]], "exchange_bytes_per_point": bpp,
+                 "exchange_bytes_sent_per_rank": [int(v) * bpp for v in rows[:, 3]],
+                 "exchange_bytes_received_per_rank": int(rows[:, 3].max()) * bpp * world,  # padded all-gather
+                 "exchange_collectives_per_step": 2, "backend": os.environ.get("PP_DIST_BACKEND", "nccl")}
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -456,7 +484,7 @@ def main():
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
-                       "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms,
+                       "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms, "multi_gpu": multi,
                        # the host side of the timed region (the step has ~25 host reads of data-dependent sizes): CPU time
                        # this process used, and how long the container's CPU quota throttled it
                        "host": {"cpu_s": round(host1[0] - host0[0], 3), "wall_s": round(dt, 3), "step_ms": step_ms,
