@@ -195,6 +195,11 @@ int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t bloc
 size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout);
 int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin, int32_t cout,
                    int32_t transpose_w, float* packed, pp_stream_t stream);
+/* All layers of a model in one launch (training: every weight changes with the optimizer step).  desc int64 [n_desc][6] on the
+ * device = {weight pointer, packed pointer, K, cin, cout, flags as pp_pack_weight's transpose_w}; first_block int64 [n_desc+1]
+ * = running sum of ceil(pp_packed_weight_floats / 256) (first_block[n_desc] = total_blocks). */
+int pp_pack_weights_batched(const int64_t* desc, const int64_t* first_block, int32_t n_desc, int64_t total_blocks,
+                            pp_stream_t stream);
 int pp_spconv_fwd(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in /*rows of in0 (and in1)*/,
                   const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale,
                   const float* shift, int32_t relu, const float* residual,
@@ -270,6 +275,14 @@ int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float* weight, c
 int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_t n, int32_t c,
                     const float* weight, const double* save_mean, const double* save_rstd, float* dx,
                     float* dweight, float* dbias, void* ws, size_t ws_bytes, pp_stream_t stream);
+
+/* Weight / bias gradient of a skinny Linear layer y = x W^T + b (cin, cout <= 32, millions of rows): dw [cout,cin] =
+ * dy^T x, db [cout] = column sums of dy (db nullable).  replaces: the torch.nn.Linear backward (rocBLAS split-K GEMM with
+ * K = n) of the heads' layers in the training step, PointGroup3heads.py:69-81 / core/common_modules/base_modules.py:35-45.
+ * Block partials in float64, no atomics (run-to-run reproducible). */
+size_t pp_linear_wgrad_workspace(int64_t n, int32_t cin, int32_t cout);
+int pp_linear_wgrad(const float* x, const float* dy, int64_t n, int32_t cin, int32_t cout, float* dw, float* db,
+                    void* ws, size_t ws_bytes, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Heads                           replaces: Semantic/Offset/Embed MLP heads in eval mode,

@@ -489,6 +489,14 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------------------
 # autograd functions (training path); eval uses the fused entry points below
 # ------------------------------------------------------------------------------------------------
+def _pack(kernel, transpose=False, kflip=False):
+    """packed weights of a layer: model parameters go through the per-version cache (one launch re-packs all of them after
+    an optimizer step), anything else is packed on the spot"""
+    if isinstance(kernel, nn.Parameter) and os.environ.get("PP_PACK_BATCHED", "1") != "0":
+        return ops.pack_weight_cached(kernel, transpose=transpose, kflip=kflip)
+    return ops.pack_weight(kernel, transpose=transpose, kflip=kflip)
+
+
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, kernel, nbr, inv_fn, n_out, K, same_level=False, kflip=False):
@@ -496,7 +504,7 @@ class _SparseConvFn(torch.autograd.Function):
         layer (kflip) and every input gradient reuse nbr with the offsets of the packed weights reversed.  Cross-level
         maps are slot-ordered (nbr.pp_order: slot -> output row)."""
         feats = feats.contiguous()
-        packed = ops.pack_weight(kernel, kflip=kflip)
+        packed = _pack(kernel, kflip=kflip)
         cout = kernel.shape[-1]
         bf16 = _CONV_BF16[0]
         out = ops.spconv_fwd(feats, packed, nbr, n_out, cout, K, row_order=getattr(nbr, "pp_order", None), bf16=bf16)
@@ -512,10 +520,10 @@ class _SparseConvFn(torch.autograd.Function):
         din = dw = None
         if ctx.needs_input_grad[0]:
             if ctx.same_level:
-                packed_t = ops.pack_weight(kernel, transpose=True, kflip=not ctx.kflip)
+                packed_t = _pack(kernel, transpose=True, kflip=not ctx.kflip)
                 inv = ctx.nbr
             else:
-                packed_t = ops.pack_weight(kernel, transpose=True)
+                packed_t = _pack(kernel, transpose=True)
                 inv = ctx.inv_fn()
             din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
                                  row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp, vp]),
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
+    "pp_pack_weights_batched": (C.c_int, [vp, vp, i32, i64, vp]),
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_set_scratch": (C.c_int, [vp, sz]),
     "pp_spconv_fwd_shortcut": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "pp_bn_train_bwd": (C.c_int, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "pp_linear_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
+    "pp_linear_wgrad": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, C.c_size_t, vp]),
     "pp_heads": (C.c_int, [vp, i64, i32, vp, i64, vp, i32, vp, vp]),
     "pp_region_grow_workspace": (sz, [i64, i32]),
     "pp_region_grow_workspace_for": (sz, [i64, i64, i32]),

@@ -24,16 +24,15 @@
 // ---------------------------------------------------------------------------------------------
 static inline int pp_nt(int cout) { return (cout + 15) / 16; }
 
-extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) {
-  int NT = pp_nt(cout);
+__host__ __device__ static inline size_t packed_floats(int K, int cin, int cout) {
+  const int NT = (cout + 15) / 16;
   if (cin % 16 == 0) return (size_t)K * (cin / 16) * NT * 256;
   return (size_t)K * ((cin + 3) / 4) * NT * 64;
 }
+extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) { return packed_floats(K, cin, cout); }
 
-__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int K, int cin, int cout,
-                                                     int transpose_w, float* __restrict__ packed, int64_t total) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+// element e of the packed tensor of one layer (shared by the single-layer and the batched kernel)
+__device__ __forceinline__ float pack_weight_element(const float* __restrict__ w, int K, int cin, int cout, int transpose_w, int64_t e) {
   int NT = (cout + 15) / 16;
   int k, ci, co;
   if (cin % 16 == 0) {
@@ -65,7 +64,13 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
     const int64_t ks = (transpose_w & 2) ? K - 1 - k : k;
     v = (transpose_w & 1) ? w[(ks * cout + co) * cin + ci] : w[(ks * cin + ci) * cout + co];
   }
-  packed[e] = v;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int K, int cin, int cout,
+                                                     int transpose_w, float* __restrict__ packed, int64_t total) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  packed[e] = pack_weight_element(w, K, cin, cout, transpose_w, e);
 }
 
 extern "C" int pp_pack_weight(const float* weight, int32_t K, int32_t cin, int32_t cout, int32_t transpose_w,
@@ -75,6 +80,32 @@ extern "C" int pp_pack_weight(const float* weight, int32_t K, int32_t cin, int32
   int64_t total = (int64_t)pp_packed_weight_floats(K, cin, cout);
   hipLaunchKernelGGL(k_pack_weight, dim3(pp_blocks(total, 256)), dim3(256), 0, pp_s(stream), weight, K, cin, cout,
                      transpose_w, packed, total);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+// every layer of a model in ONE launch (training: all weights change with the optimizer step, i.e. ~190 packings of a few
+// microseconds each per step otherwise).  desc[l] = {weight pointer, packed pointer, K, cin, cout, flags}, first_block[l] =
+// number of 256-element blocks of the layers in front of l (first_block[n] = grid size).
+__global__ __launch_bounds__(256) void k_pack_weights_batched(const int64_t* __restrict__ desc, const int64_t* __restrict__ first_block,
+                                                              int n_desc) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = n_desc;  // last l with first_block[l] <= b
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first_block[mid] <= b) lo = mid; else hi = mid;
+  }
+  const int64_t* d = desc + 6 * (int64_t)lo;
+  const int K = (int)d[2], cin = (int)d[3], cout = (int)d[4], flags = (int)d[5];
+  const int64_t total = (int64_t)packed_floats(K, cin, cout);
+  const int64_t e = (b - first_block[lo]) * 256 + threadIdx.x;
+  if (e < total) ((float*)d[1])[e] = pack_weight_element((const float*)d[0], K, cin, cout, flags, e);
+}
+extern "C" int pp_pack_weights_batched(const int64_t* desc, const int64_t* first_block, int32_t n_desc, int64_t total_blocks,
+                                       pp_stream_t stream) {
+  if (n_desc == 0 || total_blocks == 0) return PP_OK;
+  PP_REQUIRE(desc && first_block && n_desc > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "pp_pack_weights_batched: bad arguments");
+  hipLaunchKernelGGL(k_pack_weights_batched, dim3((unsigned)total_blocks), dim3(256), 0, pp_s(stream), desc, first_block, n_desc);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -455,6 +455,63 @@ def pack_weight(weight, transpose=False, kflip=False):
     return packed
 
 
+class _PackedWeights:
+    """Packed copies of a model's convolution weights, refreshed in ONE launch per weight version (training: the optimizer
+    step changes every weight, and packing each of the ~190 (layer, orientation) pairs of a step as its own 4 us launch
+    costs 2 ms of host time per step).  An entry is (parameter, flags) -> packed tensor; the first request of an entry packs
+    it alone and registers it; when a registered entry is requested with a new `_version` of its parameter, ALL registered
+    entries are re-packed by pp_pack_weights_batched (parameters whose weights did not change are simply packed again)."""
+
+    def __init__(self):
+        self.entries = {}      # (id(param), flags) -> [weakref(param), flags, packed, version, K, cin, cout]
+        self.table = None      # (desc, first_block, n, total_blocks) on the device, or None when entries changed
+
+    def get(self, param, transpose, kflip):
+        import weakref
+        flags = int(bool(transpose)) | (2 if kflip else 0)
+        key = (id(param), flags)
+        ent = self.entries.get(key)
+        if ent is not None and ent[0]() is param and ent[2].device == param.device:
+            if ent[3] != param._version:
+                self._repack_all(param.device)
+            return ent[2]
+        packed = pack_weight(param, transpose=transpose, kflip=kflip)
+        w = param.detach()
+        K, a, b = (1,) + tuple(w.shape) if w.dim() == 2 else tuple(w.shape)
+        cin, cout = (b, a) if transpose else (a, b)
+        self.entries[key] = [weakref.ref(param), flags, packed, param._version, K, cin, cout]
+        self.table = None
+        return packed
+
+    def _repack_all(self, device):
+        lib = _lib.load()
+        live = [(k, e) for k, e in self.entries.items() if e[0]() is not None and e[2].device == device]
+        if len(live) != len(self.entries):
+            self.entries = dict(live)
+            self.table = None
+        if self.table is None:
+            rows, first, blocks = [], [0], 0
+            for _, e in live:
+                p = e[0]()
+                rows.append([p.data_ptr(), e[2].data_ptr(), e[4], e[5], e[6], e[1]])
+                blocks += (e[2].numel() + 255) // 256
+                first.append(blocks)
+            self.table = (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(first, dtype=torch.int64).to(device),
+                          len(rows), blocks)
+        desc, first, n, blocks = self.table
+        _lib.check(lib.pp_pack_weights_batched(_ptr(desc), _ptr(first), n, blocks, _stream()), "pp_pack_weights_batched")
+        for _, e in live:
+            e[3] = e[0]()._version
+
+
+PACKED_WEIGHTS = _PackedWeights()
+
+
+def pack_weight_cached(param, transpose=False, kflip=False):
+    """pack_weight for a model PARAMETER: packed once per weight version, all registered parameters in one launch"""
+    return PACKED_WEIGHTS.get(param, transpose, kflip)
+
+
 _CONV_SCRATCH = {"device": None, "buf": None}
 CONV_SCRATCH_BYTES = int(os.environ.get("PP_CONV_SCRATCH_MB", "64")) << 20
 
@@ -614,6 +671,22 @@ def affine_act(x, scale=None, shift=None, act=0, slope=0.0, residual=None):
                                  _ptr(_need(shift, torch.float32, "shift")), int(act), float(slope),
                                  _ptr(_need(residual, torch.float32, "residual")), _ptr(y), _stream()), "pp_affine_act")
     return y
+
+
+def linear_wgrad(x, dy, want_bias=True):
+    """(dW [cout, cin], db [cout] or None) of y = x W^T + b for a skinny layer (cin, cout <= 32): one streaming pass over
+    x and dy instead of a split-K GEMM with K = rows (csrc/pp_dense.hip)."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    dy = _need(dy, torch.float32, "dy")
+    n, cin = x.shape
+    cout = dy.shape[1]
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    wsb = lib.pp_linear_wgrad_workspace(n, cin, cout)
+    ws = _ws(wsb, x.device)
+    _lib.check(lib.pp_linear_wgrad(_ptr(x), _ptr(dy), n, cin, cout, _ptr(dw), _ptr(db), _ptr(ws), wsb, _stream()), "pp_linear_wgrad")
+    return dw, db
 
 
 def head_mlp(x, w1, scale, shift, w2, b2, log_softmax=False, want_argmax=False):

@@ -20,7 +20,7 @@ from torch import nn
 from .. import MinkowskiEngine as ME
 from .. import ops
 from ..applications import Data, Minkowski
-from ..modules import MLP, Seq, fused_head, head_spec
+from ..modules import MLP, Linear, Seq, fused_head, head_spec
 from ..torch_points_kernels import region_grow_csr
 from ..torch_scatter import gather, scatter
 from ..utils import meanshift_cluster
@@ -66,11 +66,11 @@ class PointGroup3heads(nn.Module):
 
         if "Offset" in self.HEADS:
             self.Offset = Seq().append(MLP([nc, nc], bias=False))
-            self.Offset.append(nn.Linear(nc, 3))
+            self.Offset.append(Linear(nc, 3))
         if "Embed" in self.HEADS:
             self.Embed = Seq().append(MLP([nc, nc], bias=False))
-            self.Embed.append(nn.Linear(nc, option.get("embed_dim", 5)))
-        self.Semantic = (Seq().append(MLP([nc, nc], bias=False)).append(nn.Linear(nc, dataset.num_classes))
+            self.Embed.append(Linear(nc, option.get("embed_dim", 5)))
+        self.Semantic = (Seq().append(MLP([nc, nc], bias=False)).append(Linear(nc, dataset.num_classes))
                          .append(nn.LogSoftmax(dim=-1)))
         self.num_classes = dataset.num_classes
         self.loss_names = ["loss", "offset_norm_loss", "offset_dir_loss", "ins_loss", "ins_var_loss", "ins_dist_loss",

@@ -918,3 +918,52 @@ def test_coarser_levels_from_the_block_index(ops, oracle):
         down = ops.kernel_map_bi(got, cur_idx, 3, ts // 2, 1)
         assert np.array_equal(down.cpu().numpy(), oracle.kernel_map(want, cur, 3, ts // 2, 1))
         cur_idx, cur = got_idx, want
+
+
+def test_linear_wgrad_matches_torch(ops):
+    """pp_linear_wgrad (streaming dW / db of a skinny Linear layer) vs the float64 product; through modules.Linear's autograd
+    path vs torch.nn.Linear; bit-reproducible from run to run"""
+    from panopticsegforlargescalepointcloud_amd.modules import Linear
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for n, cin, cout in [(0, 16, 9), (1, 16, 3), (63, 4, 1), (5000, 16, 16), (300_001, 16, 5), (70_000, 32, 32), (12_345, 7, 13)]:
+        x = torch.randn((n, cin), device="cuda", generator=g)
+        dy = torch.randn((n, cout), device="cuda", generator=g)
+        dw, db = ops.linear_wgrad(x, dy)
+        want_w, want_b = (dy.double().T @ x.double()), dy.double().sum(0)
+        scale = max(1.0, float(want_w.abs().max())) if n else 1.0
+        assert float((dw.double() - want_w).abs().max()) <= 2e-6 * scale * max(1, n) ** 0.5
+        assert float((db.double() - want_b).abs().max()) <= 2e-6 * max(1.0, float(want_b.abs().max())) * max(1, n) ** 0.5
+        dw2, db2 = ops.linear_wgrad(x, dy)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    torch.manual_seed(0)
+    a, b = Linear(16, 9).cuda(), torch.nn.Linear(16, 9).cuda()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn((20_000, 16), device="cuda", generator=g)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    w = torch.randn((20_000, 9), device="cuda", generator=g)
+    (a(xa) * w).sum().backward()
+    (b(xb) * w).sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
+    assert list(a.state_dict()) == list(b.state_dict())
+
+
+def test_batched_weight_packing_equals_single_layer_packing(ops):
+    """ops.pack_weight_cached: after the parameters change (optimizer step) ONE pp_pack_weights_batched launch refreshes every
+    registered (layer, orientation); results equal pp_pack_weight's, layer by layer"""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cache = ops._PackedWeights()
+    params = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=g)) for s in [(27, 16, 16), (27, 32, 48), (16, 32), (27, 4, 16), (27, 64, 32)]]
+    combos = [(p, t, k) for p in params for (t, k) in ((False, False), (True, False), (True, True), (False, True)) if not (p.dim() == 2 and k)
+              and not (t and p.shape[-1] % 4)]
+    first = [cache.get(p, t, k).clone() for p, t, k in combos]
+    for (p, t, k), f in zip(combos, first):
+        assert torch.equal(f, ops.pack_weight(p, transpose=t, kflip=k))
+    with torch.no_grad():
+        for p in params:
+            p.mul_(1.5).add_(0.25)
+    got = [cache.get(p, t, k) for p, t, k in combos]          # first request re-packs all of them in one launch
+    for (p, t, k), gt, f in zip(combos, got, first):
+        assert torch.equal(gt, ops.pack_weight(p, transpose=t, kflip=k)) and not torch.equal(gt, f)
+    assert cache.table is not None and cache.table[2] == len(combos)
