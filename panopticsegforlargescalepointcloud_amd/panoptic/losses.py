@@ -35,7 +35,7 @@ def _proposal_rows(predicted_clusters, clusters_csr, device):
 def _gt_layout(instance_labels, batch):
     """per batch element: number of ground-truth instances (= its largest id) and the offset of its first column"""
     nb = int(batch[-1]) + 1
-    k = scatter(instance_labels.long(), batch.long(), dim=0, reduce="max", dim_size=nb)
+    k = torch.zeros(nb, dtype=torch.int64, device=batch.device).scatter_reduce_(0, batch.long(), instance_labels.long(), "amax")
     off = torch.cumsum(k, 0) - k
     return k, off, int(k.sum())
 
