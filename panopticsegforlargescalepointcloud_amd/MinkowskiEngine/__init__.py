@@ -525,8 +525,12 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 packed_t = _pack(kernel, transpose=True)
                 inv = ctx.inv_fn()
-            din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
-                                 row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)
+            ops.PROFILE_TAG = "dgrad"
+            try:
+                din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
+                                     row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)
+            finally:
+                ops.PROFILE_TAG = "fwd"
         if ctx.needs_input_grad[1]:
             order = getattr(ctx.nbr, "pp_order", None)
             # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order

@@ -54,6 +54,8 @@ class LaunchProfiler:
 
     def __init__(self, reserve=0):
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
+        self.tags = []     # per record: TAG at launch time ("fwd" / "dgrad": the input gradient runs on the forward kernel)
+        self.records_w = []  # weight-gradient launches (pp_spconv_bwd_weight): (start, end, n_in, n_out, cin, cout, K, pairs)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
         # (bench.py: launches per step x steps, counted during the warm-up) so that a timed launch only pays the records
         self._pool = [_TimingEvent() for _ in range(2 * int(reserve))]
@@ -70,11 +72,30 @@ class LaunchProfiler:
         vals = iter(torch.stack([d.reshape(()).to(torch.int64) for d in dev]).tolist()) if dev else iter(())
         return [r[3] if r[7] is None else int(next(vals)) for r in self.records]
 
-    def summarize(self):
+    def summarize_wgrad(self, elem_bytes=4.0):
+        """time, algorithmic bytes and flops of the weight-gradient launches: dW[k] = sum over pairs of in^T dout reads both
+        feature matrices once and the map once, writes K x cin x cout floats; 2 flops per pair and channel pair"""
+        torch.cuda.synchronize()
+        dev = [r[7] for r in self.records_w if r[7] is not None]
+        vals = iter(torch.stack([d.reshape(()).to(torch.int64) for d in dev]).tolist()) if dev else iter(())
+        ms = b = fl = 0.0
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs) in self.records_w:
+            P = n_out if pairs is None else int(next(vals))
+            ms += e0.elapsed_time(e1)
+            b += elem_bytes * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P
+            fl += 2.0 * P * cin * cout
+        return {"launches": len(self.records_w), "ms": ms, "bytes": b, "flops": fl}
+
+    def summarize(self, tag=None):
         torch.cuda.synchronize()
         tot_ms = tot_bytes = tot_flops = map_bytes = 0.0
         counts = self._pair_counts()
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P in zip(self.records, counts):
+        n_used = 0
+        tags = self.tags if len(self.tags) == len(self.records) else [None] * len(self.records)
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg in zip(self.records, counts, tags):
+            if tag is not None and tg != tag:
+                continue
+            n_used += 1
             map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
             # SURVEY.md 8(d): features read once + written once, weights once, one (in,out) int32 pair per map entry;
             # a fused 1x1 shortcut (ds_c input channels) adds its input rows, its weights and its flops
@@ -83,7 +104,7 @@ class LaunchProfiler:
             tot_bytes += b
             tot_flops += 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
             tot_ms += e0.elapsed_time(e1)
-        return {"launches": len(self.records), "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes}
+        return {"launches": n_used, "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes}
 
     def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12):
         """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
@@ -108,6 +129,7 @@ class LaunchProfiler:
 
 
 PROFILER = None
+PROFILE_TAG = "fwd"  # what the next pp_spconv_fwd launches are (the autograd backward sets "dgrad" around its launch)
 
 
 def _pairs_of(nbr):
@@ -589,6 +611,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         e1.record()
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None,
                              shortcut[0].shape[1] if shortcut is not None else 0))
+        prof.tags.append(PROFILE_TAG)
     return out
 
 
@@ -599,8 +622,15 @@ def spconv_bwd_weight(inp, dout, nbr, K, bf16=False):
     cin, cout = inp.shape[1], dout.shape[1]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=inp.device)
     fn = lib.pp_spconv_bwd_weight_bf16 if (bf16 and nbr is not None and cout <= 192) else lib.pp_spconv_bwd_weight
+    prof = PROFILER
+    if prof is not None:
+        e0, e1 = prof.events()
+        e0.record()
     _lib.check(fn(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, _ptr(nbr), K, dout.shape[0], _ptr(dw), _stream()),
                "pp_spconv_bwd_weight")
+    if prof is not None:
+        e1.record()
+        prof.records_w.append((e0, e1, inp.shape[0], dout.shape[0], cin, cout, K, _pairs_of(nbr)))
     return dw
 
 

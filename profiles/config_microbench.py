@@ -2,7 +2,7 @@
   C2  NPM3D-like full scene, ~2 M points, 5 cm voxels        (bench.py --points 2000000 --grid 4)
   C3  FOR-instance-like forest tile set, ~1 M points, 10 cm voxels, r = 8 m cylinders, two classes, offset + embedding
       dual clustering (cluster_type of the published setting), same timed region as bench.py.
-usage (GPU box): python profiles/config_microbench.py"""
+usage (GPU box): python profiles/config_microbench.py [--out DIR]      (DIR/c2.json, DIR/c3.json: one JSON object each)"""
 import copy
 import json
 import os
@@ -20,11 +20,26 @@ from panopticsegforlargescalepointcloud_amd import panoptic, synthetic as syn  #
 from panopticsegforlargescalepointcloud_amd.scene import TileRunner  # noqa: E402
 
 
+OUT = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+
+
+def _save(name, obj):
+    if OUT:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(obj, f)
+
+
 def c2():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--points", "2000000", "--grid", "4", "--steps", "5",
-                          "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    """the bench's own JSON line for configs[1] (incl. roofline and its self-check: batch invariance + oracle parity of the
+    median tile, which needs the CPU pass -- a bounded one)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--points", "2000000", "--grid", "4", "--steps", "10",
+                          "--warmup", "2"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
-    print("C2  %s: %.1f ms/step, %.1f M points/s" % (d["config"]["workload"][:90], d["ms_per_step"], d["value"] / 1e6))
+    d["config"]["baseline_config"] = "BASELINE.json configs[1]: NPM3D full scene (~2M pts, 5 cm voxel) on 1 x MI355X"
+    _save("c2.json", d)
+    print("C2  %s: %.1f ms/step, %.1f M points/s, checks %s" % (d["config"]["workload"][:90], d["ms_per_step"], d["value"] / 1e6,
+                                                                d["config"].get("checks", {}).get("all")))
 
 
 def c3(n_points=1_000_000, voxel=0.10, grid=10, steps=5):
@@ -58,6 +73,22 @@ def c3(n_points=1_000_000, voxel=0.10, grid=10, steps=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     n = len(b["pos"])
+    # self-check (untimed): the median tile of the batch run alone gives bit-identical instance labels
+    sizes = np.bincount(b["batch"])
+    j = int(np.argsort(sizes)[len(sizes) // 2])
+    m = torch.from_numpy(b["batch"] == j).to(dev)
+    one = {k: (v[m] if k != "batch" else torch.zeros(int(m.sum()), dtype=v.dtype, device=dev)) for k, v in dev_b.items()}
+    l1, r1, c1 = runner.run(one, 1, override=tuple(o[m] for o in override))
+    ok = bool(torch.equal(labels[m], l1)) and counts[j] == c1[0]
+    _save("c3.json", {"metric": "points/sec end-to-end (sparse-conv fwd + clustering)", "value": n / dt, "unit": "points/sec",
+                      "n_gpus": 1, "steps": steps, "warmup": 2, "ms_per_step": 1e3 * dt, "dtype": "f32", "data": "synthetic",
+                      "config": {"baseline_config": "BASELINE.json configs[2]: FOR-instance forest tile (r = 8 m cylinders, ~1M pts, 10 cm "
+                                                    "voxel), offset + embedding dual clustering on 1 x MI355X",
+                                 "workload": "synthetic forest, %d cylinders (r = %.1f m), %d voxels fed (%d scene voxels, %d trees), "
+                                             "cluster_type %s" % (len(ids), radius, n, len(scene.pos), scene.n_inst, cfg.cluster_type),
+                                 "proposals_per_step": int(res.clusters_csr.n), "instances_per_step": int(sum(counts)),
+                                 "checks": {"batch_invariance": "pass" if ok else "FAIL", "oracle": "tests/test_forest_gpu.py (same model "
+                                            "and generator at test size)", "all": "pass" if ok else "FAIL"}}})
     print("C3  forest: %d cylinders (r = %.1f m), %d voxels fed (%d scene voxels, %d trees), cluster_type %s: %.1f ms/step, "
           "%.1f M points/s, %d proposals -> %d instances" % (len(ids), radius, n, len(scene.pos), scene.n_inst, cfg.cluster_type,
                                                                1e3 * dt, n / dt / 1e6, res.clusters_csr.n, sum(counts)))
