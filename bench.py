@@ -222,12 +222,38 @@ def _scaled_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if a.size else 0.0
 
 
+def _near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5):
+    """points whose instance label hangs on a score comparison closer than eps: two proposals overlapping by more than the NMS
+    threshold (region growing and mean shift propose every object twice, with nearly the same points -- their max-pooled
+    scorer features, hence scores, agree to the last bits) or a score within eps of the score filter.  Which of such twins
+    survives is decided by float rounding, legitimately differently in two correct implementations."""
+    amb = np.zeros(n_points, bool)
+    scores = np.asarray(scores, np.float64)
+    owner = {}
+    for i, c in enumerate(clusters):
+        for p in np.asarray(c).tolist():
+            owner.setdefault(p, []).append(i)
+    inter = {}
+    for lst in owner.values():
+        for a in range(len(lst)):
+            for b in range(a + 1, len(lst)):
+                inter[(lst[a], lst[b])] = inter.get((lst[a], lst[b]), 0) + 1
+    for (i, j), n in inter.items():
+        if n / (len(clusters[i]) + len(clusters[j]) - n) > nms_threshold and abs(scores[i] - scores[j]) < eps:
+            amb[np.asarray(clusters[i])] = True
+            amb[np.asarray(clusters[j])] = True
+    for i in np.nonzero(np.abs(scores - min_score) < eps)[0]:
+        amb[np.asarray(clusters[i])] = True
+    return amb
+
+
 def self_check(runner, batches, device, oracle_case):
     """Untimed correctness checks of the benchmark's own run (the 10 M-row kernel variants are not reachable from the
     unit tests' sizes): (1) batch invariance -- a tile of the 64-tile batch gives the same result as that tile run alone
     (instance labels bit-exact, semantic / embedding outputs 1e-4); (2) the median tile run alone equals the CPU oracle
     pipeline (proposals bit-exact, scores / embeddings / semantic log-probabilities within 1e-4 of their magnitude,
-    instance labels equal after canonicalisation -- the oracle's own scores, no substitution).  The measured errors are
+    instance labels equal after canonicalisation -- the oracle's own scores, no substitution; points whose label hangs on
+    a score near-tie below 1e-5 between two overlapping proposals are excluded and counted).  The measured errors are
     reported in `checks["max_err"]`."""
     checks = {}
     ids, dev_b, override, starts, _ = batches[0]
@@ -257,10 +283,14 @@ def self_check(runner, batches, device, oracle_case):
         e_feat = _scaled_err(rg.embed_logits.cpu().numpy(), want["embed_logits"])
         e_seml = _scaled_err(rg.semantic_logits.cpu().numpy(), want["semantic_logits"])
         ok_score, ok_feat = ok_prop and e_score < 1e-4, e_feat < 1e-4 and e_seml < 1e-4
-        ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()), _canonical(want_labels)))
+        # instance labels against the oracle's own scores and NMS; points that hang on a score near-tie (< 1e-5) between two
+        # overlapping proposals are left out and counted
+        amb = _near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"])) if ok_prop else np.zeros(len(b["pos"]), bool)
+        ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()[~amb]), _canonical(want_labels[~amb]))) and amb.mean() < 0.25
         checks["oracle"] = "pass" if (ok_prop and ok_score and ok_feat and ok_inst) else \
             "FAIL(proposals=%s scores=%s embeddings=%s instances=%s)" % (ok_prop, ok_score, ok_feat, ok_inst)
-        checks["oracle_tile"] = {"rows": len(b["pos"]), "proposals": len(got), "instances": int(cg[0])}
+        checks["oracle_tile"] = {"rows": len(b["pos"]), "proposals": len(got), "instances": int(cg[0]),
+                                 "points_on_score_near_ties": int(amb.sum())}
         checks["max_err"].update({"oracle_scores": e_score, "oracle_embeddings": e_feat, "oracle_semantic": e_seml})
     checks["all"] = "pass" if all(not str(v).startswith("FAIL") for v in checks.values()) else "FAIL"
     return checks
