@@ -42,12 +42,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef F3_WPB
 #define F3_WPB 4
 #endif
-// F3_PREFETCH (A/B builds): same-level launches with <= 32 input channels read the wave's OWN rows with coalesced loads
-// while the kernel map is in flight -- the compulsory HBM miss of every input row is then taken by a streaming load
-// (full 128-byte lines, 16 TA cycles per KiB) instead of by the first 64-byte gather that names the row
-#ifndef F3_PREFETCH
-#define F3_PREFETCH 0
-#endif
 
 // C4: the 4-channel input layer (rows of 16 bytes).  A step is one kernel offset with ONE fp32 MFMA per tile (k = the four
 // channels): lane (i, q) loads channel q of its row and weight [q][column i] as single dwords.
@@ -102,22 +96,6 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) v[kk] = (rv && kk + NL * kh < a.K) ? (int)row : -1;
     }
-    f32x4 pf[F3_PREFETCH ? T * 2 : 1];
-    bool pf_on = false;
-    if constexpr (F3_PREFETCH != 0 && !C4) {
-      pf_on = a.nbr && !a.row_order && a.c1 == 0 && a.c0 <= 32 && a_bytes == (unsigned)a.n_out * row_bytes;
-      if (pf_on) {
-        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)a_bytes, 0x00020000);
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt)
-#pragma unroll
-          for (int ss = 0; ss < 2; ++ss) {
-            const unsigned o = ((unsigned)(row_base + tt * 16 + i)) * row_bytes + (unsigned)ss * 64u + (unsigned)q * 16u;
-            pf[tt * 2 + ss] = (ss * 16 < a.c0) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)o, 0, 0))
-                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-      }
-    }
     unsigned ml = 0;
 #pragma unroll
     for (int kk = 0; kk < NL; ++kk) {
@@ -133,12 +111,6 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 #pragma unroll
       for (int h = 0; h < KPL; ++h)
         m[tt] |= (unsigned)__builtin_amdgcn_readlane((int)ml, h * R + tt * 16) << (NL * h);
-    }
-    if constexpr (F3_PREFETCH != 0 && !C4) {
-      if (pf_on) {
-#pragma unroll
-        for (int u = 0; u < T * 2; ++u) asm volatile("" ::"v"(pf[u]));  // the loads must not be dropped; their data is
-      }
     }
   }
   unsigned rem = 0;
