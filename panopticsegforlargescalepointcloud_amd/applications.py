@@ -123,24 +123,21 @@ class UnwrappedUnetBasedModel(nn.Module):
 class BaseMinkowski(UnwrappedUnetBasedModel):
     CONV_TYPE = "sparse"
 
-    def __init__(self, model_config, model_type, dataset, modules, *args, **kwargs):
+    def __init__(self, model_config, model_type, dataset, modules, *args, default_output_nc=None, **kwargs):
+        """Same construction order as the reference (applications/minkowski.py:81-93) because it decides the RNG stream of
+        the seeded initial values: layers, then their initialisation, then -- only if the caller asks for a different
+        `output_nc` -- a bias-free Linear + BN + LeakyReLU(0.2) head named `mlp` (a state_dict key)."""
         super().__init__(model_config, model_type, dataset, modules)
         self.weight_initialization()
-        default_output_nc = kwargs.get("default_output_nc", None) or extract_output_nc(model_config)
-        self._output_nc = default_output_nc
-        self._has_mlp_head = False
-        if "output_nc" in kwargs:
-            self._has_mlp_head = True
-            self._output_nc = kwargs["output_nc"]
-            self.mlp = MLP([default_output_nc, self.output_nc], activation=nn.LeakyReLU(0.2), bias=False)
+        backbone_nc = default_output_nc or extract_output_nc(model_config)
+        head_nc = kwargs.get("output_nc")
+        self.mlp = None
+        if head_nc is not None:
+            self.mlp = MLP([backbone_nc, head_nc], activation=nn.LeakyReLU(0.2), bias=False)
+        self._widths = (backbone_nc, head_nc)
 
-    @property
-    def has_mlp_head(self):
-        return self._has_mlp_head
-
-    @property
-    def output_nc(self):
-        return self._output_nc
+    has_mlp_head = property(lambda self: self._widths[1] is not None)
+    output_nc = property(lambda self: self._widths[1] if self._widths[1] is not None else self._widths[0])
 
     @property
     def device(self):
@@ -168,16 +165,18 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
 
 class MinkowskiEncoder(BaseMinkowski):
     def forward(self, data, *args, **kwargs):
+        """down modules -> (features, batch id) of the coarsest level -> innermost module (global pooling head) -> optional
+        `mlp` head; returns one row per batch element (applications/minkowski.py:129-156)."""
         self._set_input(data)
-        data = self.input
-        for m in self.down_modules:
-            data = m(data)
-        out = Batch(x=data.F, batch=data.C[:, 0].long())
-        if not isinstance(self.inner_modules[0], Identity):
-            out = self.inner_modules[0](out)
-        if self.has_mlp_head:
-            out.x = self.mlp(out.x)
-        return out
+        x = self.input
+        for down in self.down_modules:
+            x = down(x)
+        pooled = Batch(x=x.F, batch=x.C[:, 0].long())
+        inner = self.inner_modules[0]
+        pooled = pooled if isinstance(inner, Identity) else inner(pooled)
+        if self.mlp is not None:
+            pooled.x = self.mlp(pooled.x)
+        return pooled
 
 
 class MinkowskiUnet(BaseMinkowski):
@@ -210,7 +209,7 @@ class MinkowskiUnet(BaseMinkowski):
             out = Data(x=data.feats, pos=None, batch=data.coordinate_manager.level(1).coords[:, 0])
         else:
             out = Data(x=data.F, pos=self.xyz, batch=data.C[:, 0])
-        if self.has_mlp_head:
+        if self.mlp is not None:
             out.x = self.mlp(out.x)
         return out
 
