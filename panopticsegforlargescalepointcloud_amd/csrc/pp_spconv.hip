@@ -301,7 +301,11 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
-  const int max_ntw = (mode16 || c4) ? 4 : 7;
+  // column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
+  // gathers the input rows again).  PP_MAX_NTW overrides (A/B runs).
+  static const int env_ntw = getenv("PP_MAX_NTW") ? atoi(getenv("PP_MAX_NTW")) : 0;
+  int max_ntw = (mode16 || c4) ? 4 : 7;
+  if (mode16 && env_ntw >= 4 && env_ntw <= 6 && (a.NT + env_ntw - 1) / env_ntw < (a.NT + 3) / 4) max_ntw = env_ntw;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
   groups = (a.NT + ntw - 1) / ntw;

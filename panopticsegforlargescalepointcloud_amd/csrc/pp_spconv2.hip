@@ -408,6 +408,8 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
       case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
       case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
       case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 5: hipLaunchKernelGGL((k_spconv_fwd3<5, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 6: hipLaunchKernelGGL((k_spconv_fwd3<6, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
       default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
     }
     return PP_OK;
@@ -435,7 +437,7 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
 #define F3_CASE(N, D) \
   case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
   switch (10 * depth + ntw) {
-    F3_CASE(1, 1) F3_CASE(2, 1) F3_CASE(3, 1) F3_CASE(4, 1)
+    F3_CASE(1, 1) F3_CASE(2, 1) F3_CASE(3, 1) F3_CASE(4, 1) F3_CASE(5, 1) F3_CASE(6, 1)
     F3_CASE(1, 3) F3_CASE(2, 3) F3_CASE(3, 3) F3_CASE(4, 3)
     default: pp_set_error("pp_spconv_fwd3: ntw %d / depth %d out of range", ntw, depth); return PP_ERR_INVALID;
   }
