@@ -301,11 +301,14 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
-  // column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
-  // gathers the input rows again).  PP_MAX_NTW overrides (A/B runs).
+  // column tiles per wave: 4, or up to 6 where that saves a column group on a LARGE launch (80 / 96 / 160 / 192 output
+  // channels: every group gathers the input rows again) -- 96->96 transposed onto 5.4 M rows 3814 -> 3400 us, 160->160 onto
+  // 0.67 M rows 1395 -> 1191 us; launches below ~0.4 M rows lose (fewer waves: 80->80 at 149 k rows 487 -> 527 us), 128
+  // channels are two groups of 4 either way (profiles/r03_ab_ntw.log).  PP_MAX_NTW = 4 .. 6 forces the bound (A/B runs).
   static const int env_ntw = getenv("PP_MAX_NTW") ? atoi(getenv("PP_MAX_NTW")) : 0;
   int max_ntw = (mode16 || c4) ? 4 : 7;
-  if (mode16 && env_ntw >= 4 && env_ntw <= 6 && (a.NT + env_ntw - 1) / env_ntw < (a.NT + 3) / 4) max_ntw = env_ntw;
+  const int want_ntw = env_ntw >= 4 && env_ntw <= 6 ? env_ntw : (n_out >= 400000 ? 6 : 4);
+  if (mode16 && (a.NT + want_ntw - 1) / want_ntw < (a.NT + 3) / 4) max_ntw = want_ntw;
   int groups = (a.NT + max_ntw - 1) / max_ntw;
   int ntw = (a.NT + groups - 1) / groups;
   groups = (a.NT + ntw - 1) / ntw;
