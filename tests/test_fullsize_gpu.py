@@ -247,10 +247,12 @@ def _report(name, got, want):
 
 @pytest.mark.parametrize("cin,cout,cat,bf16", [(16, 16, False, False), (32, 32, False, False), (64, 48, False, False),
                                                (48, 48, True, False), (4, 16, False, False), (32, 32, False, True),
-                                               (64, 64, True, True)])
+                                               (64, 64, True, True), (32, 96, False, False), (48, 80, False, False),
+                                               (16, 160, False, True)])
 def test_general_weight_convolution_vs_fp64_on_sampled_rows(ops, level, cin, cout, cat, bf16):
     """same-level convolution with the fused epilogue (cat + BN + ReLU + residual) at the size where the 64-rows-per-wave /
-    unsplit variants are selected, against a float64 evaluation of 20 k sampled output rows; 1e-4 of the output magnitude"""
+    unsplit variants are selected -- and, for 80 / 96 / 160 output channels, the 5 / 6-column-tiles-per-wave variants only
+    launches of >= 0.4 M rows take -- against a float64 evaluation of 20 k sampled output rows; 1e-4 of the output magnitude"""
     nbr, n = level["nbr"], level["n"]
     g = torch.Generator(device="cuda").manual_seed(100 + cin + cout)
     x0 = torch.randn((n, cin), device="cuda", generator=g)
@@ -264,7 +266,7 @@ def test_general_weight_convolution_vs_fp64_on_sampled_rows(ops, level, cin, cou
     assert _report("same %d%s->%d%s" % (cin, "+%d" % cin if cat else "", cout, " bf16" if bf16 else ""), got[rows], want) < 1e-4
 
 
-@pytest.mark.parametrize("c,bf16", [(32, False), (64, False), (64, True)])
+@pytest.mark.parametrize("c,bf16", [(32, False), (64, False), (64, True), (96, False)])
 def test_strided_and_transposed_convolutions_vs_fp64_on_sampled_rows(ops, level, c, bf16):
     """strided (fine -> coarse) and transposed (coarse -> fine, slot-ordered map with row_order) launches of this size"""
     coords, index, n = level["coords"], level["index"], level["n"]
