@@ -44,6 +44,9 @@ _CONV_BF16 = [os.environ.get("PP_CONV_DTYPE", "fp32").lower() == "bf16"]
 # inference: coarser levels and their kernel maps are built on a side stream by a worker thread that replays the
 # requests of the model's previous forward, while the main stream already runs the convolutions of the finer levels
 MAP_PREFETCH = os.environ.get("PP_MAP_PREFETCH", "1") != "0"
+# inference: the map of a stride-2 transposed convolution in its 8-wide form (a fine row has <= 8 coarse neighbours, fixed by
+# its parity class): 32 instead of 108 bytes per row through transpose, mask, sort, permute and the convolution's prologue
+MAP_T8 = os.environ.get("PP_MAP_T8", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -335,6 +338,8 @@ class CoordinateManager:
         order = getattr(m, "pp_order", None)
         if m is None or order is None:
             return m
+        if getattr(m, "pp_t8", False):  # 8-wide transposed map: expand, then un-slot
+            m, order = ops.map8_to_dense(m, order), order & 0x0FFFFFFF
         rows = torch.empty_like(m)
         rows[:, order.long()] = m
         return rows
@@ -360,11 +365,20 @@ class CoordinateManager:
                     m.pp_pairs = rev.pp_pairs
             elif rev is not None:
                 # transposed strided map by scatter from the strided one; rows = physical rows of the finer level
-                m = ops.kernel_map_transpose(rev, dst.n, order=getattr(rev, "pp_order", None))
-                if MAP_ORDER and dst.n >= MAP_ORDER_MIN_ROWS:
-                    order = ops.map_order(ops.map_mask(m))
-                    m = ops.map_permute(m, order)
-                    m.pp_order = order
+                ordered = MAP_ORDER and dst.n >= MAP_ORDER_MIN_ROWS
+                if (ordered and MAP_T8 and not torch.is_grad_enabled() and ksize == 3 and ts_from == 2 * ts_to
+                        and rev.shape[0] == 27 and dst.n < (1 << 28)):
+                    m8, cls, key8 = ops.kernel_map_transpose8(rev, dst.n, order=getattr(rev, "pp_order", None))
+                    order = ops.map_order(key8)
+                    m = ops.map_permute(m8, order)
+                    m.pp_order = ops.order_encode(order, cls)  # row | parity class << 28
+                    m.pp_t8 = True
+                else:
+                    m = ops.kernel_map_transpose(rev, dst.n, order=getattr(rev, "pp_order", None))
+                    if ordered:
+                        order = ops.map_order(ops.map_mask(m))
+                        m = ops.map_permute(m, order)
+                        m.pp_order = order
             else:
                 src = self.levels[ts_from]
                 if src.index is not None:

@@ -284,7 +284,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
                            const int32_t* row_order, float* out, int bf16, int rows_per_wave, int pipeline, int split_k,
                            pp_stream_t stream, const float* ds_in = nullptr, int32_t ds_c = 0,
                            const float* ds_packed = nullptr, const float* ds_scale = nullptr,
-                           const float* ds_shift = nullptr) {
+                           const float* ds_shift = nullptr, int t8 = 0) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
@@ -300,6 +300,9 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.residual = residual; a.row_order = row_order; a.out = out; a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout;
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
+  a.t8 = t8;
+  if (row_order) PP_REQUIRE(n_out < (1ll << 28), "pp_spconv_fwd: a row order addresses at most 2^28 rows");
+  if (t8) PP_REQUIRE(row_order && nbr && K == 27 && !ds_in, "pp_spconv_fwd_t8: needs the 8-wide map, its encoded row order and K = 27");
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
   // column tiles per wave: 4, or up to 6 where that saves a column group on a LARGE launch (80 / 96 / 160 / 192 output
   // channels: every group gathers the input rows again) -- 96->96 transposed onto 5.4 M rows 3814 -> 3400 us, 160->160 onto
@@ -352,6 +355,10 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
   } else {
     if (ds_in) return PP_UNSUPPORTED;
+    if (t8) {
+      pp_set_error("pp_spconv_fwd_t8: needs cin %% 16 == 0 and inputs < 4 GiB per source (the pipelined kernel)");
+      return PP_ERR_INVALID;
+    }
     // first-version kernel: Cin % 16 != 0 other than the 4-channel input layer, and inputs of 4 GiB or more per source
     if (bf16) {
       pp_set_error("pp_spconv_fwd_bf16: needs cin %% 16 == 0, K <= 28, inputs < 4 GiB (got cin %d, K %d)", c0 + c1, K);
@@ -402,6 +409,16 @@ extern "C" int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1
                                   const float* residual, const int32_t* row_order, float* out, pp_stream_t stream) {
   return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr, K, n_out, cout, scale, shift, relu, residual,
                          row_order, out, 1, 0, 0, 0, stream);
+}
+/* Transposed stride-2 convolution on the 8-wide map of pp_kernel_map_transpose8: nbr8 int32 [8][n_out] slot-major (after
+ * pp_map_permute with K = 8), row_order [n_out] from pp_order_encode (row | parity class << 28).  Same results, bit for bit,
+ * as pp_spconv_fwd on the dense 27-wide map of pp_kernel_map_transpose in the same slot order. */
+extern "C" int pp_spconv_fwd_t8(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                                const float* packed_weight, const int32_t* nbr8, int64_t n_out, int32_t cout,
+                                const float* scale, const float* shift, int32_t relu, const float* residual,
+                                const int32_t* row_order, float* out, int32_t bf16, pp_stream_t stream) {
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr8, 27, n_out, cout, scale, shift, relu, residual,
+                         row_order, out, bf16 ? 1 : 0, 0, 0, 0, stream, nullptr, 0, nullptr, nullptr, nullptr, 1);
 }
 extern "C" int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                                 const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,

@@ -54,6 +54,7 @@ class LaunchProfiler:
 
     def __init__(self, reserve=0):
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
+        self.map_k = []    # per record: rows of the kernel map the launch streams (27, or 8 for an 8-wide transposed map)
         self.tags = []     # per record: TAG at launch time ("fwd" / "dgrad": the input gradient runs on the forward kernel)
         self.records_w = []  # weight-gradient launches (pp_spconv_bwd_weight): (start, end, n_in, n_out, cin, cout, K, pairs)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
@@ -92,10 +93,13 @@ class LaunchProfiler:
         counts = self._pair_counts()
         n_used = 0
         tags = self.tags if len(self.tags) == len(self.records) else [None] * len(self.records)
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg in zip(self.records, counts, tags):
+        map_k = self.map_k if len(self.map_k) == len(self.records) else [None] * len(self.records)
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg, mk in zip(self.records, counts, tags, map_k):
             if tag is not None and tg != tag:
                 continue
             n_used += 1
+            if mk is not None and K > 1:
+                map_bytes += 4.0 * (mk - K) * n_out  # (corrects the dense estimate below for 8-wide maps)
             map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
             # features read once + written once, weights once, one (in,out) int32 pair per map entry;
             # a fused 1x1 shortcut (ds_c input channels) adds its input rows, its weights and its flops
@@ -429,6 +433,48 @@ def kernel_map_transpose(nbr, n_in, order=None):
     return out
 
 
+def kernel_map_transpose8(nbr, n_in, order=None, want_key=True):
+    """8-wide form of kernel_map_transpose for a stride-2 transposed convolution (csrc/pp_coords.hip): (map8 int32 [8, n_in],
+    cls uint8 [n_in] parity class of every fine row, key int32 [n_in] = cls << 8 | presence bits or None)."""
+    lib = _lib.load()
+    K, n_out = nbr.shape
+    if K != 27:
+        raise ValueError("kernel_map_transpose8: 3x3x3 maps only")
+    dev = nbr.device
+    map8 = torch.empty((8, n_in), dtype=torch.int32, device=dev)
+    cls = torch.empty(max(n_in, 1), dtype=torch.uint8, device=dev)
+    key = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev) if want_key else None
+    _lib.check(lib.pp_kernel_map_transpose8(_ptr(nbr), n_out, int(n_in), _ptr(_need(order, torch.int32, "order")), _ptr(map8),
+                                            _ptr(cls), _ptr(key), _stream()), "pp_kernel_map_transpose8")
+    if hasattr(nbr, "pp_pairs"):
+        map8.pp_pairs = nbr.pp_pairs
+    return map8, cls[:n_in], (key[:n_in] if want_key else None)
+
+
+def order_encode(order, cls):
+    """row_order of pp_spconv_fwd_t8: order[s] | cls[order[s]] << 28 (order None = identity)"""
+    lib = _lib.load()
+    n = cls.shape[0]
+    enc = torch.empty(max(n, 1), dtype=torch.int32, device=cls.device)
+    _lib.check(lib.pp_order_encode(_ptr(_need(order, torch.int32, "order")), _ptr(cls), n, _ptr(enc), _stream()), "pp_order_encode")
+    return enc[:n]
+
+
+def map8_to_dense(map8, order_enc):
+    """the dense [27, n] slot-major map an 8-wide transposed map stands for (tests / consumers outside the convolution)"""
+    n = map8.shape[1]
+    cls = ((order_enc.long() >> 28) & 7)
+    dense = torch.full((27, n), -1, dtype=torch.int32, device=map8.device)
+    cols = torch.arange(n, device=map8.device)
+    for j in range(8):
+        ok = ((j & ~cls) & 7) == 0
+        d = [torch.where((cls >> a) & 1 == 1, torch.full_like(cls, 2 if (j >> a) & 1 else 0), torch.ones_like(cls)) for a in range(3)]
+        k = d[0] + 3 * d[1] + 9 * d[2]
+        sel = ok & (map8[j] >= 0)
+        dense[k[sel], cols[sel]] = map8[j][sel]
+    return dense
+
+
 def compose_perm(perm32, order, n, device):
     """(perm, inv) int64: perm[s] = perm32[order[s]] (None = identity for either), inv[perm[s]] = s"""
     lib = _lib.load()
@@ -590,7 +636,14 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         groups = (nt + 3) // 4
         ntw = (nt + groups - 1) // groups
         variant = (64 if (ntw <= _AB_T4[0] and n_out >= _AB_T4[1]) else 32, 0, 0)
-    if shortcut is not None:
+    t8 = bool(getattr(nbr, "pp_t8", False))
+    if t8:
+        if variant is not None or shortcut is not None or K != 27 or row_order is None:
+            raise ValueError("spconv_fwd: an 8-wide transposed map takes the default variant, K = 27 and its encoded row order")
+        _lib.check(lib.pp_spconv_fwd_t8(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), n_out, cout,
+                                        _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out),
+                                        int(use_bf16), _stream()), "pp_spconv_fwd_t8")
+    elif shortcut is not None:
         xs, pks, scs, shs = shortcut
         xs = _need(xs, torch.float32, "shortcut input")
         rc = lib.pp_spconv_fwd_shortcut(*args[:14], _ptr(out), int(use_bf16 and xs.shape[1] % 16 == 0), _ptr(xs), xs.shape[1], _ptr(pks),
@@ -612,6 +665,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None,
                              shortcut[0].shape[1] if shortcut is not None else 0))
         prof.tags.append(PROFILE_TAG)
+        prof.map_k.append(8 if t8 else K)
     return out
 
 

@@ -967,3 +967,51 @@ def test_batched_weight_packing_equals_single_layer_packing(ops):
     for (p, t, k), gt, f in zip(combos, got, first):
         assert torch.equal(gt, ops.pack_weight(p, transpose=t, kflip=k)) and not torch.equal(gt, f)
     assert cache.table is not None and cache.table[2] == len(combos)
+
+
+def test_transposed_map_8_wide_equals_dense(ops, oracle):
+    """pp_kernel_map_transpose8 / pp_order_encode / pp_spconv_fwd_t8: the 8-wide form of a stride-2 transposed map holds
+    exactly the pairs of the dense 27-wide one (expanded back through the parity classes), its classes are the fine rows'
+    coordinate parities, and the convolution on it is bit-identical to the dense form in the same slot order -- fp32 and bf16,
+    32 and 64 rows per wave sizes, with and without a slot-ordered strided map behind it"""
+    import bruteforce as bf
+    rng = np.random.default_rng(12)
+    coords = bf.surface_coords(rng, n_batch=3, n=20000, extent=60)
+    c = torch.from_numpy(coords).cuda()
+    perm, cs = ops.morton_order(c, 1, 4, want_sorted=True, raw=True)
+    index, ndup = ops.block_index_build(cs, 1, 4)
+    assert ndup == 0
+    cidx, cc = ops.block_index_coarsen(index, cs.shape[0])
+    n, nc = cs.shape[0], cc.shape[0]
+    down = ops.kernel_map_bi(cc, index, 3, 1, 1)                      # coarse rows gather fine rows
+    for slot_ordered in (False, True):
+        rev, rev_order = down, None
+        if slot_ordered:                                                # the strided map in its own slot order
+            rev_order = ops.map_order(ops.map_mask(down))
+            rev = ops.map_permute(down, rev_order)
+        dense = ops.kernel_map_transpose(rev, n, order=rev_order)      # [27, n] physical fine rows
+        m8, cls, key = ops.kernel_map_transpose8(rev, n, order=rev_order)
+        par = ((cs[:, 1:] & 1) * torch.tensor([1, 2, 4], device="cuda")).sum(1)
+        has = (dense >= 0).any(0)
+        assert torch.equal(cls[has].long(), par[has].long())            # class = parity of the fine coordinate (unit 1)
+        assert torch.equal((key.long() >> 8)[has], par[has].long()) and int((m8 >= 0).sum()) == int((dense >= 0).sum())
+        ident = ops.order_encode(None, cls)
+        assert torch.equal(ops.map8_to_dense(m8, ident), dense)
+        order = ops.map_order(key)
+        m8s = ops.map_permute(m8, order)
+        enc = ops.order_encode(order, cls)
+        assert torch.equal(enc & 0x0FFFFFFF, order) and torch.equal(ops.map8_to_dense(m8s, enc), dense[:, order.long()])
+        m8s.pp_t8 = True
+        dense_s = dense[:, order.long()].contiguous()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for cin, cout, bf16 in [(16, 16, False), (64, 64, False), (96, 96, False), (32, 48, True), (160, 160, False)]:
+            x = torch.randn((nc, cin), device="cuda", generator=g)
+            pk = ops.pack_weight(torch.randn((27, cin, cout), device="cuda", generator=g) * 0.1)
+            sc, sh = torch.rand(cout, device="cuda", generator=g) + 0.5, torch.randn(cout, device="cuda", generator=g)
+            res = torch.randn((n, cout), device="cuda", generator=g)
+            want = ops.spconv_fwd(x, pk, dense_s, n, cout, 27, scale=sc, shift=sh, relu=True, residual=res, row_order=order, bf16=bf16)
+            got = ops.spconv_fwd(x, pk, m8s, n, cout, 27, scale=sc, shift=sh, relu=True, residual=res, row_order=enc, bf16=bf16)
+            assert torch.equal(got, want), (cin, cout, bf16, slot_ordered)
+    # the oracle's transposed map (fine rows probing the coarse level with mirrored offsets) names the same pairs
+    want = oracle.kernel_map(cs.cpu().numpy(), cc.cpu().numpy(), 3, 1, -1)
+    assert np.array_equal(ops.map8_to_dense(m8, ident).cpu().numpy(), want)
