@@ -92,6 +92,11 @@ __global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restric
     fpos[t] = p;
   }
   __syncthreads();
+  // offsets no row of the window has take the highest positions of the key and are zero in every key: the radix passes stop
+  // at the number of offsets that occur (an 8-wide transposed map's key has 11 bits, a window on a plane ~9 offsets)
+  int nbits = 0;
+  for (int k = 0; k < MO_MASK_BITS; ++k) nbits += fcnt[k] > 0 ? 1 : 0;
+  nbits = __builtin_amdgcn_readfirstlane(nbits);
   {
     uint32_t out[8];
 #pragma unroll
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restric
     for (int r = 0; r < 8; ++r) key[r] = (t * 8 + r) < cnt ? out[r] : 0x7FFFFFFu;  // padding: the largest key, behind its equals
   }
 #pragma unroll 1
-  for (int bit = 0; bit < MO_MASK_BITS; bit += 2) {
+  for (int bit = 0; bit < nbits; bit += 2) {
     unsigned long long c = 0;
     int lr[8];
 #pragma unroll
