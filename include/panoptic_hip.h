@@ -103,14 +103,13 @@ int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int32_t K, int
                             int32_t* out_map, pp_stream_t stream);
 /* 8-wide form of the same map for a stride-2 transposed convolution: a fine row has a coarse neighbour only through offsets
  * whose components are 0 on its even axes and +-1 on its odd ones, i.e. through <= 8 of the 27, fixed by the row's parity class
- * cls = (x odd) | (y odd) << 1 | (z odd) << 2.  map8 int32 [8][n_in] (entry j = (dx>0) | (dy>0)<<1 | (dz>0)<<2; -1 = none),
- * cls uint8 [n_in], key uint32 [n_in] (nullable) = cls << 8 | presence bits -- what pp_map_order sorts by.  Same pairs as
- * pp_kernel_map_transpose at 32 instead of 108 bytes per row; consumed by pp_spconv_fwd_t8 after pp_map_permute (K = 8) and
- * pp_order_encode (enc[s] = order[s] | cls[order[s]] << 28; order NULL = identity).  n_in < 2^28.
+ * cls = (x odd) | (y odd) << 1 | (z odd) << 2.  map8 int32 [8][n_in]: entry j = (dx>0) | (dy>0)<<1 | (dz>0)<<2 holds
+ * coarse row | cls << 28 (-1 = none); key uint32 [n_in] (nullable) = cls << 8 | presence bits -- what pp_map_order sorts by.
+ * Same pairs as pp_kernel_map_transpose at 32 instead of 108 bytes per row; consumed by pp_spconv_fwd_t8 after pp_map_permute
+ * (K = 8).  n_out (coarse rows) < 2^28.
  * replaces: the transposed kernel maps MinkowskiConvolutionTranspose requests, api_modules.py:259-267 (inference). */
 int pp_kernel_map_transpose8(const int32_t* in_map, int64_t n_out, int64_t n_in, const int32_t* in_order, int32_t* map8,
-                             uint8_t* cls, uint32_t* key, pp_stream_t stream);
-int pp_order_encode(const int32_t* order, const uint8_t* cls, int64_t n, int32_t* enc, pp_stream_t stream);
+                             uint32_t* key, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K1b/K3c  block index of a level + kernel maps through it (what the coordinate manager uses; the
@@ -234,7 +233,7 @@ int pp_spconv_fwd_shortcut(const float* in0, int32_t c0, const float* in1, int32
  * the LDS read of the step after that), split_k in {0, 1, 2, 4, 8} (kernel offsets split over that many waves, partial
  * sums added in a fixed order; needs pp_spconv_set_scratch); 0 = the per-shape choice pp_spconv_fwd makes.  bf16 != 0
  * selects the bfloat16 compute variant.  PP_ERR_INVALID for shapes the pipelined kernel does not take. */
-/* pp_spconv_fwd on the 8-wide transposed map (pp_kernel_map_transpose8 -> pp_map_permute(K = 8) -> pp_order_encode); bit-identical
+/* pp_spconv_fwd on the 8-wide transposed map (pp_kernel_map_transpose8 -> pp_map_permute(K = 8)); bit-identical
  * to the dense 27-wide form in the same slot order.  cin % 16 == 0, inputs < 4 GiB per source. */
 int pp_spconv_fwd_t8(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
                      const int32_t* nbr8, int64_t n_out, int32_t cout, const float* scale, const float* shift, int32_t relu,

@@ -339,7 +339,7 @@ class CoordinateManager:
         if m is None or order is None:
             return m
         if getattr(m, "pp_t8", False):  # 8-wide transposed map: expand, then un-slot
-            m, order = ops.map8_to_dense(m, order), order & 0x0FFFFFFF
+            m = ops.map8_to_dense(m)
         rows = torch.empty_like(m)
         rows[:, order.long()] = m
         return rows
@@ -367,11 +367,11 @@ class CoordinateManager:
                 # transposed strided map by scatter from the strided one; rows = physical rows of the finer level
                 ordered = MAP_ORDER and dst.n >= MAP_ORDER_MIN_ROWS
                 if (ordered and MAP_T8 and not torch.is_grad_enabled() and ksize == 3 and ts_from == 2 * ts_to
-                        and rev.shape[0] == 27 and dst.n < (1 << 28)):
-                    m8, cls, key8 = ops.kernel_map_transpose8(rev, dst.n, order=getattr(rev, "pp_order", None))
+                        and rev.shape[0] == 27 and rev.shape[1] < (1 << 28)):
+                    m8, key8 = ops.kernel_map_transpose8(rev, dst.n, order=getattr(rev, "pp_order", None))
                     order = ops.map_order(key8)
                     m = ops.map_permute(m8, order)
-                    m.pp_order = ops.order_encode(order, cls)  # row | parity class << 28
+                    m.pp_order = order
                     m.pp_t8 = True
                 else:
                     m = ops.kernel_map_transpose(rev, dst.n, order=getattr(rev, "pp_order", None))

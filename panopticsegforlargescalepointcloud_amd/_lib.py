@@ -63,8 +63,7 @@ SIGNATURES = {
     "pp_morton_order_workspace": (sz, [i64]),
     "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp, vp]),
     "pp_packed_weight_floats": (sz, [i32, i32, i32]),
-    "pp_kernel_map_transpose8": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp]),
-    "pp_order_encode": (C.c_int, [vp, vp, i64, vp, vp]),
+    "pp_kernel_map_transpose8": (C.c_int, [vp, i64, i64, vp, vp, vp, vp]),
     "pp_spconv_fwd_t8": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i64, i32, vp, vp, i32, vp, vp, vp, i32, vp]),
     "pp_pack_weight": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "pp_pack_weights_batched": (C.c_int, [vp, vp, i32, i64, vp]),

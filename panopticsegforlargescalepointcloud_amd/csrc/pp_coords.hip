@@ -237,16 +237,16 @@ extern "C" int pp_kernel_map_transpose(const int32_t* in_map, int64_t n_out, int
 // through offsets whose components are 0 on the axes where f is even and +-1 where it is odd (in units of t): at most
 // 2 x 2 x 2 of the 27, fixed by the row's parity class cls = (x odd) | (y odd) << 1 | (z odd) << 2.  Instead of a dense
 // [27][n_fine] map (108 B per row, four passes over it: scatter, mask, permute read + write) the map is
-//   map8[j][f], j = (dx > 0) | (dy > 0) << 1 | (dz > 0) << 2     (32 B per row; entries with a bit on an even axis stay -1)
-// plus the class per row; the convolution kernel expands (cls, j) back to the offset index k in its prologue.
-//   k_kernel_map_transpose8: map8[j(k)][in_map[k][c]] = c, cls[f] = class(k)          (all writers of a row agree)
+//   map8[j][f] = c | cls << 28,  j = (dx > 0) | (dy > 0) << 1 | (dz > 0) << 2     (32 B per row; -1 = none)
+// -- every entry of a row carries the row's class in bits 28..30 (a separate class array cost a scattered BYTE write per
+// pair: the scatter took 737 instead of 627 us per 10 M rows); the convolution kernel expands (cls, j) back to the offset
+// index k in its prologue.
+//   k_kernel_map_transpose8: map8[j(k)][in_map[k][c]] = c | class(k) << 28
 //   k_map8_key            : key[f] = cls << 8 | presence bits of the 8 entries          (what the slot order sorts by)
-//   k_order_encode        : enc[s] = order[s] | cls[order[s]] << 28                     (row_order of the convolution)
 // Reference: none (MinkowskiEngine keeps (in, out) pair lists per offset); same pairs as pp_kernel_map_transpose.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kernel_map_transpose8(const int32_t* __restrict__ in_map, int64_t n_out, int64_t n_in,
-                                                               const int32_t* __restrict__ in_order, int32_t* __restrict__ map8,
-                                                               uint8_t* __restrict__ cls) {
+                                                               const int32_t* __restrict__ in_order, int32_t* __restrict__ map8) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 27 * n_out) return;
   const int32_t f = in_map[e];
@@ -255,48 +255,36 @@ __global__ __launch_bounds__(256) void k_kernel_map_transpose8(const int32_t* __
     const int64_t o = e - (int64_t)k * n_out;
     const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
     const int j = (dx > 0 ? 1 : 0) | (dy > 0 ? 2 : 0) | (dz > 0 ? 4 : 0);
-    map8[(int64_t)j * n_in + f] = in_order ? in_order[o] : (int32_t)o;
-    cls[f] = (uint8_t)((dx != 0 ? 1 : 0) | (dy != 0 ? 2 : 0) | (dz != 0 ? 4 : 0));
+    const uint32_t cls = (dx != 0 ? 1u : 0u) | (dy != 0 ? 2u : 0u) | (dz != 0 ? 4u : 0u);
+    const uint32_t c = (uint32_t)(in_order ? in_order[o] : (int32_t)o);
+    map8[(int64_t)j * n_in + f] = (int32_t)(c | (cls << 28));
   }
 }
-__global__ __launch_bounds__(256) void k_map8_key(const int32_t* __restrict__ map8, const uint8_t* __restrict__ cls, int64_t n,
-                                                  uint32_t* __restrict__ key) {
+__global__ __launch_bounds__(256) void k_map8_key(const int32_t* __restrict__ map8, int64_t n, uint32_t* __restrict__ key) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
-  uint32_t m = 0;
+  uint32_t m = 0, cls = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) m |= (map8[(int64_t)j * n + f] >= 0 ? 1u : 0u) << j;
-  key[f] = m | ((uint32_t)cls[f] << 8);
-}
-__global__ __launch_bounds__(256) void k_order_encode(const int32_t* __restrict__ order, const uint8_t* __restrict__ cls, int64_t n,
-                                                      int32_t* __restrict__ enc) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const int32_t r = order ? order[s] : (int32_t)s;
-  enc[s] = (int32_t)((uint32_t)r | ((uint32_t)cls[r] << 28));
+  for (int j = 0; j < 8; ++j) {
+    const int32_t v = map8[(int64_t)j * n + f];
+    if (v >= 0) {
+      m |= 1u << j;
+      cls |= (uint32_t)v >> 28;
+    }
+  }
+  key[f] = m | (cls << 8);
 }
 extern "C" int pp_kernel_map_transpose8(const int32_t* in_map, int64_t n_out, int64_t n_in, const int32_t* in_order,
-                                        int32_t* map8, uint8_t* cls, uint32_t* key, pp_stream_t stream) {
-  PP_REQUIRE(in_map && map8 && cls, "pp_kernel_map_transpose8: null pointer");
-  PP_REQUIRE(n_in < (1ll << 28), "pp_kernel_map_transpose8: more than 2^28 rows (the class shares a word with the row)");
+                                        int32_t* map8, uint32_t* key, pp_stream_t stream) {
+  PP_REQUIRE(in_map && map8, "pp_kernel_map_transpose8: null pointer");
+  PP_REQUIRE(n_out < (1ll << 28), "pp_kernel_map_transpose8: more than 2^28 coarse rows (the class shares a word with the row)");
   hipStream_t s = pp_s(stream);
-  if (n_in > 0) {
-    PP_HIP(hipMemsetAsync(map8, 0xFF, sizeof(int32_t) * 8 * (size_t)n_in, s));
-    PP_HIP(hipMemsetAsync(cls, 0, (size_t)n_in, s));
-  }
+  if (n_in > 0) PP_HIP(hipMemsetAsync(map8, 0xFF, sizeof(int32_t) * 8 * (size_t)n_in, s));
   if (n_in == 0) return PP_OK;
   if (n_out > 0)
     hipLaunchKernelGGL(k_kernel_map_transpose8, dim3(pp_blocks(27 * n_out, 256)), dim3(256), 0, s, in_map, n_out, n_in, in_order,
-                       map8, cls);
-  if (key) hipLaunchKernelGGL(k_map8_key, dim3(pp_blocks(n_in, 256)), dim3(256), 0, s, map8, cls, n_in, key);
-  PP_LAUNCH_CHECK();
-  return PP_OK;
-}
-extern "C" int pp_order_encode(const int32_t* order, const uint8_t* cls, int64_t n, int32_t* enc, pp_stream_t stream) {
-  PP_REQUIRE((cls && enc) || n == 0, "pp_order_encode: null pointer");
-  PP_REQUIRE(n < (1ll << 28), "pp_order_encode: more than 2^28 rows");
-  if (n == 0) return PP_OK;
-  hipLaunchKernelGGL(k_order_encode, dim3(pp_blocks(n, 256)), dim3(256), 0, pp_s(stream), order, cls, n, enc);
+                       map8);
+  if (key) hipLaunchKernelGGL(k_map8_key, dim3(pp_blocks(n_in, 256)), dim3(256), 0, s, map8, n_in, key);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -42,11 +42,11 @@ struct SpconvArgs {
   const float* ds_scale;
   const float* ds_shift;
   int ds_c;
-  // 8-wide transposed map (pp_kernel_map_transpose8; v3 kernel only): nbr is [8][n_out] slot-major, row_order[slot] carries the
-  // row's parity class in bits 28..30 -- the prologue expands (class, j) to the offset index k
+  // 8-wide transposed map (pp_kernel_map_transpose8; v3 kernel only): nbr is [8][n_out] slot-major, every entry = coarse row |
+  // parity class of the fine row << 28 -- the prologue expands (class, j) to the offset index k
   int t8;
 };
-#define PP_ROW_MASK 0x0FFFFFFF  // row part of a row_order entry (bits 28..30: parity class of a T8 map, else 0)
+#define PP_ROW_MASK 0x0FFFFFFFu  // row part of a T8 map entry (bits 28..30: parity class)
 
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8; give every XCD a CONTIGUOUS range of row
 // blocks so the neighbour rows gathered by adjacent blocks hit that XCD's private L2 (guide T1; speed only).

@@ -301,8 +301,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
   a.t8 = t8;
-  if (row_order) PP_REQUIRE(n_out < (1ll << 28), "pp_spconv_fwd: a row order addresses at most 2^28 rows");
-  if (t8) PP_REQUIRE(row_order && nbr && K == 27 && !ds_in, "pp_spconv_fwd_t8: needs the 8-wide map, its encoded row order and K = 27");
+  if (t8) PP_REQUIRE(row_order && nbr && K == 27 && !ds_in, "pp_spconv_fwd_t8: needs the 8-wide map, its slot order and K = 27");
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
   // column tiles per wave: 4, or up to 6 where that saves a column group on a LARGE launch (80 / 96 / 160 / 192 output
   // channels: every group gathers the input rows again) -- 96->96 transposed onto 5.4 M rows 3814 -> 3400 us, 160->160 onto
@@ -411,8 +410,8 @@ extern "C" int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1
                          row_order, out, 1, 0, 0, 0, stream);
 }
 /* Transposed stride-2 convolution on the 8-wide map of pp_kernel_map_transpose8: nbr8 int32 [8][n_out] slot-major (after
- * pp_map_permute with K = 8), row_order [n_out] from pp_order_encode (row | parity class << 28).  Same results, bit for bit,
- * as pp_spconv_fwd on the dense 27-wide map of pp_kernel_map_transpose in the same slot order. */
+ * pp_map_permute with K = 8), row_order [n_out] the slot order.  Same results, bit for bit, as pp_spconv_fwd on the dense
+ * 27-wide map of pp_kernel_map_transpose in the same slot order. */
 extern "C" int pp_spconv_fwd_t8(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                                 const float* packed_weight, const int32_t* nbr8, int64_t n_out, int32_t cout,
                                 const float* scale, const float* shift, int32_t relu, const float* residual,

@@ -79,19 +79,21 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     // slot order of a cross-level map (pp_maporder.hip): the map is stored slot-major, row_order[slot] names the output
     // row the slot writes; same-level maps have slot = row and no row_order
     const int64_t slot = rv ? row_base + rr : a.n_out - 1;
-    const int64_t row = a.row_order ? (int64_t)(a.row_order[slot] & PP_ROW_MASK) : slot;
+    const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
     int v[NL];
     const int64_t rowc = slot;
     unsigned ml = 0;
     if (a.t8) {
-      // 8-wide transposed map: the lane's row has <= 8 neighbours, entry j belongs to the offset its parity class names.
+      // 8-wide transposed map: the lane's row has <= 8 neighbours, entry j (= coarse row | class << 28) belongs to the offset
+      // the row's parity class names.
       // Every (k, row) slot is filled with MISSING first (each lane its own half of the offsets, as below), then one lane
       // per row overwrites the <= 8 real ones; LDS operations of a wave execute in program order.
-      const unsigned enc = (unsigned)a.row_order[slot];
-      const unsigned cls = (enc >> 28) & 7u;
       int e8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + rowc];
+      unsigned cls = 0;  // every entry of the row carries the row's parity class in bits 28..30
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cls |= e8[j] >= 0 ? (unsigned)e8[j] >> 28 : 0u;
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) {
         const int k = kk + NL * kh;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         const int dx = (cls & 1u) ? ((j & 1) ? 2 : 0) : 1, dy = (cls & 2u) ? ((j & 2) ? 2 : 0) : 1, dz = (cls & 4u) ? ((j & 4) ? 2 : 0) : 1;
         const int k = dx + 3 * dy + 9 * dz;
         if (ok) {
-          if (kh == 0) off[k][rr] = (unsigned)e8[j] * row_bytes;
+          if (kh == 0) off[k][rr] = ((unsigned)e8[j] & PP_ROW_MASK) * row_bytes;
           mk |= 1u << k;
         }
       }
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
           for (int r = 0; r < 4; ++r) {
             const int64_t slot = row_base + rt * 16 + q * 4 + r;
             if (slot < a.n_out) {
-              const int64_t row = a.row_order ? (int64_t)(a.row_order[slot] & PP_ROW_MASK) : slot;
+              const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
               part[row * a.cout + col] = acc[rt][jt][r];
             }
           }
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         for (int r = 0; r < 4; ++r) {
           const int64_t slot = row_base + rt * 16 + q * 4 + r;
           if (slot < a.n_out) {
-            const int64_t row = a.row_order ? (int64_t)(a.row_order[slot] & PP_ROW_MASK) : slot;
+            const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
             float v = acc[rt][jt][r] * sc + sh;
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.residual) v += a.residual[row * a.cout + col];

@@ -434,44 +434,34 @@ def kernel_map_transpose(nbr, n_in, order=None):
 
 
 def kernel_map_transpose8(nbr, n_in, order=None, want_key=True):
-    """8-wide form of kernel_map_transpose for a stride-2 transposed convolution (csrc/pp_coords.hip): (map8 int32 [8, n_in],
-    cls uint8 [n_in] parity class of every fine row, key int32 [n_in] = cls << 8 | presence bits or None)."""
+    """8-wide form of kernel_map_transpose for a stride-2 transposed convolution (csrc/pp_coords.hip): (map8 int32 [8, n_in]
+    with entries coarse row | parity class of the fine row << 28, key int32 [n_in] = class << 8 | presence bits or None)."""
     lib = _lib.load()
     K, n_out = nbr.shape
     if K != 27:
         raise ValueError("kernel_map_transpose8: 3x3x3 maps only")
     dev = nbr.device
     map8 = torch.empty((8, n_in), dtype=torch.int32, device=dev)
-    cls = torch.empty(max(n_in, 1), dtype=torch.uint8, device=dev)
     key = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev) if want_key else None
     _lib.check(lib.pp_kernel_map_transpose8(_ptr(nbr), n_out, int(n_in), _ptr(_need(order, torch.int32, "order")), _ptr(map8),
-                                            _ptr(cls), _ptr(key), _stream()), "pp_kernel_map_transpose8")
+                                            _ptr(key), _stream()), "pp_kernel_map_transpose8")
     if hasattr(nbr, "pp_pairs"):
         map8.pp_pairs = nbr.pp_pairs
-    return map8, cls[:n_in], (key[:n_in] if want_key else None)
+    return map8, (key[:n_in] if want_key else None)
 
 
-def order_encode(order, cls):
-    """row_order of pp_spconv_fwd_t8: order[s] | cls[order[s]] << 28 (order None = identity)"""
-    lib = _lib.load()
-    n = cls.shape[0]
-    enc = torch.empty(max(n, 1), dtype=torch.int32, device=cls.device)
-    _lib.check(lib.pp_order_encode(_ptr(_need(order, torch.int32, "order")), _ptr(cls), n, _ptr(enc), _stream()), "pp_order_encode")
-    return enc[:n]
-
-
-def map8_to_dense(map8, order_enc):
-    """the dense [27, n] slot-major map an 8-wide transposed map stands for (tests / consumers outside the convolution)"""
+def map8_to_dense(map8):
+    """the dense [27, n] map (same column order) an 8-wide transposed map stands for (tests / consumers outside the convolution)"""
     n = map8.shape[1]
-    cls = ((order_enc.long() >> 28) & 7)
+    present = map8 >= 0
+    cls = torch.where(present, (map8.long() >> 28) & 7, torch.zeros_like(map8, dtype=torch.int64)).amax(0)
     dense = torch.full((27, n), -1, dtype=torch.int32, device=map8.device)
     cols = torch.arange(n, device=map8.device)
     for j in range(8):
-        ok = ((j & ~cls) & 7) == 0
         d = [torch.where((cls >> a) & 1 == 1, torch.full_like(cls, 2 if (j >> a) & 1 else 0), torch.ones_like(cls)) for a in range(3)]
         k = d[0] + 3 * d[1] + 9 * d[2]
-        sel = ok & (map8[j] >= 0)
-        dense[k[sel], cols[sel]] = map8[j][sel]
+        sel = present[j]
+        dense[k[sel], cols[sel]] = map8[j][sel] & 0x0FFFFFFF
     return dense
 
 
@@ -639,7 +629,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
     t8 = bool(getattr(nbr, "pp_t8", False))
     if t8:
         if variant is not None or shortcut is not None or K != 27 or row_order is None:
-            raise ValueError("spconv_fwd: an 8-wide transposed map takes the default variant, K = 27 and its encoded row order")
+            raise ValueError("spconv_fwd: an 8-wide transposed map takes the default variant, K = 27 and its slot order")
         _lib.check(lib.pp_spconv_fwd_t8(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), n_out, cout,
                                         _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(residual), _ptr(row_order), _ptr(out),
                                         int(use_bf16), _stream()), "pp_spconv_fwd_t8")

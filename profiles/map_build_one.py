@@ -54,9 +54,8 @@ def main():
     timed("map_permute (transposed)", lambda: ops.map_permute(up, ou), reps, n, 216 * n)
     # the 8-wide form of the same transposed map (inference path since round 3)
     m8 = timed("kernel_map_transpose8 (+key)", lambda: ops.kernel_map_transpose8(down, n, order=None), reps, n, 108 * nc + 36 * n)
-    o8 = timed("map_order (8-wide key)", lambda: ops.map_order(m8[2]), reps, n)
+    o8 = timed("map_order (8-wide key)", lambda: ops.map_order(m8[1]), reps, n)
     timed("map_permute (8-wide)", lambda: ops.map_permute(m8[0], o8), reps, n, 64 * n)
-    timed("order_encode", lambda: ops.order_encode(o8, m8[1]), reps, n)
     timed("kernel_map_bi (transposed lookup)", lambda: ops.kernel_map_bi(coords_p, cidx, 3, 1, -1, want_mask=True), reps, n, 124 * n)
 
 

@@ -970,7 +970,7 @@ def test_batched_weight_packing_equals_single_layer_packing(ops):
 
 
 def test_transposed_map_8_wide_equals_dense(ops, oracle):
-    """pp_kernel_map_transpose8 / pp_order_encode / pp_spconv_fwd_t8: the 8-wide form of a stride-2 transposed map holds
+    """pp_kernel_map_transpose8 / pp_spconv_fwd_t8: the 8-wide form of a stride-2 transposed map holds
     exactly the pairs of the dense 27-wide one (expanded back through the parity classes), its classes are the fine rows'
     coordinate parities, and the convolution on it is bit-identical to the dense form in the same slot order -- fp32 and bf16,
     32 and 64 rows per wave sizes, with and without a slot-ordered strided map behind it"""
@@ -990,17 +990,16 @@ def test_transposed_map_8_wide_equals_dense(ops, oracle):
             rev_order = ops.map_order(ops.map_mask(down))
             rev = ops.map_permute(down, rev_order)
         dense = ops.kernel_map_transpose(rev, n, order=rev_order)      # [27, n] physical fine rows
-        m8, cls, key = ops.kernel_map_transpose8(rev, n, order=rev_order)
+        m8, key = ops.kernel_map_transpose8(rev, n, order=rev_order)
         par = ((cs[:, 1:] & 1) * torch.tensor([1, 2, 4], device="cuda")).sum(1)
         has = (dense >= 0).any(0)
-        assert torch.equal(cls[has].long(), par[has].long())            # class = parity of the fine coordinate (unit 1)
-        assert torch.equal((key.long() >> 8)[has], par[has].long()) and int((m8 >= 0).sum()) == int((dense >= 0).sum())
-        ident = ops.order_encode(None, cls)
-        assert torch.equal(ops.map8_to_dense(m8, ident), dense)
+        assert torch.equal((key.long() >> 8)[has], par[has].long())     # class = parity of the fine coordinate (unit 1)
+        assert int((m8 >= 0).sum()) == int((dense >= 0).sum())
+        assert torch.equal(ops.map8_to_dense(m8), dense)
         order = ops.map_order(key)
         m8s = ops.map_permute(m8, order)
-        enc = ops.order_encode(order, cls)
-        assert torch.equal(enc & 0x0FFFFFFF, order) and torch.equal(ops.map8_to_dense(m8s, enc), dense[:, order.long()])
+        enc = order
+        assert torch.equal(ops.map8_to_dense(m8s), dense[:, order.long()])
         m8s.pp_t8 = True
         dense_s = dense[:, order.long()].contiguous()
         g = torch.Generator(device="cuda").manual_seed(3)
@@ -1014,4 +1013,4 @@ def test_transposed_map_8_wide_equals_dense(ops, oracle):
             assert torch.equal(got, want), (cin, cout, bf16, slot_ordered)
     # the oracle's transposed map (fine rows probing the coarse level with mirrored offsets) names the same pairs
     want = oracle.kernel_map(cs.cpu().numpy(), cc.cpu().numpy(), 3, 1, -1)
-    assert np.array_equal(ops.map8_to_dense(m8, ident).cpu().numpy(), want)
+    assert np.array_equal(ops.map8_to_dense(m8).cpu().numpy(), want)
