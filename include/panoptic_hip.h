@@ -264,6 +264,21 @@ int pp_spconv_bwd_weight(const float* in, int32_t cin, int64_t n_in, const float
 int pp_spconv_bwd_weight_bf16(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
                               const int32_t* nbr, int32_t K, int64_t n_out, float* dw, pp_stream_t stream);
 
+/* pair-major form of K5 (what the training step uses): the pairs of every offset compacted once per kernel map, then one
+ * launch per layer over the lists -- every 16-pair MFMA step is full, and a slot-ordered map needs no re-ordered dout.
+ * pp_wgrad_pairs_build: pairs [<= K*n_out][2] int32 = (output row, input row), offset-major and in row order inside an
+ *   offset; row_order (nullable, int32 [n_out]): row r of the map is output row row_order[r] (slot-ordered maps);
+ *   tile_start int32 [K*ceil(n_out/256) + 1]: exclusive scan of the pairs per 256-row tile (last entry = total); the
+ *   list of offset k is pairs[tile_start[k*T] .. tile_start[(k+1)*T]), T = ceil(n_out/256).  K*n_out < 2^31.
+ * pp_spconv_bwd_weight_pairs: dw [K,cin,cout] float32 (zeroed by the callee) from those lists; map_rows = the n_out the
+ *   lists were built with, n_out = rows of dout; bf16 != 0: operands rounded to bfloat16 in registers.  in, dout < 4 GiB. */
+size_t pp_wgrad_pairs_workspace(int32_t K, int64_t n_out);
+int pp_wgrad_pairs_build(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* row_order, int32_t* pairs,
+                         int32_t* tile_start, void* workspace, size_t workspace_bytes, pp_stream_t stream);
+int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout, int64_t n_out,
+                               const int32_t* pairs, const int32_t* tile_start, int32_t K, int64_t map_rows, float* dw,
+                               int32_t bf16, pp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K6  batch-norm pieces on [n,C]  replaces: ME.MinkowskiBatchNorm (= BatchNorm1d on F), api_modules.py:40,53,269
  * pp_channel_stats: sum[c], sumsq[c] in float64 (training-mode statistics; two-pass inside).
@@ -281,11 +296,13 @@ int pp_bn_bwd_reduce(const float* x, const float* dy, int64_t n, int32_t c, doub
  * fwd: batch mean / biased variance in float64 -> y = act((x-mean)*rstd*weight + bias) (relu != 0 fuses the ReLU);
  *      running_mean/var (nullable pair) updated in place: r = (1-momentum)*r + momentum*stat (unbiased variance);
  *      save_mean/save_rstd [c] float64 are kept for the backward.  weight/bias nullable (affine=False).
+ *      num_batches_tracked (nullable, one int64 on the device): incremented by the same launch (nn.BatchNorm's counter).
  * bwd: y_relu non-null masks dy by (y_relu > 0) first; dx [n,c]; dweight/dbias [c] (nullable). */
 size_t pp_bn_train_workspace(int64_t n, int32_t c);
 int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, double eps,
                     double momentum, float* running_mean, float* running_var, int32_t relu, float* y,
-                    double* save_mean, double* save_rstd, void* ws, size_t ws_bytes, pp_stream_t stream);
+                    double* save_mean, double* save_rstd, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                    pp_stream_t stream);
 int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_t n, int32_t c,
                     const float* weight, const double* save_mean, const double* save_rstd, float* dx,
                     float* dweight, float* dbias, void* ws, size_t ws_bytes, pp_stream_t stream);

@@ -172,6 +172,7 @@ class CoordinateManager:
         self._ready = {}
         self._log = None
         self._worker = None
+        self._side_built = False  # anything built on the prefetch stream? (otherwise no cross-stream bookkeeping is needed)
         self._worker_err = None
         self._input_final = threading.Event()  # set when levels[1] and its same-level map are the final ones
         try:
@@ -242,6 +243,7 @@ class CoordinateManager:
             except BaseException as e:  # surfaced by join_prefetch
                 self._worker_err = e
 
+        self._side_built = True
         self._worker = threading.Thread(target=work, name="pp-map-prefetch")
         self._worker.start()
 
@@ -255,10 +257,11 @@ class CoordinateManager:
                 err, self._worker_err = self._worker_err, None
                 raise err
 
-    @staticmethod
-    def _consumed_here(*tensors):
+    def _consumed_here(self, *tensors):
         """a tensor built on the prefetch stream belongs to that stream's allocator pool: tell the allocator that the
         calling stream reads it too, so that the block is not handed out again while this stream's kernels are pending"""
+        if not self._side_built:
+            return
         cur = torch.cuda.current_stream()
         for t in tensors:
             if t is not None and t.is_cuda and getattr(t, "pp_seen_by", None) != cur.cuda_stream:
@@ -503,6 +506,15 @@ def cat(*tensors):
 # ------------------------------------------------------------------------------------------------
 # autograd functions (training path); eval uses the fused entry points below
 # ------------------------------------------------------------------------------------------------
+# weight gradients over per-offset pair lists (pp_wgrad_pairs_build + pp_spconv_bwd_weight_pairs); PP_WGRAD_PAIRS=0: over the
+# dense map (pp_spconv_bwd_weight)
+WGRAD_PAIRS = os.environ.get("PP_WGRAD_PAIRS", "1") != "0"
+
+
+def cout_ok(cout):
+    return cout <= 192
+
+
 def _pack(kernel, transpose=False, kflip=False):
     """packed weights of a layer: model parameters go through the per-version cache (one launch re-packs all of them after
     an optimizer step), anything else is packed on the spot"""
@@ -547,9 +559,17 @@ class _SparseConvFn(torch.autograd.Function):
                 ops.PROFILE_TAG = "fwd"
         if ctx.needs_input_grad[1]:
             order = getattr(ctx.nbr, "pp_order", None)
-            # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
-            dout_s = dout if order is None else ops.gather_rows(dout, order.long())
-            dw = ops.spconv_bwd_weight(feats, dout_s, ctx.nbr, ctx.K, bf16=ctx.bf16)
+            if WGRAD_PAIRS and ctx.nbr is not None and cout_ok(dout.shape[1]):
+                # the pairs of the map compacted per offset, once per map (every layer on this map re-uses the lists);
+                # a slot order is folded into the lists, dout is read in its own row order
+                wp = getattr(ctx.nbr, "pp_wpairs", None)
+                if wp is None:
+                    wp = ctx.nbr.pp_wpairs = ops.wgrad_pairs(ctx.nbr, ctx.K, row_order=order)
+                dw = ops.spconv_bwd_weight_pairs(feats, dout, wp, bf16=ctx.bf16)
+            else:
+                # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
+                dout_s = dout if order is None else ops.gather_rows(dout, order.long())
+                dw = ops.spconv_bwd_weight(feats, dout_s, ctx.nbr, ctx.K, bf16=ctx.bf16)
             if ctx.kflip:
                 dw = dw.flip(0)
             dw = dw.reshape(kernel.shape)
@@ -563,8 +583,8 @@ class _BatchNormTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, relu, momentum, running):
         x = x.contiguous()
-        rm, rv = running if running is not None else (None, None)
-        y, mean, rstd = ops.bn_train_fwd(x, weight, bias, eps, momentum, rm, rv, relu)
+        rm, rv, nbt = running if running is not None else (None, None, None)
+        y, mean, rstd = ops.bn_train_fwd(x, weight, bias, eps, momentum, rm, rv, relu, nbt)
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
         return y
 
@@ -589,7 +609,7 @@ class _AffineFn(torch.autograd.Function):
     def backward(ctx, dy):
         scale, y = ctx.saved_tensors
         if ctx.act == 1:
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)  # dy where y > 0 else 0, one launch
         if scale is not None:
             dy = ops.affine_act(dy.contiguous(), scale, None)
         return dy, None, None, None
@@ -779,13 +799,10 @@ class MinkowskiBatchNorm(nn.Module):
             mom = 0.0
             if bn.track_running_stats:
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                running = (bn.running_mean, bn.running_var)  # updated in place by the finalize kernel
+                # updated in place by the finalize kernel (the counter too: one launch less per layer)
+                running = (bn.running_mean, bn.running_var, bn.num_batches_tracked)
                 self._folded = None  # ... which does not bump the tensors' version counters
-            y = _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu, mom, running)
-            if bn.track_running_stats:
-                with torch.no_grad():
-                    bn.num_batches_tracked += 1
-            return y
+            return _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu, mom, running)
         scale, shift = self.folded()
         return _AffineFn.apply(feats, scale, shift, 1 if relu else 0)
 

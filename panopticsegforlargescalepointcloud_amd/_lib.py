@@ -74,11 +74,14 @@ SIGNATURES = {
     "pp_spconv_fwd_ex": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "pp_spconv_bwd_weight": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
     "pp_spconv_bwd_weight_bf16": (C.c_int, [vp, i32, i64, vp, i32, vp, i32, i64, vp, vp]),
+    "pp_wgrad_pairs_workspace": (sz, [i32, i64]),
+    "pp_wgrad_pairs_build": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "pp_spconv_bwd_weight_pairs": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, vp, i32, i64, vp, i32, vp]),
     "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),
     "pp_affine_act": (C.c_int, [vp, i64, i32, vp, vp, i32, f32, vp, vp, vp]),
     "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),
     "pp_bn_train_workspace": (sz, [i64, i32]),
-    "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
     "pp_bn_train_bwd": (C.c_int, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "pp_linear_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),

@@ -148,14 +148,23 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_partial(const float* __res
   }
   if (tid < cout) out[ne + tid] = accb;
 }
+// one block per entry: 256 threads split the partials (fixed assignment), LDS tree in a fixed order -> reproducible
 __global__ __launch_bounds__(256) void k_linear_wgrad_finish(const double* __restrict__ partial, int blocks, int ne, int cout,
                                                               float* __restrict__ dw, float* __restrict__ db) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ne + cout) return;
+  __shared__ double red[256];
+  const int e = blockIdx.x, tid = threadIdx.x;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * (ne + cout) + e];
-  if (e < ne) dw[e] = (float)s;
-  else if (db) db[e - ne] = (float)s;
+  for (int b = tid; b < blocks; b += 256) s += partial[(int64_t)b * (ne + cout) + e];
+  red[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (e < ne) dw[e] = (float)red[0];
+    else if (db) db[e - ne] = (float)red[0];
+  }
 }
 static int lwg_blocks(int64_t n) {
   const int64_t t = (n + LWG_TILE - 1) / LWG_TILE;
@@ -174,7 +183,7 @@ extern "C" int pp_linear_wgrad(const float* x, const float* dy, int64_t n, int32
   const int blocks = lwg_blocks(n);
   const int ne = cin * cout;
   hipLaunchKernelGGL(k_linear_wgrad_partial, dim3(blocks), dim3(256), 0, s, x, dy, n, cin, cout, (double*)ws);
-  hipLaunchKernelGGL(k_linear_wgrad_finish, dim3(pp_blocks(ne + cout, 256)), dim3(256), 0, s, (const double*)ws, blocks, ne, cout, dw, db);
+  hipLaunchKernelGGL(k_linear_wgrad_finish, dim3(ne + cout), dim3(256), 0, s, (const double*)ws, blocks, ne, cout, dw, db);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
@@ -341,6 +350,7 @@ struct BnFinalize {
   double n, eps, momentum;
   const float *weight, *bias;
   float *running_mean, *running_var;   // forward, nullable
+  int64_t* num_batches_tracked;        // forward, nullable: += 1 (nn.BatchNorm's counter, kept on the device)
   float *k0, *k1, *k2;                 // forward: scale, shift, -   backward: a, b, c
   double *save_mean, *save_rstd;       // forward: written; backward: read
   float *dweight, *dbias;              // backward, nullable
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalize f) {
   sm[1][j][cl] = a1;
   __syncthreads();
   if (j != 0 || col >= f.c) return;
+  if (col == 0 && !f.backward && f.num_batches_tracked) *f.num_batches_tracked += 1;
   a0 = a1 = 0.0;
   for (int q = 0; q < 32; ++q) {
     a0 += sm[0][q][cl];
@@ -454,7 +465,8 @@ static int bn_partial_launch(const float* x, const float* dy, const float* yr, i
 
 extern "C" int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, double eps,
                                double momentum, float* running_mean, float* running_var, int32_t relu, float* y,
-                               double* save_mean, double* save_rstd, void* ws, size_t ws_bytes, pp_stream_t stream) {
+                               double* save_mean, double* save_rstd, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                               pp_stream_t stream) {
   PP_REQUIRE(c >= 1 && c <= 256, "pp_bn_train_fwd: c must be in [1,256]");
   PP_REQUIRE(n >= 1, "pp_bn_train_fwd: batch statistics need at least one row");
   PP_REQUIRE(x && y && save_mean && save_rstd && ws, "pp_bn_train_fwd: null pointer");
@@ -470,6 +482,7 @@ extern "C" int pp_bn_train_fwd(const float* x, int64_t n, int32_t c, const float
   f.partial = partial; f.nb = nb; f.c = c; f.backward = 0;
   f.n = (double)n; f.eps = eps; f.momentum = momentum;
   f.weight = weight; f.bias = bias; f.running_mean = running_mean; f.running_var = running_var;
+  f.num_batches_tracked = num_batches_tracked;
   f.k0 = coef; f.k1 = coef + c; f.k2 = nullptr; f.save_mean = save_mean; f.save_rstd = save_rstd;
   hipLaunchKernelGGL(k_bn_finalize, dim3((c + 7) / 8), dim3(256), 0, s, f);
   PP_LAUNCH_CHECK();

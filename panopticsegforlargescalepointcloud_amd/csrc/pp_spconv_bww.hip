@@ -182,3 +182,264 @@ int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* d
   PP_LAUNCH_CHECK();
   return PP_OK;
 }
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// Pair-major weight gradient.  On the model's maps k_spconv_bww2 runs only 1.2 - 1.7 x faster than on a dense map with
+// 27 neighbours per row although the maps hold 5.6 .. 16 (profiles/r03_ab_bww3.log): its time goes into the (offset,
+// 16-row) groups it has to enter -- every group with at least one neighbour costs the full loads -- and with the
+// neighbours of one offset scattered over the rows, about twice as many groups are entered as the pairs would fill.
+// dW[k] is a sum over PAIRS, and unlike the forward pass nothing is accumulated per output row, so the pairs of every
+// offset can be compacted first:
+//   pp_wgrad_pairs_build : per offset k the list of (output row, input row) of its pairs, in row order (tile counts ->
+//                          exclusive scan -> ordered write; a map is compacted once and serves every layer that uses it)
+//   k_spconv_bww4        : a wave walks a chunk of one offset's list; every 16-pair step is full (but the tail), both
+//                          operands are gathered (dout rows by the stored output row: a slot-ordered map needs no
+//                          re-ordered copy of dout any more, the row order is folded into the list).
+// -------------------------------------------------------------------------------------------------------------------
+#define WP_TILE 256   // rows of one offset per counted tile = one block step; the lists are addressed per tile (tile_start)
+
+__global__ __launch_bounds__(256) void k_wpairs_count(const int32_t* __restrict__ nbr, int64_t n_out, int tiles_per_k,
+                                                      int32_t* __restrict__ tile_count) {
+  __shared__ int wc[4];
+  const int k = blockIdx.x / tiles_per_k, t = blockIdx.x - k * tiles_per_k;
+  const int64_t r = (int64_t)t * WP_TILE + threadIdx.x;
+  const unsigned long long b = __ballot(r < n_out && nbr[(int64_t)k * n_out + r] >= 0);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(256) void k_wpairs_write(const int32_t* __restrict__ nbr, const int32_t* __restrict__ order,
+                                                      int64_t n_out, int tiles_per_k,
+                                                      const int32_t* __restrict__ tile_start, int2* __restrict__ pairs) {
+  __shared__ int wc[4];
+  const int k = blockIdx.x / tiles_per_k, t = blockIdx.x - k * tiles_per_k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)t * WP_TILE + threadIdx.x;
+  const int src = r < n_out ? nbr[(int64_t)k * n_out + r] : -1;
+  const unsigned long long b = __ballot(src >= 0);
+  if (lane == 0) wc[wave] = __popcll(b);
+  __syncthreads();
+  int off = tile_start[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += wc[w];
+  if (src >= 0) pairs[off + __popcll(b & ((1ull << lane) - 1ull))] = make_int2(order ? order[r] : (int)r, src);
+}
+
+extern "C" size_t pp_wgrad_pairs_workspace(int32_t K, int64_t n_out) {
+  const int64_t tiles = (int64_t)K * ((n_out + WP_TILE - 1) / WP_TILE);
+  return pp_align((size_t)tiles * 4) + pp_scan_workspace(tiles) + 256;
+}
+
+extern "C" int pp_wgrad_pairs_build(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* row_order,
+                                    int32_t* pairs, int32_t* tile_start, void* ws, size_t ws_bytes, pp_stream_t stream) {
+  PP_REQUIRE(nbr && pairs && tile_start && ws, "pp_wgrad_pairs_build: null pointer");
+  PP_REQUIRE(K >= 1 && n_out >= 0 && (int64_t)K * n_out < (int64_t(1) << 31), "pp_wgrad_pairs_build: K * n_out must be < 2^31");
+  PP_REQUIRE(ws_bytes >= pp_wgrad_pairs_workspace(K, n_out), "pp_wgrad_pairs_build: workspace too small");
+  hipStream_t s = pp_s(stream);
+  const int tiles_per_k = (int)((n_out + WP_TILE - 1) / WP_TILE);
+  const int64_t tiles = (int64_t)K * tiles_per_k;
+  if (tiles == 0) {
+    PP_HIP(hipMemsetAsync(tile_start, 0, sizeof(int32_t), s));
+    return PP_OK;
+  }
+  PPArena ar(ws, ws_bytes);
+  int32_t* cnt = ar.take<int32_t>((size_t)tiles);
+  hipLaunchKernelGGL(k_wpairs_count, dim3((unsigned)tiles), dim3(256), 0, s, nbr, n_out, tiles_per_k, cnt);
+  PP_LAUNCH_CHECK();
+  int rc = pp_exclusive_scan_i32(cnt, tile_start, tiles, tile_start + tiles, ar.cur(), ar.left(), s);
+  if (rc != PP_OK) return rc;
+  hipLaunchKernelGGL(k_wpairs_write, dim3((unsigned)tiles), dim3(256), 0, s, nbr, row_order, n_out, tiles_per_k, tile_start,
+                     (int2*)pairs);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+template <int MT, int NTO, bool BF16, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_spconv_bww4(const float* __restrict__ in, int cin, u32 in_bytes,
+                                                     const float* __restrict__ dout, int cout, u32 dout_bytes,
+                                                     const int2* __restrict__ pairs, const int32_t* __restrict__ tile_start,
+                                                     int tiles_per_k, int chunk, float* __restrict__ dw) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  // the WPB waves of a block: consecutive chunks of `chunk` pairs of ONE offset; their partial tiles are added in LDS
+  // and leave the block as one set of atomics (device-scope float atomics are the expensive part of short chunks)
+  __shared__ float red[WPB][MT * NTO][256];
+  const int k = blockIdx.y;
+  const int k0 = tile_start[k * tiles_per_k], cnt = tile_start[(k + 1) * tiles_per_k] - k0;
+  if ((int64_t)blockIdx.x * WPB * chunk >= cnt) return;  // the whole block is past the end of the list
+  const int64_t p0 = ((int64_t)blockIdx.x * WPB + wave) * chunk;
+  const int ks = k0 + (int)(p0 < cnt ? p0 : cnt);
+  const int np = p0 >= cnt ? 0 : (cnt - (int)p0 < chunk ? cnt - (int)p0 : chunk);
+  const int ci0 = blockIdx.z * (16 * MT);
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)dout_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(pairs + ks), 0, np * 8, 0x00020000);
+  const u32 cin4 = (u32)cin * 4u, cout4 = (u32)cout * 4u;
+  u32 cio[MT], cofs[NTO];
+  bool civ[MT], cov[NTO];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int ci = ci0 + mt * 16 + i;
+    civ[mt] = ci < cin;
+    cio[mt] = (u32)ci * 4u;
+  }
+#pragma unroll
+  for (int jt = 0; jt < NTO; ++jt) {
+    const int co = jt * 16 + i;
+    cov[jt] = co < cout;
+    cofs[jt] = (u32)co * 4u;
+  }
+  f32x4 acc[MT][NTO];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int jt = 0; jt < NTO; ++jt) acc[mt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  // software pipeline, two steps deep: the operands of step r+16 are in flight during the MFMAs of step r, the pairs of
+  // step r+32 behind them.  Pairs beyond the chunk become (-1, -1) -> out-of-range offsets -> hardware zeros, no traffic.
+#define BWW4_PAIRS(R, P)                                                                                              \
+  _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                                     \
+    P[m] = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rp, ((R) + 4 * q + m) * 8, 0, 0));            \
+  }
+#define BWW4_MASK(R, P) \
+  _Pragma("unroll") for (int m = 0; m < 4; ++m) if ((R) + 4 * q + m >= np) P[m] = (v2i){-1, -1};
+#define BWW4_OPERANDS(P, AX, BX)                                                                                      \
+  _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                                     \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                               \
+      const u32 o = (P[m].y < 0 || !civ[mt]) ? 0xFFFFFFFFu : (u32)P[m].y * cin4 + cio[mt];                            \
+      AX[m][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)o, 0, 0));                  \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int jt = 0; jt < NTO; ++jt) {                                                              \
+      const u32 o = (P[m].x < 0 || !cov[jt]) ? 0xFFFFFFFFu : (u32)P[m].x * cout4 + cofs[jt];                          \
+      BX[m][jt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)o, 0, 0));                  \
+    }                                                                                                                 \
+  }
+  v2i pr[4];
+  float A[4][MT], B[4][NTO], An[4][MT], Bn[4][NTO];
+  BWW4_PAIRS(0, pr)
+  BWW4_MASK(0, pr)
+  BWW4_OPERANDS(pr, A, B)
+  BWW4_PAIRS(16, pr)
+  for (int r = 0; r < np; r += 16) {
+    BWW4_MASK(r + 16, pr)
+    BWW4_OPERANDS(pr, An, Bn)
+    BWW4_PAIRS(r + 32, pr)
+    if constexpr (BF16) {
+      s16x4 ah[MT], bh[NTO];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) ah[mt] = pp_bf16x4((f32x4){A[0][mt], A[1][mt], A[2][mt], A[3][mt]});
+#pragma unroll
+      for (int jt = 0; jt < NTO; ++jt) bh[jt] = pp_bf16x4((f32x4){B[0][jt], B[1][jt], B[2][jt], B[3][jt]});
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < NTO; ++jt)
+          acc[mt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[jt], acc[mt][jt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int jt = 0; jt < NTO; ++jt)
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][mt], B[m][jt], acc[mt][jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) A[m][mt] = An[m][mt];
+#pragma unroll
+      for (int jt = 0; jt < NTO; ++jt) B[m][jt] = Bn[m][jt];
+    }
+  }
+#undef BWW4_PAIRS
+#undef BWW4_MASK
+#undef BWW4_OPERANDS
+  // block reduction of the waves' tiles through LDS, then one atomic per entry.  D[row = ci_local = 4q + e][col = co_local = i]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int jt = 0; jt < NTO; ++jt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][mt * NTO + jt][e * 64 + lane] = acc[mt][jt][e];
+  __syncthreads();
+  for (int x = threadIdx.x; x < MT * NTO * 256; x += WPB * 64) {
+    const int tile = x >> 8, e = (x >> 6) & 3, ln = x & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) v += red[w][tile][e * 64 + ln];
+    const int mt = tile / NTO, jt = tile - mt * NTO;
+    const int ci = ci0 + mt * 16 + 4 * (ln >> 4) + e, co = jt * 16 + (ln & 15);
+    if (ci < cin && co < cout && v != 0.f) atomicAdd(&dw[((int64_t)k * cin + ci) * cout + co], v);
+  }
+}
+
+#ifndef BWW4_WPB
+#define BWW4_WPB 4   // waves per block (their tiles meet in LDS: WPB * MT * NTO KiB)
+#endif
+template <int MT, int NTO>
+static void bww4_go(dim3 grid, hipStream_t s, const float* in, int cin, u32 in_bytes, const float* dout, int cout,
+                    u32 dout_bytes, const int2* pairs, const int32_t* tile_start, int tiles_per_k, int chunk, float* dw,
+                    int bf16) {
+  if (bf16)
+    hipLaunchKernelGGL((k_spconv_bww4<MT, NTO, true, BWW4_WPB>), grid, dim3(BWW4_WPB * 64), 0, s, in, cin, in_bytes, dout, cout,
+                       dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
+  else
+    hipLaunchKernelGGL((k_spconv_bww4<MT, NTO, false, BWW4_WPB>), grid, dim3(BWW4_WPB * 64), 0, s, in, cin, in_bytes, dout, cout,
+                       dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
+}
+
+extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                          int64_t n_out, const int32_t* pairs, const int32_t* tile_start, int32_t K,
+                                          int64_t map_rows, float* dw, int32_t bf16, pp_stream_t stream) {
+  PP_REQUIRE(in && dout && dw && pairs && tile_start, "pp_spconv_bwd_weight_pairs: null pointer");
+  PP_REQUIRE(cin >= 1 && cout >= 1 && cout <= 192, "pp_spconv_bwd_weight_pairs: cout must be in [1,192]");
+  PP_REQUIRE((double)n_in * cin * 4.0 < 4294967040.0 && (double)n_out * cout * 4.0 < 4294967040.0,
+             "pp_spconv_bwd_weight_pairs: in and dout must be < 4 GiB each (32-bit buffer offsets)");
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
+  if (map_rows == 0 || n_in == 0 || n_out == 0) return PP_OK;
+  const int tiles_per_k = (int)((map_rows + WP_TILE - 1) / WP_TILE);
+  const int nto = (cout + 15) / 16, ntiles = (cin + 15) / 16;
+  int mt = nto <= 2 ? 4 : (nto <= 6 ? 2 : 1);
+  while (mt > 1 && ntiles % mt != 0) mt >>= 1;
+  const unsigned gz = (unsigned)(ntiles / mt);
+  // an offset holds at most map_rows pairs; blocks past the end of their offset's list leave at once
+  static const int chunk_env = [] { const char* e = getenv("PP_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();
+  int chunk = 256;  // pairs per wave: 128 / 256 / 384 measured within 5 % of each other, 512 and 64 slower
+  if (((map_rows + 4 * chunk - 1) / (4 * chunk)) * (int64_t)K * gz < 2048) chunk = 128;
+  if (chunk_env > 0) chunk = chunk_env;
+  dim3 grid((unsigned)((map_rows + BWW4_WPB * chunk - 1) / (BWW4_WPB * chunk)), (unsigned)K, gz);
+  const u32 in_bytes = (u32)((uint64_t)n_in * cin * 4u), dout_bytes = (u32)((uint64_t)n_out * cout * 4u);
+#define BWW4(M, N) \
+  bww4_go<M, N>(grid, s, in, cin, in_bytes, dout, cout, dout_bytes, (const int2*)pairs, tile_start, tiles_per_k, chunk, dw, bf16); break;
+  switch (mt * 16 + nto) {
+    case 4 * 16 + 1: BWW4(4, 1)
+    case 4 * 16 + 2: BWW4(4, 2)
+    case 2 * 16 + 1: BWW4(2, 1)
+    case 2 * 16 + 2: BWW4(2, 2)
+    case 2 * 16 + 3: BWW4(2, 3)
+    case 2 * 16 + 4: BWW4(2, 4)
+    case 2 * 16 + 5: BWW4(2, 5)
+    case 2 * 16 + 6: BWW4(2, 6)
+    case 1 * 16 + 1: BWW4(1, 1)
+    case 1 * 16 + 2: BWW4(1, 2)
+    case 1 * 16 + 3: BWW4(1, 3)
+    case 1 * 16 + 4: BWW4(1, 4)
+    case 1 * 16 + 5: BWW4(1, 5)
+    case 1 * 16 + 6: BWW4(1, 6)
+    case 1 * 16 + 7: BWW4(1, 7)
+    case 1 * 16 + 8: BWW4(1, 8)
+    case 1 * 16 + 9: BWW4(1, 9)
+    case 1 * 16 + 10: BWW4(1, 10)
+    case 1 * 16 + 11: BWW4(1, 11)
+    default: BWW4(1, 12)
+  }
+#undef BWW4
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -678,6 +678,51 @@ def spconv_bwd_weight(inp, dout, nbr, K, bf16=False):
     return dw
 
 
+class WgradPairs:
+    """the pairs of a kernel map compacted per offset (pp_wgrad_pairs_build): what spconv_bwd_weight_pairs walks"""
+    __slots__ = ("pairs", "tile_start", "K", "rows", "n_pairs")
+
+    def __init__(self, pairs, tile_start, K, rows, n_pairs):
+        self.pairs, self.tile_start, self.K, self.rows, self.n_pairs = pairs, tile_start, K, rows, n_pairs
+
+
+def wgrad_pairs(nbr, K, row_order=None):
+    """(output row, input row) lists per offset of the dense map nbr [K, rows]; row_order folds a slot order in (row r of
+    the map is output row row_order[r]).  The list buffer is sized for the worst case (K * rows pairs)."""
+    lib = _lib.load()
+    nbr = _need(nbr, torch.int32, "nbr")
+    rows = nbr.shape[1]
+    dev = nbr.device
+    tiles = K * ((rows + 255) // 256)
+    pairs = torch.empty((max(K * rows, 1), 2), dtype=torch.int32, device=dev)
+    tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
+    nbytes = lib.pp_wgrad_pairs_workspace(K, rows)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pp_wgrad_pairs_build(_ptr(nbr), K, rows, _ptr(_need(row_order, torch.int32, "row_order")), _ptr(pairs),
+                                        _ptr(tile_start), _ptr(ws), nbytes, _stream()), "pp_wgrad_pairs_build")
+    return WgradPairs(pairs, tile_start, K, rows, _pairs_of(nbr))
+
+
+def spconv_bwd_weight_pairs(inp, dout, wp, bf16=False):
+    """dW [K, cin, cout] over the pair lists of wgrad_pairs (dout in its own row order)"""
+    lib = _lib.load()
+    inp = _need(inp, torch.float32, "in")
+    dout = _need(dout, torch.float32, "dout")
+    cin, cout = inp.shape[1], dout.shape[1]
+    dw = torch.empty((wp.K, cin, cout), dtype=torch.float32, device=inp.device)
+    prof = PROFILER
+    if prof is not None:
+        e0, e1 = prof.events()
+        e0.record()
+    _lib.check(lib.pp_spconv_bwd_weight_pairs(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, dout.shape[0], _ptr(wp.pairs),
+                                              _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _stream()),
+               "pp_spconv_bwd_weight_pairs")
+    if prof is not None:
+        e1.record()
+        prof.records_w.append((e0, e1, inp.shape[0], dout.shape[0], cin, cout, wp.K, wp.n_pairs))
+    return dw
+
+
 def channel_stats(x):
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
@@ -699,8 +744,9 @@ def bn_bwd_reduce(x, dy):
     return a, b
 
 
-def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu):
-    """Training-mode BatchNorm1d (+ fused ReLU); running statistics (nullable) updated in place.
+def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked=None):
+    """Training-mode BatchNorm1d (+ fused ReLU); running statistics (nullable) updated in place, num_batches_tracked (nullable
+    int64 scalar on the device) incremented by the same launches.
     Returns (y, save_mean, save_rstd); the saved statistics are float64."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
@@ -713,7 +759,9 @@ def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu
                                    _ptr(_need(bias, torch.float32, "bias")), float(eps), float(momentum),
                                    _ptr(_need(running_mean, torch.float32, "running_mean")),
                                    _ptr(_need(running_var, torch.float32, "running_var")), 1 if relu else 0,
-                                   _ptr(y), _ptr(stat[0]), _ptr(stat[1]), _ptr(ws), nbytes, _stream()),
+                                   _ptr(y), _ptr(stat[0]), _ptr(stat[1]),
+                                   _ptr(_need(num_batches_tracked, torch.int64, "num_batches_tracked")), _ptr(ws), nbytes,
+                                   _stream()),
                "pp_bn_train_fwd")
     return y, stat[0], stat[1]
 

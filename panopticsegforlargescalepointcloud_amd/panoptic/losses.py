@@ -9,6 +9,15 @@ from ..torch_points_kernels import instance_iou, instance_iou_csr
 from ..torch_scatter import gather, scatter
 
 
+def semantic_nll(log_probs, labels, ignore_index):
+    """mean over the non-ignored rows of -log_probs[i, labels[i]] == torch.nn.functional.nll_loss(..., ignore_index) (reference
+    pointgroup3heads.py:367) written as gather + masked mean: torch's nll_loss forward reduces in ONE workgroup (0.33 ms at
+    325 k rows)"""
+    keep = labels != ignore_index
+    picked = log_probs.gather(1, labels.clamp_min(0).unsqueeze(1)).squeeze(1)
+    return -(picked * keep).sum() / keep.sum()
+
+
 def offset_loss(pred_offsets, gt_offsets, total_instance_points):
     """L1 regression + direction (negative cosine) terms over the instance points, both normalised by the number of
     instance points (panoptic_losses.py:7-23)."""

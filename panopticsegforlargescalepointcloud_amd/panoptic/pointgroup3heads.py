@@ -24,7 +24,7 @@ from ..modules import MLP, Linear, Seq, fused_head, head_spec
 from ..torch_points_kernels import region_grow_csr
 from ..torch_scatter import gather, scatter
 from ..utils import meanshift_cluster
-from .losses import discriminative_loss, instance_iou_loss, instance_ious, mask_loss, offset_loss
+from .losses import discriminative_loss, instance_iou_loss, instance_ious, mask_loss, offset_loss, semantic_nll
 from .structures import PanopticLabels, PanopticResults
 
 IGNORE_LABEL = -1  # torch_points3d/datasets/segmentation/__init__.py
@@ -358,8 +358,7 @@ class PointGroup3heads(nn.Module):
     # ------------------------------------------------------------------ losses / backward
     def _compute_loss(self, epoch):
         out, inp = self.output, self.input
-        self.semantic_loss = torch.nn.functional.nll_loss(out.semantic_logits, self.labels.y.to(torch.int64),
-                                                          ignore_index=IGNORE_LABEL)
+        self.semantic_loss = semantic_nll(out.semantic_logits, self.labels.y.to(torch.int64), IGNORE_LABEL)
         self.loss = self.opt.loss_weights.semantic * self.semantic_loss
         mask = inp.instance_mask
         if out.offset_logits is not None:

@@ -157,7 +157,8 @@ def train_step(model, data, optimizer, epoch, device, world_size=1, group=None, 
     """set_input -> forward -> loss -> backward (gradient all-reduces overlapped) -> optimizer step.  Returns the local
     loss.  Pass a GradientReducer built once over model.parameters() to overlap; without one the reduction runs after
     backward."""
-    model.train()
+    if not model.training:  # nn.Module.train() walks every submodule (1.5 ms of host time for this model)
+        model.train()
     model.set_input(data, device)
     optimizer.zero_grad(set_to_none=True)
     model.forward(epoch=epoch)

@@ -3,11 +3,12 @@
 # -> gpurun_out/pmc_<tag>/{time.txt,passN.md,summary.md}.  Counter passes run with --kernel-trace only.
 set -u
 TAG=$1; shift
+PROG=${PMC_PROG:-conv_one.py}   # PMC_PROG=wgrad_one.py: the weight-gradient shapes (arguments: <shape list>)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/profiles/conv_one.py "$@" 5 2>/dev/null | tail -2 > $O/time.txt
+python $R/profiles/$PROG "$@" 5 2>/dev/null | tail -${PMC_TAIL:-2} > $O/time.txt
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" \
          "SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
@@ -18,7 +19,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
   i=$((i+1))
   [ $i -gt ${PMC_PASSES:-7} ] && break   # PMC_PASSES=2: the two SQ passes only (the TCC / TCP passes take minutes each)
   rm -rf /tmp/pm_$i
-  timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pm_$i -o p -- python $R/profiles/conv_one.py "$@" 2 > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pm_$i -o p -- python $R/profiles/$PROG "$@" 2 > /dev/null 2>&1
   python $R/profiles/rocpd_summary.py --pmc /tmp/pm_$i/p_results.db $O/pass$i.md > /dev/null 2>&1 || echo "pass $i failed ($C)" >> $O/time.txt
 done
 ( cat $O/time.txt; echo; echo "| kernel | counter | dispatches | avg per dispatch | sum |"; echo "|---|---|---|---|---|"; grep -h spconv $O/pass*.md ) > $O/summary.md

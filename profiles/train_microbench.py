@@ -51,25 +51,31 @@ def main():
     ids = [(rank * ncyl + i) % len(tiles) for i in range(ncyl)]
     data, n = make_batch(scene, tiles, ids)
     data = data.to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    fused = os.environ.get("PP_ADAM", "fused") == "fused"   # torch's single-launch Adam; "foreach" = torch's default on a GPU
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=fused)
     reducer = GradientReducer(model.parameters()) if world > 1 else None  # bucketed all-reduce overlapped with backward
     from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, ops
     bf16 = os.environ.get("PP_CONV_DTYPE", "fp32").lower() == "bf16"
     result = {"metric": "training step (fwd + bwd + Adam), BASELINE.json configs[4] shape on one GPU", "unit": "ms/step",
               "dtype": "bf16 convolution compute, fp32 tensors" if bf16 else "f32", "n_gpus": world, "voxels_per_rank": n,
-              "cylinders_per_rank": ncyl, "data": "synthetic", "modes": {}}
-    for epoch, tag in [(1, "epoch <= prepare_epoch (heads + losses)"), (100, "epoch > prepare_epoch (+ grouping, ScorerUnet, score loss)")]:
+              "cylinders_per_rank": ncyl, "data": "synthetic",
+              "optimizer": "torch.optim.Adam(lr=1e-3, %s)" % ("fused=True" if fused else "foreach"), "modes": {}}
+    modes = [(1, "epoch <= prepare_epoch (heads + losses)"), (100, "epoch > prepare_epoch (+ grouping, ScorerUnet, score loss)")]
+    if os.environ.get("PP_TRAIN_MODES"):  # "1" or "2": one mode only (kernel traces of one mode)
+        modes = [modes[int(m) - 1] for m in os.environ["PP_TRAIN_MODES"].split(",")]
+    for epoch, tag in modes:
         times = []
         for it in range(7):
-            if it == 6:  # one more step with per-launch HIP events on the convolution kernels (not part of the median)
+            if it == 2:  # one step with per-launch HIP events on the convolution kernels (not part of the median)
                 ops.PROFILER = ops.LaunchProfiler()
+            elif it == 3:
+                prof, ops.PROFILER = ops.PROFILER, None
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             train_step(model, data, opt, epoch, dev, world, reducer=reducer)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-        prof, ops.PROFILER = ops.PROFILER, None
-        t = float(np.median(times[2:6]))
+        t = float(np.median(times[3:7]))
         fwd, dgrad, wgrad = prof.summarize("fwd"), prof.summarize("dgrad"), prof.summarize_wgrad()
 
         def roof(p):

@@ -1,5 +1,5 @@
 """Which Python lines launch the expensive torch kernels of a training step (torch.profiler with stacks).
-usage (GPU box): python profiles/train_torch_profile.py [epoch]"""
+usage (GPU box): python profiles/train_torch_profile.py [epoch] [sort key: self_cuda_time_total | count]"""
 import os
 import sys
 
@@ -21,14 +21,22 @@ def main():
     model = bench.build_model(dev, 0.05)[0].train()
     data, n = tm.make_batch(scene, tiles, [0, 1, 2, 3])
     data = data.to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    fused = os.environ.get("PP_ADAM", "fused") == "fused"   # torch's single-launch Adam; "foreach" = torch's default on a GPU
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=fused)
     for _ in range(3):
         train_step(model, data, opt, epoch, dev, 1)
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         train_step(model, data, opt, epoch, dev, 1)
         torch.cuda.synchronize()
-    print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=25, max_name_column_width=60,
+    if len(sys.argv) > 2 and sys.argv[2] == "stacks":  # who calls the small aten ops: count per (op, Python stack)
+        rows = [e for e in prof.key_averages(group_by_stack_n=8) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+        for e in sorted(rows, key=lambda e: -e.count)[:60]:
+            st = [f for f in e.stack if "panopticseg" in f or "training.py" in f][:3]
+            print("%5d x %-28s %7.0f us  %s" % (e.count, e.key, e.self_device_time_total, " <- ".join(f.split("repo/")[-1] for f in st)))
+        return
+    by = sys.argv[2] if len(sys.argv) > 2 else "self_cuda_time_total"   # or "count": which lines launch the MOST kernels
+    print(prof.key_averages(group_by_stack_n=6).table(sort_by=by, row_limit=25 if by != "count" else 70, max_name_column_width=60,
                                                       max_src_column_width=110))
 
 

@@ -137,11 +137,14 @@ def test_spconv_strided_and_transposed(ops, oracle):
     np.testing.assert_allclose(z.cpu().numpy(), z_want, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 16), (64, 32), (32, 16), (48, 96), (16, 128), (16, 192), (20, 40), (96, 96)])
+@pytest.mark.parametrize("cin,cout", [(64, 16), (64, 32), (32, 16), (48, 96), (16, 128), (16, 192), (20, 40), (96, 96),
+                                      (48, 16), (48, 32), (32, 48), (32, 64), (16, 80), (16, 112), (16, 144), (16, 160),
+                                      (16, 176), (8, 8), (4, 4), (4, 16), (224, 96), (6, 10), (18, 7)])
 def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
-    """every (ci tiles per wave, co tiles) instantiation of the pipelined weight gradient, ragged row counts, a strided
-    map (n_in != n_out, many missing neighbours) and a ragged channel count; float32 accumulation order differs from
-    the oracle's, hence the tolerance."""
+    """every (offsets per wave, ci tiles per wave, co tiles) instantiation of the LDS-staged weight gradient (widths that
+    are multiples of 4) and the per-operand-load kernel behind it (the other widths), ragged row counts, a strided map
+    (n_in != n_out, many missing neighbours) and ragged channel counts; float32 accumulation order differs from the
+    oracle's, hence the tolerance."""
     rng = np.random.default_rng(60 + cin + cout)
     fine = surface(rng, n=1500, n_batch=2, extent=36)
     coarse, _ = oracle.stride_coords(fine, 2)
@@ -155,6 +158,18 @@ def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
             want[k] = x[nbr[k][m]].astype(np.float64).T @ g[m].astype(np.float64)
         dw = ops.spconv_bwd_weight(dev(x), dev(g), dev(nbr), 27)
         np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-4, atol=2e-3)
+        # pair-major form: the per-offset lists are exactly the pairs of the map in row order ...
+        wp = ops.wgrad_pairs(dev(nbr), 27)
+        ts, pairs, T = wp.tile_start.cpu().numpy(), wp.pairs.cpu().numpy(), (nbr.shape[1] + 255) // 256
+        assert ts[0] == 0 and ts[-1] == (nbr >= 0).sum() and len(ts) == 27 * T + 1
+        for k in range(27):
+            rows = np.nonzero(nbr[k] >= 0)[0]
+            np.testing.assert_array_equal(pairs[ts[k * T]:ts[(k + 1) * T]], np.stack([rows, nbr[k][rows]], 1))
+        np.testing.assert_allclose(ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp).cpu().numpy(), want, rtol=2e-4, atol=2e-3)
+        # ... and a slot-ordered map (rows permuted, row_order = slot -> output row) gives the same dW from the same dout
+        perm = rng.permutation(nbr.shape[1]).astype(np.int32)
+        wp = ops.wgrad_pairs(dev(np.ascontiguousarray(nbr[:, perm])), 27, row_order=dev(perm))
+        np.testing.assert_allclose(ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp).cpu().numpy(), want, rtol=2e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("cin,cout,n", [(96, 96, 900), (112, 112, 300), (64, 80, 4000), (16, 16, 40), (160, 64, 2500)])
@@ -221,6 +236,8 @@ def test_spconv_bf16_entries_match_oracle_on_rounded_operands(ops, oracle, cin, 
             want_dw[k] = xr[nbr[k][m]].T @ gr[m]
         dw = ops.spconv_bwd_weight(dev(x), dev(g), dev(nbr), 27, bf16=True).cpu().numpy()
         np.testing.assert_allclose(dw, want_dw, rtol=2e-4, atol=2e-3)
+        dw = ops.spconv_bwd_weight_pairs(dev(x), dev(g), ops.wgrad_pairs(dev(nbr), 27), bf16=True).cpu().numpy()
+        np.testing.assert_allclose(dw, want_dw, rtol=2e-4, atol=2e-3)
     if cin % 32 == 0:  # two sources (ME.cat fused)
         nbr = oracle.kernel_map(fine, fine, 3, 1, 1)
         x0 = rng.normal(size=(len(fine), cin // 2)).astype(np.float32)
@@ -270,7 +287,9 @@ def test_bn_train_fwd_bwd_matches_torch_float64(ops):
                 yt = torch.relu(yt)
             yt.backward(torch.tensor(dy, dtype=torch.float64))
             grm, grv = dev(rm0), dev(rv0)
-            y, mean, rstd = ops.bn_train_fwd(dev(x), dev(w), dev(b), 1e-5, 0.1, grm, grv, relu)
+            nbt = torch.tensor(41, dtype=torch.int64, device=grm.device)   # nn.BatchNorm's num_batches_tracked
+            y, mean, rstd = ops.bn_train_fwd(dev(x), dev(w), dev(b), 1e-5, 0.1, grm, grv, relu, nbt)
+            assert int(nbt) == 42
             np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), rtol=2e-5, atol=2e-5)
             np.testing.assert_allclose(grm.cpu().numpy(), rm.numpy(), rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(grv.cpu().numpy(), rv.numpy(), rtol=1e-6, atol=1e-6)

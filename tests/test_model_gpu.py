@@ -155,6 +155,7 @@ def test_training_step_runs_and_matches_torch_autograd(setup, monkeypatch, min_r
     y = up(ME.MinkowskiReLU()(bn(conv(st))))
     loss = (y.F ** 2).mean()
     loss.backward()
+    assert int(bn.bn.num_batches_tracked) == 1   # nn.BatchNorm's counter, incremented on the device by the stats launch
     # dense re-implementation with index_add on the same kernel maps
     cm = st.coordinate_manager
     down = cm.kernel_map_rows(1, 2, 3, 1).long()   # indexed by physical output rows (the conv kernels use slot order)
