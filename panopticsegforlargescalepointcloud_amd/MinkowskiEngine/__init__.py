@@ -693,7 +693,7 @@ class _ConvBase(nn.Module):
 
     def packed(self):
         k = self.kernel
-        tag = (k._version, k.data_ptr(), k.device)
+        tag = (k._version, ops.param_epoch(), k.data_ptr(), k.device)
         if self._packed is None or self._packed[0] != tag:
             self._packed = (tag, ops.pack_weight(k, kflip=self.mirrored))
         return self._packed[1]
@@ -769,7 +769,7 @@ class MinkowskiBatchNorm(nn.Module):
         bn = self.bn
         p, b = bn._parameters, bn._buffers  # direct dict access: nn.Module.__getattr__ costs ~1 us per attribute
         w, bias, mean, var = p["weight"], p["bias"], b["running_mean"], b["running_var"]
-        tag = (w._version, bias._version, mean._version, var._version, w.data_ptr())
+        tag = (w._version, bias._version, mean._version, var._version, ops.param_epoch(), w.data_ptr())
         if self._folded is None or self._folded[0] != tag:
             with torch.no_grad():
                 scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)

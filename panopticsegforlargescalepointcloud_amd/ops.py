@@ -513,11 +513,34 @@ def pack_weight(weight, transpose=False, kflip=False):
     return packed
 
 
+# Derived copies of parameters (packed weights, folded BatchNorm) are keyed by the parameters' `_version`.  Not every writer
+# bumps it: torch's fused optimizers (Adam(fused=True), ...) update the parameters in place WITHOUT touching the version
+# counter (measured on torch 2.10: foreach -> version + 1, fused -> unchanged), and a stale packed copy trains silently
+# on the old weights.  So every optimizer step also advances an epoch that is part of every such key.
+_PARAM_EPOCH = [0]
+
+
+def param_epoch():
+    return _PARAM_EPOCH[0]
+
+
+def parameters_changed():
+    """call after writing parameters through a path that does not bump tensor versions (`.data`, custom fused kernels)"""
+    _PARAM_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(lambda *a, **k: parameters_changed())
+except ImportError:  # very old torch: versions only
+    pass
+
+
 class _PackedWeights:
     """Packed copies of a model's convolution weights, refreshed in ONE launch per weight version (training: the optimizer
     step changes every weight, and packing each of the ~190 (layer, orientation) pairs of a step as its own 4 us launch
     costs 2 ms of host time per step).  An entry is (parameter, flags) -> packed tensor; the first request of an entry packs
-    it alone and registers it; when a registered entry is requested with a new `_version` of its parameter, ALL registered
+    it alone and registers it; when a registered entry is requested with a new version of its parameter (or after an optimizer step, see above), ALL registered
     entries are re-packed by pp_pack_weights_batched (parameters whose weights did not change are simply packed again)."""
 
     def __init__(self):
@@ -530,14 +553,14 @@ class _PackedWeights:
         key = (id(param), flags)
         ent = self.entries.get(key)
         if ent is not None and ent[0]() is param and ent[2].device == param.device:
-            if ent[3] != param._version:
+            if ent[3] != (param._version, _PARAM_EPOCH[0]):
                 self._repack_all(param.device)
             return ent[2]
         packed = pack_weight(param, transpose=transpose, kflip=kflip)
         w = param.detach()
         K, a, b = (1,) + tuple(w.shape) if w.dim() == 2 else tuple(w.shape)
         cin, cout = (b, a) if transpose else (a, b)
-        self.entries[key] = [weakref.ref(param), flags, packed, param._version, K, cin, cout]
+        self.entries[key] = [weakref.ref(param), flags, packed, (param._version, _PARAM_EPOCH[0]), K, cin, cout]
         self.table = None
         return packed
 
@@ -559,7 +582,7 @@ class _PackedWeights:
         desc, first, n, blocks = self.table
         _lib.check(lib.pp_pack_weights_batched(_ptr(desc), _ptr(first), n, blocks, _stream()), "pp_pack_weights_batched")
         for _, e in live:
-            e[3] = e[0]()._version
+            e[3] = (e[0]()._version, _PARAM_EPOCH[0])
 
 
 PACKED_WEIGHTS = _PackedWeights()

@@ -186,9 +186,15 @@ def test_training_step_runs_and_matches_torch_autograd(setup, monkeypatch, min_r
     np.testing.assert_allclose(up.kernel.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-3, atol=1e-5)
 
 
-def test_full_model_training_step(setup):
+_LOSSES_BY_OPT = {}
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_full_model_training_step(setup, fused):
     """optimize_parameters2 semantics (models/base_model.py:259-285): forward in train mode (batch-statistics BN through
-    the HIP stats kernels), _compute_loss, backward through every sparse conv, Adam step; loss finite and decreasing."""
+    the HIP stats kernels), _compute_loss, backward through every sparse conv, Adam step; loss finite and decreasing.
+    fused: torch's fused Adam writes the parameters without bumping their version counters -- the packed-weight cache must
+    follow the optimizer step all the same (the losses of the two optimizers agree step by step)."""
     import bench
     from panopticsegforlargescalepointcloud_amd.applications import Data
     s = setup
@@ -209,7 +215,7 @@ def test_full_model_training_step(setup):
                 instance_labels=torch.from_numpy(inst_local), instance_mask=torch.from_numpy(inst > 0),
                 vote_label=torch.from_numpy(vote), center_label=torch.from_numpy(scene.inst_center[inst]),
                 num_instances=torch.tensor([int(inst_local.max())]))
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=fused)
     losses = []
     for it in range(3):
         model.set_input(data, dev)
@@ -222,6 +228,9 @@ def test_full_model_training_step(setup):
     g = [p.grad for n, p in model.named_parameters() if n.startswith("Backbone") and p.grad is not None]
     assert len(g) > 150 and all(torch.isfinite(x).all() for x in g)
     assert losses[-1] < losses[0]
+    _LOSSES_BY_OPT[fused] = losses
+    if len(_LOSSES_BY_OPT) == 2:
+        np.testing.assert_allclose(_LOSSES_BY_OPT[True], _LOSSES_BY_OPT[False], rtol=2e-3)
     cur = model.get_current_losses()
     assert set(("loss", "semantic_loss", "offset_norm_loss", "ins_loss")) <= set(cur)
 
