@@ -61,12 +61,25 @@ def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_in
     return clusters, [type] * len(clusters)
 
 
+def loop_csr(x, label_batch, local_ind, picks):
+    """[(ops.ClusterCSR, loop index)] for the feature subsets of sizes `picks`; the subsets are drawn as the reference
+    draws them (torch.multinomial on the CPU generator, :32 / :83), one HDBSCAN launch sequence per subset over all
+    batch elements with more than 5 points"""
+    parts = []
+    for loop_i, k in enumerate(picks):
+        feature_choose = torch.multinomial(torch.ones(x.shape[-1]), int(k), replacement=False)
+        parts.append((cluster_csr(x[:, feature_choose.to(x.device)], label_batch, local_ind, 5), loop_i))
+    return parts
+
+
+def loop_picks(low, high, loop_num):
+    """subset sizes of cluster_loop: numpy's global generator, as in the reference (:28)"""
+    return np.random.randint(low=low, high=high + 1, size=loop_num)
+
+
 def _loop(x, label_batch, local_ind, picks):
     final_result, cluster_type = [], []
-    for loop_i, k in enumerate(picks):
-        # the reference draws the feature subset with torch.multinomial on the CPU generator (:32, :83)
-        feature_choose = torch.multinomial(torch.ones(x.shape[-1]), int(k), replacement=False)
-        csr = cluster_csr(x[:, feature_choose.to(x.device)], label_batch, local_ind, 5)
+    for csr, loop_i in loop_csr(x, label_batch, local_ind, picks):
         clusters = csr.to_list()
         final_result += clusters
         cluster_type += [loop_i] * len(clusters)
@@ -74,8 +87,7 @@ def _loop(x, label_batch, local_ind, picks):
 
 
 def cluster_loop(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, low, high, loop_num):
-    pick_num = np.random.randint(low=low, high=high + 1, size=loop_num)
-    return _loop(embed_logits_logits_u, label_batch, local_ind, pick_num)
+    return _loop(embed_logits_logits_u, label_batch, local_ind, loop_picks(low, high, loop_num))
 
 
 def cluster_loop_fixedD(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, low, high, loop_num):

@@ -4,6 +4,11 @@ Same functions and return conventions as the reference wrapper:
   meanshift_cluster(prediction, bandwidth) -> LongTensor labels                 (reference :9-18)
   cluster_single(embed_logits_u, unique_in_batch, label_batch, local_ind, type, bandwidth)
       -> (List[LongTensor] of point indices, List[int] cluster types)          (reference :72-123)
+  cluster_loop(embed_logits_u, unique_in_batch, label_batch, local_ind, low, high, loop_num, bandwidth=None)
+      -> the same pair over loop_num random 5-feature subsets                    (reference :20-70)
+      The reference's loop hands `meanshift_cluster` to Pool.map with the samples alone (:57) although the function
+      takes (prediction, bandwidth) (:9): it raises TypeError there, i.e. no reference run of it exists.  Here it takes
+      the bandwidth as a keyword and raises the same TypeError when it is not given.
 but all samples (cylinders) of the batch are clustered together on the GPU -- no multiprocessing.Pool, no
 device->host->worker round trip.  Indices are returned on the input's device.
 """
@@ -65,3 +70,25 @@ def cluster_single(embed_logits_logits_u, unique_in_batch, label_batch, local_in
     csr = cluster_single_csr(embed_logits_logits_u, label_batch, local_ind, bandwidth)
     clusters = csr.to_list()
     return clusters, [type] * len(clusters)
+
+
+def loop_csr(x, label_batch, local_ind, loop_num, bandwidth):
+    """[(ops.ClusterCSR, loop index)]: loop_num subsets of 5 features drawn with torch.multinomial on the CPU generator
+    (reference :33-36; `pick_num = 5`, low / high unused), batch elements with more than 5 points"""
+    parts = []
+    for loop_i in range(loop_num):
+        feature_choose = torch.multinomial(torch.ones(x.shape[-1]), 5, replacement=False)
+        parts.append((cluster_single_csr(x[:, feature_choose.to(x.device)], label_batch, local_ind, bandwidth,
+                                         min_points_exclusive=5), loop_i))
+    return parts
+
+
+def cluster_loop(embed_logits_logits_u, unique_in_batch, label_batch, local_ind, low, high, loop_num, bandwidth=None):
+    if bandwidth is None:
+        raise TypeError("meanshift_cluster() missing 1 required positional argument: 'bandwidth'")
+    final_result, cluster_type = [], []
+    for csr, loop_i in loop_csr(embed_logits_logits_u, label_batch, local_ind, loop_num, bandwidth):
+        clusters = csr.to_list()
+        final_result += clusters
+        cluster_type += [loop_i] * len(clusters)
+    return final_result, cluster_type

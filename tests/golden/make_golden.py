@@ -539,6 +539,92 @@ def make_proposals():
     np.savez_compressed(os.path.join(OUT, "proposal_cases.npz"), **cases)
 
 
+def make_embed_recipes():
+    """PointGroupEmbed._cluster .. _cluster16 (torch_points3d/models/panoptic/pointgroupembed.py:219-783) extracted with `ast`
+    and executed with recording stand-ins for the clustering primitives (the hdbscan package is absent; the stand-ins return
+    one tagged single-point proposal per (call, loop index) so that the order of the final list is visible).  Pins, per
+    cluster_type: which primitive runs on which feature matrix (xyz / embeddings / both) with which numeric arguments, in
+    which order, how the proposal lists are concatenated and which type codes they get.  The reference's
+    meanshift_cluster.cluster_loop raises TypeError when really executed (it calls meanshift_cluster without its bandwidth,
+    :57); the stand-in records the call instead -- the fixture marks those cluster types."""
+    import ast
+    import json
+    path = os.path.join(REF, "torch_points3d/models/panoptic/pointgroupembed.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "PointGroupEmbed"][0]
+    wanted = ["_cluster"] + ["_cluster%d" % i for i in range(2, 17)]
+    fns = [m for m in cls.body if isinstance(m, ast.FunctionDef) and m.name in wanted]
+    n = 40
+    rng = np.random.default_rng(5)
+    pos = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32))
+    emb = torch.from_numpy(rng.normal(size=(n, 5)).astype(np.float32))
+    pred = np.array([2, 3, 4, 6, 7, 8, 0, 1, 5, 2] * 4)
+    sem = np.full((n, 9), -5.0, np.float32)
+    sem[np.arange(n), pred] = 5.0
+    thing = ~np.isin(pred, [0, 1, 5])
+    trace = []
+
+    def feat_name(x):
+        x = x.detach().cpu()
+        for name, ref in (("xyz", pos[thing]), ("emb", emb[thing]), ("all", torch.cat((pos[thing], emb[thing]), 1)),
+                          ("raw_pos(all points)", pos)):
+            if x.shape == ref.shape and torch.equal(x, ref):
+                return name
+        raise AssertionError("unknown feature matrix %s" % (tuple(x.shape),))
+
+    def tagged(count):
+        base = 1000 * len(trace)
+        return [torch.tensor([base + i]) for i in range(count)]
+
+    class H:
+        @staticmethod
+        def cluster_single(x, unique_in_batch, label_batch, local_ind, type):
+            trace.append(["hdbscan.cluster_single", feat_name(x), int(type)])
+            return tagged(1), [type]
+
+        @staticmethod
+        def cluster_loop(x, unique_in_batch, label_batch, local_ind, low, high, loop_num):
+            trace.append(["hdbscan.cluster_loop", feat_name(x), int(low), int(high), int(loop_num)])
+            return tagged(loop_num), list(range(loop_num))
+
+        @staticmethod
+        def cluster_loop_fixedD(x, unique_in_batch, label_batch, local_ind, low, high, loop_num):
+            trace.append(["hdbscan.cluster_loop_fixedD", feat_name(x), int(low), int(high), int(loop_num)])
+            return tagged(loop_num), list(range(loop_num))
+
+    class M:
+        @staticmethod
+        def cluster_single(x, unique_in_batch, label_batch, local_ind, type, bandwidth):
+            trace.append(["meanshift.cluster_single", feat_name(x), int(type), "bandwidth=%g" % bandwidth])
+            return tagged(1), [type]
+
+        @staticmethod
+        def cluster_loop(x, unique_in_batch, label_batch, local_ind, low, high, loop_num):
+            trace.append(["meanshift.cluster_loop", feat_name(x), int(low), int(high), int(loop_num)])
+            return tagged(loop_num), list(range(loop_num))
+
+    def region_grow(p, labels, batch, ignore_labels=[], radius=0.02, nsample=16, min_cluster_size=32):
+        trace.append(["region_grow", feat_name(p), "ignore=%s" % sorted(int(v) for v in ignore_labels), "radius=%g" % radius,
+                      "nsample=%d" % nsample, "min_cluster_size=%d" % min_cluster_size])
+        return tagged(2)
+
+    ns = {"torch": torch, "np": np, "region_grow": region_grow, "hdbscan_cluster": H, "meanshift_cluster": M}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    me = types.SimpleNamespace(raw_pos=pos, input=types.SimpleNamespace(batch=torch.zeros(n, dtype=torch.long)), device="cpu",
+                               _stuff_classes=torch.tensor([0, 1, 5]),
+                               opt=types.SimpleNamespace(cluster_radius_search=0.3, bandwidth=0.6))
+    out = {}
+    for i, name in enumerate(wanted):
+        del trace[:]
+        cl, ct = ns[name](me, torch.from_numpy(sem), emb)
+        out[str(i + 1)] = {"calls": [list(c) for c in trace], "proposal_tags": [int(c[0]) for c in cl],
+                           "types": [int(v) for v in (ct.tolist() if torch.is_tensor(ct) else ct)],
+                           "raises_in_the_reference": any(c[0] == "meanshift.cluster_loop" for c in trace)}
+        print("embed recipe", i + 1, out[str(i + 1)])
+    with open(os.path.join(OUT, "embed_cluster_recipes.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     if "--grid-only" in sys.argv:
         make_grid_cylinders()
@@ -548,6 +634,9 @@ if __name__ == "__main__":
             os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1",
                                                                          OPENBLAS_NUM_THREADS="1"))
         make_proposals()
+        sys.exit(0)
+    if "--embed-recipes-only" in sys.argv:
+        make_embed_recipes()
         sys.exit(0)
     if "--mask-losses-only" in sys.argv:
         make_mask_losses()
@@ -575,3 +664,4 @@ if __name__ == "__main__":
 # tests/golden/ref_written_npm3d_like.ply (+ _values.npz): 50 vertices written by the reference's own
 # torch_points3d/models/panoptic/ply.py:write_ply (fields x, y, z, scalar_class, scalar_label as float32, the way
 # CloudCompare exports NPM3D) -- generated once with the snippet in the commit that added panopticsegforlargescalepointcloud_amd/io.py.
+    make_embed_recipes()

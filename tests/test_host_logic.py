@@ -378,3 +378,50 @@ def test_sparseconv3d_backend_surface():
     assert isinstance(snn.ReLU(inplace=True), ME.MinkowskiReLU)
     with pytest.raises(Exception):  # no CPU execution path: the tensor has to live on a HIP device
         snn.SparseTensor(torch.zeros(4, 3), torch.zeros(4, 3, dtype=torch.int32), torch.zeros(4, dtype=torch.int64))
+
+
+def test_pointgroupembed_recipes_match_the_trace_of_the_reference_functions():
+    """tests/golden/embed_cluster_recipes.json: PointGroupEmbed._cluster .. _cluster16 of the reference executed with
+    recording stand-ins for the clustering primitives (make_golden.make_embed_recipes).  The recipe table of
+    panoptic/variants.py must name the same primitive on the same feature matrix with the same arguments, and combine the
+    proposal sets in the same order with the same type codes."""
+    import json
+    import types as T
+    from panopticsegforlargescalepointcloud_amd.panoptic.variants import PointGroupEmbed
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "embed_cluster_recipes.json")))
+    assert sorted(int(k) for k in fx) == sorted(PointGroupEmbed.RECIPES) == list(range(1, 17))
+    for ct, rec in fx.items():
+        recipe = PointGroupEmbed.RECIPES[int(ct)]
+        # the reference's calls, in OUTPUT order (tags = 1000 * call number + index inside the call)
+        call_of = []
+        for tag in rec["proposal_tags"]:
+            if tag // 1000 not in call_of:
+                call_of.append(tag // 1000)
+        ref_calls = [rec["calls"][c - 1] for c in call_of]
+        assert len(ref_calls) == len(recipe) == len(rec["calls"])
+        parts = []
+        for step, call in zip(recipe, ref_calls):
+            kind = step[0]
+            if kind == "H":
+                assert call == ["hdbscan.cluster_single", step[1], step[2]]
+                parts.append([(T.SimpleNamespace(n=1, tag=(call, 0)), step[2])])
+            elif kind == "HL":
+                assert call == ["hdbscan.cluster_loop", step[1], step[2], step[3], step[4]]
+                parts.append([(T.SimpleNamespace(n=1, tag=(call, i)), i) for i in range(step[4])])
+            elif kind == "HF":
+                assert call[:2] == ["hdbscan.cluster_loop_fixedD", step[1]] and call[4] == step[2]
+                parts.append([(T.SimpleNamespace(n=1, tag=(call, i)), i) for i in range(step[2])])
+            elif kind == "M":
+                assert call[:3] == ["meanshift.cluster_single", step[1], step[2]] and call[3].startswith("bandwidth=")
+                parts.append([(T.SimpleNamespace(n=1, tag=(call, 0)), step[2])])
+            elif kind == "ML":
+                assert call[:2] == ["meanshift.cluster_loop", step[1]] and call[4] == step[2] and rec["raises_in_the_reference"]
+                parts.append([(T.SimpleNamespace(n=1, tag=(call, i)), i) for i in range(step[2])])
+            else:
+                assert call == ["region_grow", "raw_pos(all points)", "ignore=[0, 1, 5]", "radius=0.3", "nsample=16", "min_cluster_size=10"]
+                parts.append([(T.SimpleNamespace(n=2, tag=(call, 0)), step[1])])
+        proposals, typed = PointGroupEmbed._order(int(ct), parts)
+        # output order of the proposal sets = the reference's list order
+        got_order = [rec["calls"].index(p.tag[0]) + 1 for p in proposals for _ in range(p.n)]
+        assert got_order == [t // 1000 for t in rec["proposal_tags"]], ct
+        assert [t for c, t in typed for _ in range(c.n)] == rec["types"], ct

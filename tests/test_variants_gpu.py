@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cls_name, **over):
+def _setup(cls_name, n_points=60_000, **over):
     import bench
     from panopticsegforlargescalepointcloud_amd import panoptic, synthetic as syn
     from panopticsegforlargescalepointcloud_amd.applications import Data
@@ -21,7 +21,7 @@ def _setup(cls_name, **over):
         cfg[k] = v
     torch.manual_seed(3)
     model = getattr(panoptic, cls_name)(cfg, "dummy", DS, None).to(dev).eval()
-    scene, tiles, _ = bench.build_scene(60_000, 2, 0.05, 2022)
+    scene, tiles, _ = bench.build_scene(n_points, 2, 0.05, 2022)
     b = syn.tile_batch(scene, tiles, [0, 1])
     data = Data(pos=torch.from_numpy(b["pos"]), coords=torch.from_numpy(b["coords"]), x=torch.from_numpy(b["x"]),
                 batch=torch.from_numpy(b["batch"]))
@@ -100,6 +100,100 @@ def test_pointgroupembed_setting_i_and_hdbscan(oracle):
         assert res.cluster_scores is None            # no ScoreNet: get_instances hands back every proposal
         ids, clusters = res._replace(clusters=res.clusters_csr.to_list()).get_instances()
         assert ids is None and len(clusters) == len(want)
+
+
+@pytest.mark.parametrize("ct", [2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 15, 16])
+def test_pointgroupembed_other_cluster_types(oracle, ct):
+    """cluster_type 2-6, 8-13, 15, 16 of pointgroupembed.py (:258-681, :712-783), each restated here from the reference's
+    function as a union of oracle primitives; the random feature subsets replay numpy's and torch's global generators in
+    the order the reference consumes them.  (9, 10, 12, 15 go through meanshift_cluster.cluster_loop, which raises
+    TypeError in the reference -- checked against the restatement with opt.bandwidth.)"""
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.utils import hdbscan_cluster as hc
+    model, cfg, scene, b, data, dev = _setup("PointGroupEmbed", n_points=24_000, cluster_type=ct, use_score_net=False)
+    model.set_input(data, dev)
+    cls, _, emb_np = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(4))
+    with torch.no_grad():
+        feats, sem, off, emb, pred = model.backbone_and_heads()
+        np.random.seed(11)
+        torch.manual_seed(11)
+        res = model.group_and_score(-1, feats, sem, None, torch.from_numpy(emb_np).to(dev), torch.from_numpy(cls).to(dev))
+    stuff = np.concatenate([[-1], syn.NPM3D_STUFF])
+    thing = ~np.isin(cls, stuff)
+    local = np.nonzero(thing)[0]
+    bt = b["batch"][thing]
+    offs = [0] + np.cumsum(np.bincount(bt, minlength=2)).tolist()
+    xyz, em = b["pos"][thing], emb_np[thing]
+    both = np.concatenate([xyz, em], 1)
+
+    def lists(labels, ncl):
+        out = []
+        for s in range(len(offs) - 1):
+            seg = labels[offs[s]: offs[s + 1]]
+            out += [local[offs[s]: offs[s + 1]][seg == l] for l in range(ncl[s]) if np.any(seg == l)]
+        return out
+
+    def H(x, t):
+        got = lists(*oracle.hdbscan(x, offs, 15, 5, 0.006, hc.COUNT_SELF))
+        return got, [t] * len(got)
+
+    def M(x, t):
+        got = lists(*oracle.meanshift(x, offs, cfg.bandwidth)[:2])
+        return got, [t] * len(got)
+
+    def loop(x, sizes, one):
+        out, types = [], []
+        for i, k in enumerate(sizes):
+            cols = torch.multinomial(torch.ones(x.shape[1]), int(k), replacement=False).numpy()
+            got, _ = one(np.ascontiguousarray(x[:, cols]), i)
+            out += got
+            types += [i] * len(got)
+        return out, types
+
+    HL = lambda x, lo, hi, n: loop(x, np.random.randint(low=lo, high=hi + 1, size=n), H)   # noqa: E731
+    HF = lambda x, n: loop(x, [5] * n, H)                                                   # noqa: E731
+    ML = lambda x, n: loop(x, [5] * n, M)                                                   # noqa: E731
+
+    def R(t):
+        got, _ = oracle.region_grow(b["pos"], cls, b["batch"], stuff, 16, cfg.cluster_radius_search, 10)
+        return got, [t] * len(got)
+
+    np.random.seed(11)
+    torch.manual_seed(11)
+    if ct == 2:
+        parts = [HL(both, 3, 5, 9), H(em, 9)]
+    elif ct == 3:
+        parts = [HL(both, 3, 5, 9), H(xyz, 9)]
+    elif ct == 4:
+        parts = [HL(both, 3, 5, 8), H(em, 8), H(xyz, 9)]
+    elif ct == 5:
+        parts = [HL(both, 3, 5, 10)]
+    elif ct == 6:
+        parts = [HL(em, 2, 5, 6)]
+    elif ct == 8:
+        parts = [R(0), M(em, 1)]
+    elif ct == 9:
+        parts = [R(0), ML(em, 10)]
+    elif ct == 10:
+        parts = [ML(em, 6)]
+    elif ct == 11:
+        parts = [HF(em, 6)]
+    elif ct == 12:
+        parts = [R(6), ML(em, 6)]
+    elif ct == 13:
+        parts = [HF(em, 6), H(xyz, 6)]
+    elif ct == 15:
+        parts = [ML(em, 6), H(em, 6)]
+    else:
+        hl = HL(em, 2, 5, 6)          # drawn first (:770), listed second (:777-780)
+        parts = [M(em, 6), hl]
+    want = [c for p in parts for c in p[0]]
+    types = [t for p in parts for t in p[1]]
+    if ct == 12:                      # :638-641: the region-growing proposals come first, their types last
+        types = parts[1][1] + parts[0][1]
+    assert len(want) > 0
+    _same(res.clusters_csr.to_list(), want)
+    assert res.cluster_type.cpu().tolist() == types
 
 
 def test_cluster_functions_match_the_reference_model():
