@@ -268,8 +268,8 @@ int pp_spconv_bwd_weight_bf16(const float* in, int32_t cin, int64_t n_in, const 
  * launch per layer over the lists -- every 16-pair MFMA step is full, and a slot-ordered map needs no re-ordered dout.
  * pp_wgrad_pairs_build: pairs [<= K*n_out][2] int32 = (output row, input row), offset-major and in row order inside an
  *   offset; row_order (nullable, int32 [n_out]): row r of the map is output row row_order[r] (slot-ordered maps);
- *   tile_start int32 [K*ceil(n_out/256) + 1]: exclusive scan of the pairs per 256-row tile (last entry = total); the
- *   list of offset k is pairs[tile_start[k*T] .. tile_start[(k+1)*T]), T = ceil(n_out/256).  K*n_out < 2^31.
+ *   tile_start int32 [K*ceil(n_out/1024) + 1]: exclusive scan of the pairs per 1024-row tile (last entry = total); the
+ *   list of offset k is pairs[tile_start[k*T] .. tile_start[(k+1)*T]), T = ceil(n_out/1024).  K*n_out < 2^31.
  * pp_spconv_bwd_weight_pairs: dw [K,cin,cout] float32 (zeroed by the callee) from those lists; map_rows = the n_out the
  *   lists were built with, n_out = rows of dout; bf16 != 0: operands rounded to bfloat16 in registers.  in, dout < 4 GiB. */
 size_t pp_wgrad_pairs_workspace(int32_t K, int64_t n_out);

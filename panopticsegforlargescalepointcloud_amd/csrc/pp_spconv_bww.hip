@@ -197,15 +197,20 @@ int pp_spconv_bww2_launch(const float* in, int cin, int64_t n_in, const float* d
 //                          operands are gathered (dout rows by the stored output row: a slot-ordered map needs no
 //                          re-ordered copy of dout any more, the row order is folded into the list).
 // -------------------------------------------------------------------------------------------------------------------
-#define WP_TILE 256   // rows of one offset per counted tile = one block step; the lists are addressed per tile (tile_start)
+#define WP_TILE 1024   // rows of one offset per counted tile: 256 threads x 4 consecutive rows
 
 __global__ __launch_bounds__(256) void k_wpairs_count(const int32_t* __restrict__ nbr, int64_t n_out, int tiles_per_k,
                                                       int32_t* __restrict__ tile_count) {
   __shared__ int wc[4];
   const int k = blockIdx.x / tiles_per_k, t = blockIdx.x - k * tiles_per_k;
-  const int64_t r = (int64_t)t * WP_TILE + threadIdx.x;
-  const unsigned long long b = __ballot(r < n_out && nbr[(int64_t)k * n_out + r] >= 0);
-  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(b);
+  const int32_t* row = nbr + (int64_t)k * n_out;
+  const int64_t r0 = (int64_t)t * WP_TILE + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c += (r0 + e < n_out && row[r0 + e] >= 0) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) tile_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
@@ -215,15 +220,24 @@ __global__ __launch_bounds__(256) void k_wpairs_write(const int32_t* __restrict_
                                                       const int32_t* __restrict__ tile_start, int2* __restrict__ pairs) {
   __shared__ int wc[4];
   const int k = blockIdx.x / tiles_per_k, t = blockIdx.x - k * tiles_per_k;
+  const int32_t* row = nbr + (int64_t)k * n_out;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t r = (int64_t)t * WP_TILE + threadIdx.x;
-  const int src = r < n_out ? nbr[(int64_t)k * n_out + r] : -1;
-  const unsigned long long b = __ballot(src >= 0);
-  if (lane == 0) wc[wave] = __popcll(b);
+  const int64_t r0 = (int64_t)t * WP_TILE + threadIdx.x * 4;
+  int src[4], before = 0, total = 0;   // pairs of this wave in earlier lanes / in the whole wave (row order = lane, then e)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    src[e] = r0 + e < n_out ? row[r0 + e] : -1;
+    const unsigned long long b = __ballot(src[e] >= 0);
+    before += __popcll(b & ((1ull << lane) - 1ull));
+    total += __popcll(b);
+  }
+  if (lane == 0) wc[wave] = total;
   __syncthreads();
-  int off = tile_start[blockIdx.x];
+  int off = tile_start[blockIdx.x] + before;
   for (int w = 0; w < wave; ++w) off += wc[w];
-  if (src >= 0) pairs[off + __popcll(b & ((1ull << lane) - 1ull))] = make_int2(order ? order[r] : (int)r, src);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (src[e] >= 0) pairs[off++] = make_int2(order ? order[r0 + e] : (int)(r0 + e), src[e]);
 }
 
 extern "C" size_t pp_wgrad_pairs_workspace(int32_t K, int64_t n_out) {

@@ -716,7 +716,7 @@ def wgrad_pairs(nbr, K, row_order=None):
     nbr = _need(nbr, torch.int32, "nbr")
     rows = nbr.shape[1]
     dev = nbr.device
-    tiles = K * ((rows + 255) // 256)
+    tiles = K * ((rows + 1023) // 1024)
     pairs = torch.empty((max(K * rows, 1), 2), dtype=torch.int32, device=dev)
     tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
     nbytes = lib.pp_wgrad_pairs_workspace(K, rows)

@@ -76,9 +76,9 @@ def test_ply_to_device_path_to_eval_ply_matches_the_oracle_chain(tmp_path, oracl
     from oracle import pipeline as opipe
     from panopticsegforlargescalepointcloud_amd import io as pio, ops, scene as sc, synthetic as syn
     dev = torch.device("cuda")
-    voxel, radius, extent = 0.05, 7.5, 24.0
+    voxel, radius, extent = 0.05, 4.5, 15.0   # sized so that the oracle's chain (CPU) takes ~40 s
     # ---- the input file: reference field names, float scalar fields as CloudCompare writes them
-    raw, cls, inst = syn.urban_points(180_000, extent, np.random.default_rng(8))
+    raw, cls, inst = syn.urban_points(70_000, extent, np.random.default_rng(8))
     src = pio.write_ply(str(tmp_path / "scene"), [raw, (cls + 1).astype(np.float32), (inst - 1).astype(np.float32)],
                         ["x", "y", "z", "scalar_class", "scalar_label"])
     xyz, sem_gt, ins_gt = pio.read_npm3d(src)
@@ -86,7 +86,7 @@ def test_ply_to_device_path_to_eval_ply_matches_the_oracle_chain(tmp_path, oracl
     n_full = len(raw)
     model, cfg, DS = bench.build_model(dev, voxel)
     opt = {"cluster_radius_search": cfg.cluster_radius_search, "cluster_type": cfg.cluster_type, "bandwidth": cfg.bandwidth}
-    cen = np.array([[6.0, 6.0], [18.0, 6.5], [12.0, 13.0], [6.5, 18.0], [18.0, 18.0]], np.float32)
+    cen = np.array([[4.5, 4.5], [10.5, 5.0], [7.5, 10.5]], np.float32)
     # ---- device chain: voxelise -> cylinders -> batch -> model -> assembly -> back-projection
     xyz_d = xyz.to(dev)
     coords, rep, _ = ops.voxelize(xyz_d, voxel)

@@ -160,7 +160,7 @@ def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
         np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=2e-4, atol=2e-3)
         # pair-major form: the per-offset lists are exactly the pairs of the map in row order ...
         wp = ops.wgrad_pairs(dev(nbr), 27)
-        ts, pairs, T = wp.tile_start.cpu().numpy(), wp.pairs.cpu().numpy(), (nbr.shape[1] + 255) // 256
+        ts, pairs, T = wp.tile_start.cpu().numpy(), wp.pairs.cpu().numpy(), (nbr.shape[1] + 1023) // 1024
         assert ts[0] == 0 and ts[-1] == (nbr >= 0).sum() and len(ts) == 27 * T + 1
         for k in range(27):
             rows = np.nonzero(nbr[k] >= 0)[0]
