@@ -511,10 +511,6 @@ def cat(*tensors):
 WGRAD_PAIRS = os.environ.get("PP_WGRAD_PAIRS", "1") != "0"
 
 
-def cout_ok(cout):
-    return cout <= 192
-
-
 def _pack(kernel, transpose=False, kflip=False):
     """packed weights of a layer: model parameters go through the per-version cache (one launch re-packs all of them after
     an optimizer step), anything else is packed on the spot"""
@@ -559,7 +555,7 @@ class _SparseConvFn(torch.autograd.Function):
                 ops.PROFILE_TAG = "fwd"
         if ctx.needs_input_grad[1]:
             order = getattr(ctx.nbr, "pp_order", None)
-            if WGRAD_PAIRS and ctx.nbr is not None and cout_ok(dout.shape[1]):
+            if WGRAD_PAIRS and ctx.nbr is not None and dout.shape[1] <= 192:  # (the kernels' widest output tile set)
                 # the pairs of the map compacted per offset, once per map (every layer on this map re-uses the lists);
                 # a slot order is folded into the lists, dout is read in its own row order
                 wp = getattr(ctx.nbr, "pp_wpairs", None)
