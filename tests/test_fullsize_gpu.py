@@ -289,6 +289,46 @@ def test_strided_and_transposed_convolutions_vs_fp64_on_sampled_rows(ops, level,
     assert _report("transposed %d->%d%s" % (c, c, " bf16" if bf16 else ""), got[order[slots].long()], want) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,bf16", [(16, 16, False), (32, 48, False), (64, 64, False), (32, 32, True)])
+def test_weight_gradient_at_full_size(ops, level, cin, cout, bf16):
+    """dW over the ~6 M-row level (the 32-bit list positions, the chunk grid and the block reduction at the size of a real
+    launch): the pair lists hold exactly the map's pairs per offset, in row order; dW from the lists equals dW from the dense
+    map (two independent kernels, different summation orders: 1e-4 of the largest entry) and, for three offsets, an fp64
+    evaluation of the definition (torch index arithmetic); a slot-ordered copy of the map gives the same dW from the same
+    output gradient."""
+    nbr, n = level["nbr"], level["n"]
+    g = torch.Generator(device="cuda").manual_seed(cin * 100 + cout)
+    x = torch.randn(n, cin, device="cuda", generator=g)
+    dy = torch.randn(n, cout, device="cuda", generator=g)
+    wp = ops.wgrad_pairs(nbr, 27)
+    T = (n + 1023) // 1024
+    ts = wp.tile_start.long()
+    per_k = ts[torch.arange(1, 28, device="cuda") * T] - ts[torch.arange(0, 27, device="cuda") * T]
+    assert torch.equal(per_k, (nbr >= 0).sum(1)) and int(ts[-1]) == int(nbr.pp_pairs)
+    for k in (0, 13, 26):
+        lo, hi = int(ts[k * T]), int(ts[(k + 1) * T])
+        rows = torch.nonzero(nbr[k] >= 0).view(-1)
+        assert torch.equal(wp.pairs[lo:hi, 0].long(), rows) and torch.equal(wp.pairs[lo:hi, 1], nbr[k][rows])
+    dw = ops.spconv_bwd_weight_pairs(x, dy, wp, bf16=bf16)
+    dense = ops.spconv_bwd_weight(x, dy, nbr, 27, bf16=bf16)
+    scale = float(dense.abs().max())
+    err = float((dw - dense).abs().max()) / scale
+    print("dW %d->%d%s at %d rows: pair lists vs dense map %.2e of the largest entry" % (cin, cout, " bf16" if bf16 else "", n, err))
+    assert err < 1e-4
+    xr, dr = (x.bfloat16().double(), dy.bfloat16().double()) if bf16 else (x.double(), dy.double())
+    for k in (1, 13, 22):
+        rows = torch.nonzero(nbr[k] >= 0).view(-1)
+        want = xr[nbr[k][rows].long()].t() @ dr[rows]
+        e = float((dw[k].double() - want).abs().max()) / float(want.abs().max())
+        print("   offset %d vs fp64: %.2e" % (k, e))
+        assert e < 1e-4
+    order = ops.map_order(nbr.pp_mask)[:n]
+    slot = ops.map_permute(nbr, order)
+    wps = ops.wgrad_pairs(slot, 27, row_order=order)
+    dws = ops.spconv_bwd_weight_pairs(x, dy, wps, bf16=bf16)
+    assert float((dws - dense).abs().max()) / scale < 1e-4
+
+
 def test_region_growing_tile_inside_full_batch_equals_oracle(ops, oracle):
     """one tile of the 2 M-point batch through the literal sequential oracle: the batched launch must give that tile the
     same clusters (bit-exact) as the CPU restatement run on the tile alone"""
