@@ -727,6 +727,25 @@ def test_sort_pairs(ops, n, dtype, end_bit):
     assert torch.equal(vo.long(), order) and torch.equal(ko, keys[order])
 
 
+@pytest.mark.parametrize("n", [1, 2047, 2049, 300_001])
+def test_sort_pairs_with_constant_digits(ops, n):
+    """keys whose bytes 1, 3 and 5..7 are the same in every key (Morton keys of a small scene look like this): passes that are
+    the identity permutation between passes that are not; the result is the same stable sort"""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    lo = torch.randint(0, 256, (n,), dtype=torch.int64, device="cuda", generator=g)
+    mid = torch.randint(0, 256, (n,), dtype=torch.int64, device="cuda", generator=g)
+    hi = torch.randint(0, 3, (n,), dtype=torch.int64, device="cuda", generator=g)
+    keys = lo | (0x5A << 8) | (mid << 16) | (0x11 << 24) | (hi << 32) | (0x0102_03 << 40)
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    ko, vo = ops.sort_pairs(keys, vals, 64)
+    order = torch.sort(keys, stable=True)[1]
+    assert torch.equal(vo.long(), order) and torch.equal(ko, keys[order])
+    k32 = (lo | (0x33 << 8) | (mid << 16)).to(torch.int32)
+    ko, vo = ops.sort_pairs(k32, vals, 32)
+    order = torch.sort(k32.long(), stable=True)[1]
+    assert torch.equal(vo.long(), order) and torch.equal(ko, k32[order])
+
+
 def _mask_sort_rank(mask, window):
     """numpy restatement of the sort key of csrc/pp_maporder.hip: per window of `window` consecutive rows the offset most rows
     have is the least significant bit, the rarest the most significant (ties: lower offset index lower).  `mask` in the
