@@ -538,38 +538,43 @@ class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         feats, kernel = ctx.saved_tensors
-        dout = dout.contiguous()
-        din = dw = None
-        if ctx.needs_input_grad[0]:
-            if ctx.same_level:
-                packed_t = _pack(kernel, transpose=True, kflip=not ctx.kflip)
-                inv = ctx.nbr
-            else:
-                packed_t = _pack(kernel, transpose=True)
-                inv = ctx.inv_fn()
-            ops.PROFILE_TAG = "dgrad"
-            try:
-                din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
-                                     row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)
-            finally:
-                ops.PROFILE_TAG = "fwd"
-        if ctx.needs_input_grad[1]:
-            order = getattr(ctx.nbr, "pp_order", None)
-            if WGRAD_PAIRS and ctx.nbr is not None and dout.shape[1] <= 192:  # (the kernels' widest output tile set)
-                # the pairs of the map compacted per offset, once per map (every layer on this map re-uses the lists);
-                # a slot order is folded into the lists, dout is read in its own row order
-                wp = getattr(ctx.nbr, "pp_wpairs", None)
-                if wp is None:
-                    wp = ctx.nbr.pp_wpairs = ops.wgrad_pairs(ctx.nbr, ctx.K, row_order=order)
-                dw = ops.spconv_bwd_weight_pairs(feats, dout, wp, bf16=ctx.bf16)
-            else:
-                # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
-                dout_s = dout if order is None else ops.gather_rows(dout, order.long())
-                dw = ops.spconv_bwd_weight(feats, dout_s, ctx.nbr, ctx.K, bf16=ctx.bf16)
-            if ctx.kflip:
-                dw = dw.flip(0)
-            dw = dw.reshape(kernel.shape)
+        din, dw = _conv_backward(ctx, feats, kernel, dout.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return din, dw, None, None, None, None, None, None
+
+
+def _conv_backward(ctx, feats, kernel, dout, need_in, need_w):
+    """input and weight gradient of a sparse convolution from the context _SparseConvFn / _ConvBnActTrainFn keep"""
+    din = dw = None
+    if need_in:
+        if ctx.same_level:
+            packed_t = _pack(kernel, transpose=True, kflip=not ctx.kflip)
+            inv = ctx.nbr
+        else:
+            packed_t = _pack(kernel, transpose=True)
+            inv = ctx.inv_fn()
+        ops.PROFILE_TAG = "dgrad"
+        try:
+            din = ops.spconv_fwd(dout, packed_t, inv, feats.shape[0], feats.shape[1], ctx.K,
+                                 row_order=getattr(inv, "pp_order", None), bf16=ctx.bf16)
+        finally:
+            ops.PROFILE_TAG = "fwd"
+    if need_w:
+        order = getattr(ctx.nbr, "pp_order", None)
+        if WGRAD_PAIRS and ctx.nbr is not None and dout.shape[1] <= 192:  # (the kernels' widest output tile set)
+            # the pairs of the map compacted per offset, once per map (every layer on this map re-uses the lists);
+            # a slot order is folded into the lists, dout is read in its own row order
+            wp = getattr(ctx.nbr, "pp_wpairs", None)
+            if wp is None:
+                wp = ctx.nbr.pp_wpairs = ops.wgrad_pairs(ctx.nbr, ctx.K, row_order=order)
+            dw = ops.spconv_bwd_weight_pairs(feats, dout, wp, bf16=ctx.bf16)
+        else:
+            # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
+            dout_s = dout if order is None else ops.gather_rows(dout, order.long())
+            dw = ops.spconv_bwd_weight(feats, dout_s, ctx.nbr, ctx.K, bf16=ctx.bf16)
+        if ctx.kflip:
+            dw = dw.flip(0)
+        dw = dw.reshape(kernel.shape)
+    return din, dw
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
@@ -589,6 +594,55 @@ class _BatchNormTrainFn(torch.autograd.Function):
         x, weight, mean, rstd, y = ctx.saved_tensors
         dx, dweight, dbias = ops.bn_train_bwd(x, dy.contiguous(), y, weight, mean, rstd)
         return dx, dweight, dbias, None, None, None, None
+
+
+class _ConvBnActTrainFn(torch.autograd.Function):
+    """training-mode  act(BN(conv(x)))  as ONE autograd node: _SparseConvFn followed by _BatchNormTrainFn, same launches in
+    the same order (results are bit-identical to the two-node form), one Python round trip per layer and direction
+    instead of two -- the training step is paced by the host."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel, bn_w, bn_b, nbr, inv_fn, n_out, K, same_level, kflip, eps, relu, momentum, running):
+        feats = feats.contiguous()
+        bf16 = _CONV_BF16[0]
+        h = ops.spconv_fwd(feats, _pack(kernel, kflip=kflip), nbr, n_out, kernel.shape[-1], K,
+                           row_order=getattr(nbr, "pp_order", None), bf16=bf16)
+        rm, rv, nbt = running if running is not None else (None, None, None)
+        y, mean, rstd = ops.bn_train_fwd(h, bn_w, bn_b, eps, momentum, rm, rv, relu, nbt)
+        ctx.save_for_backward(feats, kernel, h, bn_w, mean, rstd, y if relu else None)
+        ctx.nbr, ctx.inv_fn, ctx.K, ctx.bf16 = nbr, inv_fn, K, bf16
+        ctx.same_level, ctx.kflip = same_level, kflip
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, kernel, h, bn_w, mean, rstd, y = ctx.saved_tensors
+        dh, dbw, dbb = ops.bn_train_bwd(h, dy.contiguous(), y, bn_w, mean, rstd)
+        din, dw = _conv_backward(ctx, feats, kernel, dh, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (din, dw, dbw if bn_w is not None else None, dbb if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None, None, None, None, None, None)
+
+
+FUSE_TRAIN = os.environ.get("PP_FUSE_TRAIN", "1") != "0"
+
+
+def conv_bn_act_train(x, conv, bn, relu=True):
+    """Training-mode relu?(BN(conv(x))) through _ConvBnActTrainFn; None when the pair is not the plain case (convolution
+    bias, BatchNorm in eval mode or without running statistics bookkeeping to mirror): the caller then runs the modules."""
+    b = bn.bn
+    if not FUSE_TRAIN or conv.bias is not None or not b.training or not torch.is_grad_enabled():
+        return None
+    ts_out, nbr, inv_fn = conv.out_stride_and_map(x)
+    cm = x.coordinate_manager
+    running, mom = None, 0.0
+    if b.track_running_stats:
+        mom = b.momentum if b.momentum is not None else 1.0 / float(b.num_batches_tracked + 1)
+        running = (b.running_mean, b.running_var, b.num_batches_tracked)
+        bn._folded = None
+    same_level = conv.stride == 1 and conv.kernel_volume > 1
+    feats = _ConvBnActTrainFn.apply(x.feats, conv.kernel, b.weight, b.bias, nbr, inv_fn, cm.level(ts_out).n, conv.kernel_volume,
+                                    same_level, conv.mirrored, b.eps, relu, mom, running)
+    return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)
 
 
 class _AffineFn(torch.autograd.Function):

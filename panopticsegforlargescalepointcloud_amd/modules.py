@@ -5,7 +5,8 @@ App. A) and forward semantics as
   torch_points3d/modules/MinkowskiEngine/api_modules.py:9-82 (ResBlock), :235-285 (ResNetDown), :288-311 (ResNetUp)
   torch_points3d/core/common_modules/base_modules.py:35-45 (MLP), :128-153 (FastBatchNorm1d), :156-164 (Seq).
 In eval mode every conv -> BN -> ReLU (+ residual, + skip concat) chain is ONE fused kernel launch
-(ME.conv_bn_act); in training mode the modules run unfused through autograd Functions.
+(ME.conv_bn_act); in training mode conv + BN (+ ReLU) run as one autograd node per pair (ME.conv_bn_act_train; same launches
+and results as module by module, which remains the fallback).
 """
 import os
 import sys
@@ -157,6 +158,18 @@ class ResBlock(ME.MinkowskiNetwork):
             # ... unless the library does not serve the shape that way (small split-K launches, 4-GiB inputs)
             res = ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False) if self.downsample else x
             return ME.conv_bn_act(h, b[3], b[4], relu=True, residual=res)
+        b = self.block
+        if self.training:
+            # training: one autograd node per conv + BN (+ ReLU) instead of one per module (same launches, same results)
+            h = ME.conv_bn_act_train(x, b[0], b[1], relu=True)
+            out = ME.conv_bn_act_train(h, b[3], b[4], relu=True) if h is not None else None
+            if out is not None:
+                res = x
+                if self.downsample:
+                    res = ME.conv_bn_act_train(x, self.downsample[0], self.downsample[1], relu=False)
+                    if res is None:
+                        res = self.downsample(x)
+                return out + res
         out = self.block(x)
         if self.downsample:
             out = out + self.downsample(x)
@@ -195,6 +208,10 @@ class ResNetDown(ME.MinkowskiNetwork):
             return ME.conv_bn_act(x, self.conv_in[0], self.conv_in[1], relu=True, skip=skip)
         if skip is not None:
             x = ME.cat(x, skip)
+        if self.training:
+            out = ME.conv_bn_act_train(x, self.conv_in[0], self.conv_in[1], relu=True)
+            if out is not None:
+                return out
         return self.conv_in(x)
 
     def forward(self, x):

@@ -186,6 +186,40 @@ def test_training_step_runs_and_matches_torch_autograd(setup, monkeypatch, min_r
     np.testing.assert_allclose(up.kernel.grad.cpu().numpy(), w2.grad.cpu().numpy(), rtol=1e-3, atol=1e-5)
 
 
+def test_fused_training_node_is_bit_identical_to_module_by_module(monkeypatch):
+    """ME.conv_bn_act_train (one autograd node per conv + BN + ReLU) against the module-by-module path: same launches in the
+    same order, so outputs, running statistics and every gradient except the atomically accumulated kernel gradients agree bit
+    for bit (those to float rounding); a residual block with a 1x1 shortcut, a strided and a transposed input convolution."""
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, modules as M
+    rng = np.random.default_rng(9)
+    coords = torch.from_numpy(bf.surface_coords(rng, n_batch=2, n=2500, extent=36)).cuda()
+    x0 = torch.randn(len(coords), 16, device="cuda")
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ME, "FUSE_TRAIN", fused)
+        torch.manual_seed(4)
+        down = M.ResNetDown(down_conv_nn=[16, 32], kernel_size=3, stride=2, N=1).cuda().train()
+        up = M.ResNetUp(up_conv_nn=[32 + 32, 16], kernel_size=3, stride=2, N=1).cuda().train()
+        x = x0.clone().requires_grad_(True)
+        st = ME.SparseTensor(features=x, coordinates=coords, device="cuda")
+        h = down(st)
+        y = up(h, h)          # (skip and input on the same level, as in the U-Net)
+        (y.F ** 2).mean().backward()
+        outs[fused] = (y.F.detach(), x.grad, [(n, p.grad) for n, p in list(down.named_parameters()) + list(up.named_parameters())],
+                       [(n, b.clone()) for n, b in list(down.named_buffers()) + list(up.named_buffers())])
+    ya, xa, pa, ba = outs[True]
+    yb, xb, pb, bb = outs[False]
+    assert torch.equal(ya, yb) and torch.equal(xa, xb)
+    for (n, a), (_, b) in zip(ba, bb):
+        assert torch.equal(a, b), n
+    assert any(n.endswith("num_batches_tracked") and int(v) == 1 for n, v in ba)
+    for (n, a), (_, b) in zip(pa, pb):
+        if n.endswith("kernel"):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+        else:
+            assert torch.equal(a, b), n
+
+
 _LOSSES_BY_OPT = {}
 
 
