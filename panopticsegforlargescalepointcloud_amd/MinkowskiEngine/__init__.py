@@ -626,6 +626,12 @@ class _ConvBnActTrainFn(torch.autograd.Function):
 FUSE_TRAIN = os.environ.get("PP_FUSE_TRAIN", "1") != "0"
 
 
+def _one_row_check(n, c):
+    """batch statistics of a single row: torch's BatchNorm1d (what ME.MinkowskiBatchNorm wraps) refuses them in training"""
+    if n == 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, %d])" % c)
+
+
 def conv_bn_act_train(x, conv, bn, relu=True):
     """Training-mode relu?(BN(conv(x))) through _ConvBnActTrainFn; None when the pair is not the plain case (convolution
     bias, BatchNorm in eval mode or without running statistics bookkeeping to mirror): the caller then runs the modules."""
@@ -640,6 +646,7 @@ def conv_bn_act_train(x, conv, bn, relu=True):
         running = (b.running_mean, b.running_var, b.num_batches_tracked)
         bn._folded = None
     same_level = conv.stride == 1 and conv.kernel_volume > 1
+    _one_row_check(cm.level(ts_out).n, b.num_features)
     feats = _ConvBnActTrainFn.apply(x.feats, conv.kernel, b.weight, b.bias, nbr, inv_fn, cm.level(ts_out).n, conv.kernel_volume,
                                     same_level, conv.mirrored, b.eps, relu, mom, running)
     return SparseTensor(feats, coordinate_manager=cm, tensor_stride=ts_out)
@@ -852,6 +859,8 @@ class MinkowskiBatchNorm(nn.Module):
                 # updated in place by the finalize kernel (the counter too: one launch less per layer)
                 running = (bn.running_mean, bn.running_var, bn.num_batches_tracked)
                 self._folded = None  # ... which does not bump the tensors' version counters
+            if self.training:
+                _one_row_check(feats.shape[0], bn.num_features)
             return _BatchNormTrainFn.apply(feats, bn.weight, bn.bias, bn.eps, relu, mom, running)
         scale, shift = self.folded()
         return _AffineFn.apply(feats, scale, shift, 1 if relu else 0)

@@ -247,7 +247,7 @@ extern "C" size_t pp_wgrad_pairs_workspace(int32_t K, int64_t n_out) {
 
 extern "C" int pp_wgrad_pairs_build(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* row_order,
                                     int32_t* pairs, int32_t* tile_start, void* ws, size_t ws_bytes, pp_stream_t stream) {
-  PP_REQUIRE(nbr && pairs && tile_start && ws, "pp_wgrad_pairs_build: null pointer");
+  PP_REQUIRE(tile_start && (n_out == 0 || (nbr && pairs && ws)), "pp_wgrad_pairs_build: null pointer");
   PP_REQUIRE(K >= 1 && n_out >= 0 && (int64_t)K * n_out < (int64_t(1) << 31), "pp_wgrad_pairs_build: K * n_out must be < 2^31");
   PP_REQUIRE(ws_bytes >= pp_wgrad_pairs_workspace(K, n_out), "pp_wgrad_pairs_build: workspace too small");
   hipStream_t s = pp_s(stream);
@@ -410,13 +410,14 @@ static void bww4_go(dim3 grid, hipStream_t s, const float* in, int cin, u32 in_b
 extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
                                           int64_t n_out, const int32_t* pairs, const int32_t* tile_start, int32_t K,
                                           int64_t map_rows, float* dw, int32_t bf16, pp_stream_t stream) {
-  PP_REQUIRE(in && dout && dw && pairs && tile_start, "pp_spconv_bwd_weight_pairs: null pointer");
+  PP_REQUIRE(dw && tile_start, "pp_spconv_bwd_weight_pairs: null pointer");
   PP_REQUIRE(cin >= 1 && cout >= 1 && cout <= 192, "pp_spconv_bwd_weight_pairs: cout must be in [1,192]");
   PP_REQUIRE((double)n_in * cin * 4.0 < 4294967040.0 && (double)n_out * cout * 4.0 < 4294967040.0,
              "pp_spconv_bwd_weight_pairs: in and dout must be < 4 GiB each (32-bit buffer offsets)");
   hipStream_t s = pp_s(stream);
   PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
   if (map_rows == 0 || n_in == 0 || n_out == 0) return PP_OK;
+  PP_REQUIRE(in && dout && pairs, "pp_spconv_bwd_weight_pairs: null pointer");
   const int tiles_per_k = (int)((map_rows + WP_TILE - 1) / WP_TILE);
   const int nto = (cout + 15) / 16, ntiles = (cin + 15) / 16;
   int mt = nto <= 2 ? 4 : (nto <= 6 ? 2 : 1);

@@ -58,3 +58,51 @@ def test_coordinates_at_the_ends_of_the_key_range():
         ME.SparseTensor(torch.randn(1, 4), coordinates=torch.tensor([[0, 40000, 0, 0]], dtype=torch.int32), device=dev)
     with pytest.raises(ValueError):
         ME.SparseTensor(torch.randn(2, 4), coordinates=torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32), device=dev)
+
+
+def test_weight_gradient_pair_lists_degenerate_maps():
+    """pair lists of maps with no rows, no pairs at all, one pair, 8 offsets (2x2x2 kernels) and a single row: the lists hold
+    exactly the map's pairs and dW equals the definition; a training step on a 2-voxel input runs through the fused conv + BN
+    node and the pair-major weight gradient (two batch elements of one voxel); a 1-voxel input raises torch's "more than 1 value per channel" ValueError, as
+    BatchNorm1d under ME.MinkowskiBatchNorm does in the reference."""
+    from panopticsegforlargescalepointcloud_amd import ops
+    from panopticsegforlargescalepointcloud_amd.applications import Data
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for K, rows, fill in [(27, 0, None), (27, 5, "none"), (27, 1300, "one"), (8, 777, "rand"), (27, 1, "self"), (1, 40, "self")]:
+        nbr = torch.full((K, rows), -1, dtype=torch.int32, device=dev)
+        n_in = max(rows, 1) + 3
+        if fill == "one":
+            nbr[K // 2, rows - 1] = 2
+        elif fill == "rand":
+            nbr = torch.where(torch.rand((K, rows), device=dev, generator=g) < 0.3,
+                              torch.randint(0, n_in, (K, rows), device=dev, generator=g, dtype=torch.int32), nbr)
+        elif fill == "self":
+            nbr[K // 2] = torch.arange(rows, device=dev, dtype=torch.int32)
+        x = torch.randn(n_in, 8, device=dev, generator=g)
+        dy = torch.randn(rows, 12, device=dev, generator=g)
+        wp = ops.wgrad_pairs(nbr, K)
+        assert int(wp.tile_start[-1]) == int((nbr >= 0).sum())
+        dw = ops.spconv_bwd_weight_pairs(x, dy, wp)
+        want = torch.zeros(K, 8, 12, dtype=torch.float64, device=dev)
+        for k in range(K):
+            r = torch.nonzero(nbr[k] >= 0).view(-1)
+            want[k] = x[nbr[k][r].long()].double().t() @ dy[r].double()
+        np.testing.assert_allclose(dw.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    model, cfg, DS = _model()
+    model.train()
+    for n in (2, 1):   # two batch elements of one voxel each: every level keeps two rows
+        coords = torch.zeros(n, 3, dtype=torch.int32)
+        data = Data(pos=coords.float() * 0.05, coords=coords, x=torch.randn(n, 4), batch=torch.arange(n),
+                    y=torch.zeros(n, dtype=torch.long), instance_labels=torch.ones(n, dtype=torch.long),
+                    instance_mask=torch.ones(n, dtype=torch.bool), vote_label=torch.zeros(n, 3),
+                    center_label=torch.zeros(n, 3), num_instances=torch.tensor([1]))
+        model.set_input(data, dev)
+        if n == 1:
+            with pytest.raises(ValueError, match="more than 1 value per channel"):
+                model.forward(epoch=1)
+            continue
+        model.forward(epoch=1)
+        model.backward(1)
+        assert np.isfinite(float(model.loss.detach()))
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
