@@ -222,3 +222,14 @@ def test_cluster_functions_match_the_reference_model():
             for i, c in enumerate(got):
                 assert np.array_equal(c, np.sort(pts[offs[i]: offs[i + 1]])), (tag, i)
             assert np.array_equal(types.cpu().numpy(), z["types_" + tag]), tag
+
+
+@pytest.mark.parametrize("ct", [1, 4, 8, 12, 16])
+def test_pointgroupembed_without_thing_points(ct):
+    """every primitive of the recipes on an empty selection (all points predicted as stuff): no proposals, no error"""
+    model, cfg, scene, b, data, dev = _setup("PointGroupEmbed", n_points=12_000, cluster_type=ct, use_score_net=False)
+    model.set_input(data, dev)
+    with torch.no_grad():
+        feats, sem, off, emb, pred = model.backbone_and_heads()
+        res = model.group_and_score(-1, feats, sem, None, emb, torch.zeros_like(pred))   # class 0 = ground (stuff)
+    assert res.clusters_csr.n == 0 and res.cluster_type.numel() == 0
