@@ -900,7 +900,11 @@ class MinkowskiGlobalPooling(nn.Module):
     def forward(self, x):
         b = x.coordinate_manager.level(x.tensor_stride).coords[:, 0].long()
         nb = int(b.max().item()) + 1 if b.numel() else 0
-        pooled = ops.segment_reduce(x.feats.contiguous(), b, nb, "mean")
+        if torch.is_grad_enabled() and x.feats.requires_grad:
+            from ..torch_scatter import scatter  # differentiable segment mean (the raw op below is not)
+            pooled = scatter(x.feats, b, dim=0, reduce="mean", dim_size=nb)
+        else:
+            pooled = ops.segment_reduce(x.feats.contiguous(), b, nb, "mean")
         out = SparseTensor.__new__(SparseTensor)
         out.feats, out.coordinate_manager, out.tensor_stride = pooled, x.coordinate_manager, -1
         return out

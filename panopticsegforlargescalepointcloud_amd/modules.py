@@ -2,7 +2,8 @@
 
 Same class names, constructor arguments, sub-module names (=> identical state_dict keys and shapes, SURVEY.md
 App. A) and forward semantics as
-  torch_points3d/modules/MinkowskiEngine/api_modules.py:9-82 (ResBlock), :235-285 (ResNetDown), :288-311 (ResNetUp)
+  torch_points3d/modules/MinkowskiEngine/api_modules.py:9-82 (ResBlock), :85-232 (BottleneckBlock, SELayer, SEBlock,
+  SEBottleneckBlock), :235-285 (ResNetDown), :288-311 (ResNetUp)
   torch_points3d/core/common_modules/base_modules.py:35-45 (MLP), :128-153 (FastBatchNorm1d), :156-164 (Seq).
 In eval mode every conv -> BN -> ReLU (+ residual, + skip concat) chain is ONE fused kernel launch
 (ME.conv_bn_act); in training mode conv + BN (+ ReLU) run as one autograd node per pair (ME.conv_bn_act_train; same launches
@@ -176,6 +177,98 @@ class ResBlock(ME.MinkowskiNetwork):
         else:
             out = out + x
         return out
+
+
+class BottleneckBlock(ME.MinkowskiNetwork):
+    """1x1 (C/reduction) - 3x3 - 1x1 (C) convolutions, each followed by BN + ReLU, plus (1x1 conv-BN of the input | the
+    input) (api_modules.py:85-159; selected by `block: BottleneckBlock` in a backbone YAML).  Same sub-module names as the
+    reference's class.  (The reference's constructor assigns `self.block` without calling the Module constructor first and
+    raises AttributeError; pinned in tests/test_reference_binding.py.)"""
+
+    def __init__(self, input_nc, output_nc, convolution, dimension=3, reduction=4):
+        ME.MinkowskiNetwork.__init__(self, dimension)
+        mid = output_nc // reduction
+        self.block = Seq()
+        for cin, cout, ks in ((input_nc, mid, 1), (mid, mid, 3), (mid, output_nc, 1)):
+            self.block.append(convolution(in_channels=cin, out_channels=cout, kernel_size=ks, stride=1, dilation=1, bias=False,
+                                          dimension=dimension))
+            self.block.append(ME.MinkowskiBatchNorm(cout))
+            self.block.append(ME.MinkowskiReLU())
+        if input_nc != output_nc:
+            self.downsample = (
+                Seq()
+                .append(convolution(in_channels=input_nc, out_channels=output_nc, kernel_size=1, stride=1, dilation=1,
+                                    bias=False, dimension=dimension))
+                .append(ME.MinkowskiBatchNorm(output_nc))
+            )
+        else:
+            self.downsample = None
+
+    def _body(self, x):
+        """the conv-BN-ReLU chain: one fused launch per triple in inference, one autograd node per triple in training"""
+        b = self.block
+        out = x
+        for i in range(0, len(b), 3):
+            if not self.training and not torch.is_grad_enabled():
+                out = ME.conv_bn_act(out, b[i], b[i + 1], relu=True)
+            else:
+                nxt = ME.conv_bn_act_train(out, b[i], b[i + 1], relu=True) if self.training else None
+                out = nxt if nxt is not None else b[i + 2](b[i + 1](b[i](out)))
+        return out
+
+    def _shortcut(self, x):
+        if not self.downsample:
+            return x
+        if not self.training and not torch.is_grad_enabled():
+            return ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        return self.downsample(x)
+
+    def forward(self, x):
+        return self._body(x) + self._shortcut(x)
+
+
+class SELayer(nn.Module):
+    """squeeze and excite (api_modules.py:162-191): per batch element the mean feature vector -> Linear(C, C/reduction) ->
+    ReLU -> Linear(C/reduction, C) -> Sigmoid, multiplied back onto every row of the element"""
+
+    def __init__(self, channel, reduction=16, dimension=3):
+        super().__init__()
+        self.fc = nn.Sequential(ME.MinkowskiLinear(channel, channel // reduction), ME.MinkowskiReLU(),
+                                ME.MinkowskiLinear(channel // reduction, channel), ME.MinkowskiSigmoid())
+        self.pooling = ME.MinkowskiGlobalPooling()
+        self.broadcast_mul = ME.MinkowskiBroadcastMultiplication()
+
+    def forward(self, x):
+        return self.broadcast_mul(x, self.fc(self.pooling(x)))
+
+
+class SEBlock(ResBlock):
+    """ResBlock with the SE layer between the block and the residual add (api_modules.py:194-210)"""
+
+    def __init__(self, input_nc, output_nc, convolution, dimension=3, reduction=16):
+        super().__init__(input_nc, output_nc, convolution, dimension=3)
+        self.SE = SELayer(output_nc, reduction=reduction, dimension=dimension)
+
+    def forward(self, x):
+        b = self.block
+        if not self.training and not torch.is_grad_enabled():
+            out = ME.conv_bn_act(ME.conv_bn_act(x, b[0], b[1], relu=True), b[3], b[4], relu=True)
+            res = ME.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False) if self.downsample else x
+        else:
+            out = self.block(x)
+            res = self.downsample(x) if self.downsample else x
+        return self.SE(out) + res
+
+
+class SEBottleneckBlock(BottleneckBlock):
+    """BottleneckBlock with the SE layer (api_modules.py:213-232)"""
+
+    def __init__(self, input_nc, output_nc, convolution, dimension=3, reduction=16):
+        super().__init__(input_nc, output_nc, convolution, dimension=3, reduction=4)
+        self.SE = SELayer(output_nc, reduction=reduction, dimension=dimension)
+
+    def forward(self, x):
+        return self.SE(self._body(x)) + self._shortcut(x)
 
 
 _res_blocks = sys.modules[__name__]

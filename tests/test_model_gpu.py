@@ -439,3 +439,75 @@ def test_other_scorer_types_match_oracle(setup, scorer_type):
             assert _err("scores, MLP vs plain torch", res.cluster_scores.cpu().numpy(), plain.detach().cpu().numpy()) < 1e-4
     finally:
         m._scorer_type = old
+
+
+@pytest.mark.parametrize("block", ["BottleneckBlock", "SEBlock", "SEBottleneckBlock"])
+def test_other_block_types_match_a_dense_torch_composition(block):
+    """the block types a backbone YAML can select besides ResBlock (api_modules.py:85-232), in inference (fused launches)
+    and in training (autograd nodes, batch-statistics BN, differentiable SE pooling): outputs and input gradients against
+    the same layers written with torch index arithmetic on the manager's kernel map"""
+    import torch.nn.functional as F
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, modules as M
+    rng = np.random.default_rng(12)
+    coords = torch.from_numpy(bf.surface_coords(rng, n_batch=3, n=1500, extent=30)).cuda()
+    torch.manual_seed(6)
+    blk = getattr(M, block)(16, 32, ME.MinkowskiConvolution).cuda()
+    for m in blk.modules():   # non-trivial running statistics and affine parameters
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+
+    def dense(x, cm, training):
+        nbr = cm.kernel_map_rows(1, 1, 3, 1).long()
+        batch = cm.level(1).coords[:, 0].long()
+
+        def conv(h, w):
+            if w.dim() == 2:
+                return h @ w
+            out = torch.zeros(h.shape[0], w.shape[2], device="cuda")
+            for k in range(27):
+                ok = nbr[k] >= 0
+                out = out.index_add(0, torch.nonzero(ok).view(-1), h[nbr[k][ok]] @ w[k])
+            return out
+
+        def chain(seq, h):
+            for m in seq:
+                if isinstance(m, ME.MinkowskiBatchNorm):
+                    b = m.bn
+                    h = F.batch_norm(h, b.running_mean.clone(), b.running_var.clone(), b.weight, b.bias, training, 0.1, b.eps)
+                elif isinstance(m, ME.MinkowskiReLU):
+                    h = torch.relu(h)
+                else:
+                    h = conv(h, m.kernel)
+            return h
+        out = chain(blk.block, x)
+        if hasattr(blk, "SE"):
+            nb = int(batch.max()) + 1
+            mean = torch.zeros(nb, out.shape[1], device="cuda").index_add(0, batch, out) / torch.bincount(batch, minlength=nb)[:, None]
+            fc = blk.SE.fc
+            gate = torch.sigmoid(F.linear(torch.relu(F.linear(mean, fc[0].linear.weight, fc[0].linear.bias)),
+                                          fc[2].linear.weight, fc[2].linear.bias))
+            out = out * gate[batch]
+        return out + (chain(blk.downsample, x) if blk.downsample else x)
+
+    x0 = torch.randn(len(coords), 16, device="cuda")
+    for training in (False, True):
+        blk.train(training)
+        x = x0.clone().requires_grad_(training)
+        with torch.set_grad_enabled(training):
+            st = ME.SparseTensor(features=x, coordinates=coords, device="cuda")
+            y = blk(st)
+        cm = st.coordinate_manager
+        x2 = x0.clone().requires_grad_(training)
+        xin = x2 if cm.perm is None else x2[cm.perm]
+        with torch.set_grad_enabled(training):
+            want = dense(xin, cm, training)
+        got = y.feats   # internal row order, like `want`
+        bf.scaled_err("%s %s" % (block, "train" if training else "eval"), got.detach().cpu().numpy(), want.detach().cpu().numpy())
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+        if training:
+            (y.F ** 2).mean().backward()
+            (want ** 2).mean().backward()
+            np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-3, atol=1e-6)

@@ -151,3 +151,26 @@ def test_reference_resblock_forward_order_matches(reference_minkowski):
         ta = [(n, type(m).__name__, getattr(m, "kernel_size", None), getattr(m, "stride", None)) for n, m in a.named_modules()]
         tb = [(n, type(m).__name__, getattr(m, "kernel_size", None), getattr(m, "stride", None)) for n, m in b.named_modules()]
         assert ta == tb
+
+
+def test_reference_se_and_bottleneck_blocks(reference_minkowski):
+    """the other block types of api_modules.py (`block:` in a backbone YAML): the reference's SEBlock built on the shim has the
+    same module tree and the same seeded parameters as the build-owned one; the reference's BottleneckBlock /
+    SEBottleneckBlock cannot be constructed at all (they assign sub-modules before nn.Module.__init__ ran) -- the build-owned
+    ones follow their layer list (:91-147) and construct."""
+    from panopticsegforlargescalepointcloud_amd import modules as own
+    api = sys.modules["torch_points3d.modules.MinkowskiEngine.api_modules"]
+    kw = dict(down_conv_nn=[16, 32], kernel_size=3, stride=2, N=2, block="SEBlock")
+    torch.manual_seed(5)
+    a = api.ResNetDown(**kw)
+    torch.manual_seed(5)
+    b = own.ResNetDown(**kw)
+    assert [(n, type(m).__name__) for n, m in a.named_modules()] == [(n, type(m).__name__) for n, m in b.named_modules()]
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    for name in ("BottleneckBlock", "SEBottleneckBlock"):
+        with pytest.raises(AttributeError, match="before Module.__init__"):
+            api.ResNetDown(down_conv_nn=[16, 32], kernel_size=3, stride=2, N=1, block=name)
+        blk = own.ResNetDown(down_conv_nn=[16, 32], kernel_size=3, stride=2, N=1, block=name).blocks[0]
+        convs = [(m.in_channels, m.out_channels, m.kernel_size) for m in blk.block if hasattr(m, "kernel_size")]
+        assert convs == [(16, 8, 1), (8, 8, 3), (8, 32, 1)] and blk.downsample is not None
