@@ -188,7 +188,8 @@ def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=5, warmups=2, n_ti
     timings = dict(timings)
     timings["meanshift"] = t_ms  # the fan-out over the whole batch (the per-tile passes reuse its result)
     res = {"value": n_batch / (t_net_batch + t_ms), "unit": "points/sec", "cores": threads, "host_cpus": os.cpu_count(),
-           "cgroup_cpu_quota": quota, "kind": "port", "tiles_timed": len(chosen), "meanshift_processes": procs,
+           "cgroup_cpu_quota": quota, "kind": "port", "tiles_timed_meanshift": len(chosen), "tiles_timed_network": 1,
+           "network_scaled_to_tiles": len(chosen), "meanshift_processes": procs,
            "sample": "batch of %d of %d tiles around the median size (%d voxels): %s MeanShift one sample per spawned process on %d "
                      "processes (pool.map, %.2f s per batch) + C/OpenMP oracle U-Net+heads+region_grow+scorer on %d threads "
                      "(median tile of %d voxels: %.2f s per pass, scaled by points to the batch: %.1f s); %d warm-ups, median "
@@ -247,6 +248,42 @@ def _near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, mi
     return amb
 
 
+class _SpreadScorerHead:
+    """with _SpreadScorerHead(lin, scores): ... -- rescales the ScorerHead's Linear layer from the scores of a first pass so that
+    the proposals' logits spread to mean 2.1 / unit variance (scores over roughly (0.55, 0.99)).  A random-init head squeezes
+    every score into a ~1e-3 band, where a quarter of a tile's points hang on score comparisons closer than 1e-5 by CHANCE;
+    with the logits spread, only the genuine twins (two proposals with nearly the same points, whose max-pooled features agree
+    to the last bits) stay near-tied.  Same proposals, same scorer features; the layer is restored on exit."""
+
+    def __init__(self, lin, scores):
+        self.lin, self.w0, self.b0 = lin, lin.weight.detach().clone(), lin.bias.detach().clone()
+        sc = scores.detach().double().clamp(1e-9, 1 - 1e-9)
+        z = torch.log(sc / (1 - sc)) - float(self.b0[0])
+        self.alpha = 1.0 / max(float(z.std()), 1e-9)
+        self.beta = 2.1 - self.alpha * float(z.mean())
+
+    def __enter__(self):
+        with torch.no_grad():
+            self.lin.weight.copy_(self.w0 * self.alpha)
+            self.lin.bias.fill_(self.beta)
+        return self
+
+    def __exit__(self, *exc):
+        with torch.no_grad():
+            self.lin.weight.copy_(self.w0)
+            self.lin.bias.copy_(self.b0)
+        return False
+
+    def oracle_scores(self, cluster_features):
+        """the oracle's scores under the rescaled head: sigmoid(features . w + b) as oracle/pipeline.py computes them"""
+        w = (self.w0 * self.alpha).detach().cpu().numpy().astype(np.float32)
+        z = (np.asarray(cluster_features) @ w.T + np.float32(self.beta))[:, 0]
+        return 1.0 / (1.0 + np.exp(-z))
+
+
+NEAR_TIE_BOUND = 0.10  # share of a tile's points that may hang on a score near-tie (< 1e-5) before the label check FAILS
+
+
 def self_check(runner, batches, device, oracle_case):
     """Untimed correctness checks of the benchmark's own run (the 10 M-row kernel variants are not reachable from the
     unit tests' sizes): (1) batch invariance -- a tile of the 64-tile batch gives the same result as that tile run alone
@@ -283,15 +320,31 @@ def self_check(runner, batches, device, oracle_case):
         e_feat = _scaled_err(rg.embed_logits.cpu().numpy(), want["embed_logits"])
         e_seml = _scaled_err(rg.semantic_logits.cpu().numpy(), want["semantic_logits"])
         ok_score, ok_feat = ok_prop and e_score < 1e-4, e_feat < 1e-4 and e_seml < 1e-4
-        # instance labels against the oracle's own scores and NMS; points that hang on a score near-tie (< 1e-5) between two
-        # overlapping proposals are left out and counted
-        amb = _near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"])) if ok_prop else np.zeros(len(b["pos"]), bool)
-        ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()[~amb]), _canonical(want_labels[~amb]))) and amb.mean() < 0.6
+        # instance labels against the oracle's OWN scores and NMS, with the ScorerHead's logits spread (second pass of both
+        # paths: same proposals, same scorer features) so that only genuine twins stay near-tied; those points are left out,
+        # reported as a fraction, and the check FAILS above NEAR_TIE_BOUND
+        amb = np.zeros(len(b["pos"]), bool)
+        ok_inst, e_spread, frac_unspread = False, float("nan"), float("nan")
+        if ok_prop:
+            from oracle import pipeline as opipe
+            frac_unspread = float(_near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"])).mean())
+            with _SpreadScorerHead(runner.model.ScorerHead[0], rg.cluster_scores) as sp:
+                lg, rg2, cg = runner.run(dev_one, 1, override=tuple(torch.from_numpy(a).to(device) for a in ov))
+                want_sp = dict(want)
+                want_sp["cluster_scores"] = sp.oracle_scores(want["cluster_features"])
+            e_spread = _scaled_err(rg2.cluster_scores.cpu().numpy(), want_sp["cluster_scores"])
+            want_labels = opipe.instance_labels(want_sp, len(b["pos"]), b["batch"])
+            amb = _near_tie_points(want_sp["clusters"], want_sp["cluster_scores"], len(b["pos"]))
+            ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()[~amb]), _canonical(want_labels[~amb]))) \
+                and e_spread < 1e-4 and amb.mean() <= NEAR_TIE_BOUND
         checks["oracle"] = "pass" if (ok_prop and ok_score and ok_feat and ok_inst) else \
             "FAIL(proposals=%s scores=%s embeddings=%s instances=%s)" % (ok_prop, ok_score, ok_feat, ok_inst)
         checks["oracle_tile"] = {"rows": len(b["pos"]), "proposals": len(got), "instances": int(cg[0]),
-                                 "points_on_score_near_ties": int(amb.sum())}
-        checks["max_err"].update({"oracle_scores": e_score, "oracle_embeddings": e_feat, "oracle_semantic": e_seml})
+                                 "points_on_score_near_ties": int(amb.sum()), "near_tie_fraction": round(float(amb.mean()), 4),
+                                 "near_tie_bound": NEAR_TIE_BOUND, "near_tie_fraction_random_head": round(frac_unspread, 4),
+                                 "score_spread": "ScorerHead logits rescaled to mean 2.1 / unit variance for the label check"}
+        checks["max_err"].update({"oracle_scores": e_score, "oracle_scores_spread_head": e_spread, "oracle_embeddings": e_feat,
+                                  "oracle_semantic": e_seml})
     checks["all"] = "pass" if all(not str(v).startswith("FAIL") for v in checks.values()) else "FAIL"
     return checks
 

@@ -250,7 +250,7 @@ def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklear
         pred, off, emb = override
     clusters, ctype = group(data["pos"], data["batch"], pred, off, emb, opt, stuff_classes, use_sklearn_meanshift, T, ms_clusters)
     clusters, ctype = list(clusters), list(ctype)
-    scores = None
+    scores = cf = None
     if clusters:
         t0 = time.perf_counter()
         pts = np.concatenate(clusters)
@@ -267,7 +267,8 @@ def forward(sd, data, opt, num_classes, stuff_classes, override=None, use_sklear
         scores = 1.0 / (1.0 + np.exp(-(cf @ w.T + bb)[:, 0]))
         T["scorer"] = time.perf_counter() - t0
     return {"features": feats, "semantic_logits": sem, "offset_logits": off, "embed_logits": emb, "pred": pred,
-            "clusters": clusters, "cluster_type": np.asarray(ctype, np.uint8), "cluster_scores": scores}
+            "clusters": clusters, "cluster_type": np.asarray(ctype, np.uint8), "cluster_scores": scores,
+            "cluster_features": cf}  # per-proposal maximum of the scorer's features: the ScorerHead's input
 
 
 def instance_labels(out, n_points, batch, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):

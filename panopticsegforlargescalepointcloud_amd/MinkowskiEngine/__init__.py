@@ -332,6 +332,19 @@ class CoordinateManager:
                 m = self._kernel_map_locked(key)
         self._use(key)
         self._consumed_here(m, getattr(m, "pp_order", None))
+        if getattr(m, "pp_t8", False) and torch.is_grad_enabled():
+            # The 8-wide form is an inference-only layout ([8, n], not [27, n]): the weight gradient and the pair lists index
+            # 27 * n entries.  A map built under no_grad (frozen pre-pass, prefetch worker) and then used with grad enabled
+            # is expanded once to its dense twin in the same slot order; autograd only ever sees that one.
+            d = getattr(m, "pp_dense", None)
+            if d is None:
+                with self._lock:
+                    d = getattr(m, "pp_dense", None)
+                    if d is None:
+                        d = ops.map8_to_dense(m)
+                        d.pp_order = m.pp_order
+                        m.pp_dense = d
+            return d
         return m
 
     def kernel_map_rows(self, ts_from, ts_to, ksize, sign):
@@ -545,6 +558,9 @@ class _SparseConvFn(torch.autograd.Function):
 def _conv_backward(ctx, feats, kernel, dout, need_in, need_w):
     """input and weight gradient of a sparse convolution from the context _SparseConvFn / _ConvBnActTrainFn keep"""
     din = dw = None
+    if getattr(ctx.nbr, "pp_t8", False):
+        raise RuntimeError("an 8-wide transposed map reached autograd: CoordinateManager.kernel_map hands out the dense "
+                           "twin when grad is enabled -- the map was fetched under no_grad and used with grad")
     if need_in:
         if ctx.same_level:
             packed_t = _pack(kernel, transpose=True, kflip=not ctx.kflip)
@@ -560,7 +576,8 @@ def _conv_backward(ctx, feats, kernel, dout, need_in, need_w):
             ops.PROFILE_TAG = "fwd"
     if need_w:
         order = getattr(ctx.nbr, "pp_order", None)
-        if WGRAD_PAIRS and ctx.nbr is not None and dout.shape[1] <= 192:  # (the kernels' widest output tile set)
+        if (WGRAD_PAIRS and ctx.nbr is not None and dout.shape[1] <= 192  # (the kernels' widest output tile set)
+                and ctx.K * ctx.nbr.shape[1] < (1 << 31)):  # tile offsets are int32; larger maps take the dense-map kernel
             # the pairs of the map compacted per offset, once per map (every layer on this map re-uses the lists);
             # a slot order is folded into the lists, dout is read in its own row order
             wp = getattr(ctx.nbr, "pp_wpairs", None)

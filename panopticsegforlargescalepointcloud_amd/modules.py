@@ -163,8 +163,15 @@ class ResBlock(ME.MinkowskiNetwork):
         if self.training:
             # training: one autograd node per conv + BN (+ ReLU) instead of one per module (same launches, same results)
             h = ME.conv_bn_act_train(x, b[0], b[1], relu=True)
-            out = ME.conv_bn_act_train(h, b[3], b[4], relu=True) if h is not None else None
-            if out is not None:
+            if h is not None:
+                # the first pair has run (and updated its running statistics): never run it again.  A second pair that is
+                # not the plain case (bias, BatchNorm in eval mode in a partially frozen block) goes module by module
+                # FROM h -- falling back to self.block(x) would count the first BatchNorm's batch twice
+                out = ME.conv_bn_act_train(h, b[3], b[4], relu=True)
+                if out is None:
+                    out = h
+                    for m in list(b)[3:]:
+                        out = m(out)
                 res = x
                 if self.downsample:
                     res = ME.conv_bn_act_train(x, self.downsample[0], self.downsample[1], relu=False)

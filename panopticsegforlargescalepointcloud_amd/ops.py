@@ -544,8 +544,14 @@ class _PackedWeights:
     entries are re-packed by pp_pack_weights_batched (parameters whose weights did not change are simply packed again)."""
 
     def __init__(self):
-        self.entries = {}      # (id(param), flags) -> [weakref(param), flags, packed, version, K, cin, cout]
-        self.table = None      # (desc, first_block, n, total_blocks) on the device, or None when entries changed
+        self.entries = {}      # (id(param), flags) -> [weakref(param), flags, packed, tag, K, cin, cout]
+        self.tables = {}       # device -> (desc, first_block, n, total_blocks, source pointers), dropped when its entries change
+
+    @staticmethod
+    def _tag(param):
+        # data_ptr: `p.data = ...`, vector_to_parameters, EMA / SWA swaps and to_empty replace a parameter's storage without
+        # touching its version or the optimizer epoch -- the packed copy (and the pointer table below) would go stale
+        return (param._version, _PARAM_EPOCH[0], param.data_ptr())
 
     def get(self, param, transpose, kflip):
         import weakref
@@ -553,36 +559,39 @@ class _PackedWeights:
         key = (id(param), flags)
         ent = self.entries.get(key)
         if ent is not None and ent[0]() is param and ent[2].device == param.device:
-            if ent[3] != (param._version, _PARAM_EPOCH[0]):
+            if ent[3] != self._tag(param):
                 self._repack_all(param.device)
             return ent[2]
         packed = pack_weight(param, transpose=transpose, kflip=kflip)
         w = param.detach()
         K, a, b = (1,) + tuple(w.shape) if w.dim() == 2 else tuple(w.shape)
         cin, cout = (b, a) if transpose else (a, b)
-        self.entries[key] = [weakref.ref(param), flags, packed, (param._version, _PARAM_EPOCH[0]), K, cin, cout]
-        self.table = None
+        self.entries[key] = [weakref.ref(param), flags, packed, self._tag(param), K, cin, cout]
+        self.tables.pop(param.device, None)
         return packed
 
     def _repack_all(self, device):
         lib = _lib.load()
-        live = [(k, e) for k, e in self.entries.items() if e[0]() is not None and e[2].device == device]
-        if len(live) != len(self.entries):
-            self.entries = dict(live)
-            self.table = None
-        if self.table is None:
+        dead = [k for k, e in self.entries.items() if e[0]() is None]
+        if dead:  # only dead parameters leave; entries of OTHER devices stay (one process may drive several GPUs)
+            for k in dead:
+                del self.entries[k]
+            self.tables.clear()
+        live = [e for e in self.entries.values() if e[2].device == device]
+        ptrs = tuple(e[0]().data_ptr() for e in live)
+        table = self.tables.get(device)
+        if table is None or table[4] != ptrs:
             rows, first, blocks = [], [0], 0
-            for _, e in live:
-                p = e[0]()
-                rows.append([p.data_ptr(), e[2].data_ptr(), e[4], e[5], e[6], e[1]])
+            for e, src in zip(live, ptrs):
+                rows.append([src, e[2].data_ptr(), e[4], e[5], e[6], e[1]])
                 blocks += (e[2].numel() + 255) // 256
                 first.append(blocks)
-            self.table = (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(first, dtype=torch.int64).to(device),
-                          len(rows), blocks)
-        desc, first, n, blocks = self.table
+            table = self.tables[device] = (torch.tensor(rows, dtype=torch.int64).to(device),
+                                           torch.tensor(first, dtype=torch.int64).to(device), len(rows), blocks, ptrs)
+        desc, first, n, blocks, _ = table
         _lib.check(lib.pp_pack_weights_batched(_ptr(desc), _ptr(first), n, blocks, _stream()), "pp_pack_weights_batched")
-        for _, e in live:
-            e[3] = (e[0]()._version, _PARAM_EPOCH[0])
+        for e in live:
+            e[3] = self._tag(e[0]())
 
 
 PACKED_WEIGHTS = _PackedWeights()
@@ -711,13 +720,16 @@ class WgradPairs:
 
 def wgrad_pairs(nbr, K, row_order=None):
     """(output row, input row) lists per offset of the dense map nbr [K, rows]; row_order folds a slot order in (row r of
-    the map is output row row_order[r]).  The list buffer is sized for the worst case (K * rows pairs)."""
+    the map is output row row_order[r]).  The list buffer holds exactly the map's pairs (one host read per map, amortised
+    over every layer and step that trains on it): typical maps hold 5.6 - 16 of the K = 27 neighbours per row, and the lists
+    live as long as the coordinate manager."""
     lib = _lib.load()
     nbr = _need(nbr, torch.int32, "nbr")
     rows = nbr.shape[1]
     dev = nbr.device
     tiles = K * ((rows + 1023) // 1024)
-    pairs = torch.empty((max(K * rows, 1), 2), dtype=torch.int32, device=dev)
+    n_pairs = int(_pairs_of(nbr).item())
+    pairs = torch.empty((max(n_pairs, 1), 2), dtype=torch.int32, device=dev)
     tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
     nbytes = lib.pp_wgrad_pairs_workspace(K, rows)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

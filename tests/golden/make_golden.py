@@ -355,6 +355,152 @@ def make_final_eval():
     print("final_eval:", {k: cases[k].tolist() for k in cases if k.startswith("log_e0_") and ("mean" in k or "mIoU" in k or "F1" in k)})
 
 
+
+def _parse_log(log, prefix, cases):
+    import re
+    section = ""
+    for line in log.splitlines():
+        if line.strip().startswith("Instance Segmentation for"):
+            section = "offset_" if "Offset" in line else "embed_"
+            continue
+        if ":" not in line:
+            continue
+        key, val = line.split(":", 1)
+        val = val.replace("np.float64(", "(")  # numpy 2 prints the scalars of a list with their type
+        nums = [float(v) for v in re.findall(r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?|nan|inf", val)]
+        if nums:
+            cases["log_%s_%s%s" % (prefix, section, re.sub(r"[^A-Za-z0-9]+", "_", key.strip()))] = np.asarray(nums)
+
+
+def make_treeins_eval():
+    """Runs the reference's OWN FOR-instance final_eval (torch_points3d/datasets/panoptic/treeins.py:99-497: two instance
+    predictions, three classes) on synthetic label arrays; the function is extracted with `ast` as for NPM3D and its log
+    file is parsed (section headers "for Offset" / "for Embeddings" become key prefixes)."""
+    import ast
+    import tempfile
+    import warnings
+    from scipy import stats
+    path = os.path.join(REF, "torch_points3d/datasets/panoptic/treeins.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "final_eval"][0]
+    ns = {"np": np, "stats": stats, "os": os, "torch": torch}
+    if not hasattr(np, "int"):
+        np.int, np.float = int, float
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(91)
+    cases, names = {}, []
+    for t in range(4):
+        n = 5000
+        n_inst = 18
+        gt_ins = rng.integers(0, n_inst, size=n)
+        inst_cls = np.where(rng.random(n_inst) < 0.7, 1, 0)          # 1 = tree (thing), 0 = non-tree (stuff)
+        if t == 2:
+            inst_cls[:] = 1                                           # no stuff instance at all
+        gt_sem = inst_cls[gt_ins]
+        gt_ins_lab = np.where(gt_sem == 0, -1, gt_ins)
+        unl = rng.random(n) < 0.04
+        gt_sem = np.where(unl, -1, gt_sem)
+        gt_ins_lab = np.where(unl, -1, gt_ins_lab)
+        pred_sem = np.where(rng.random(n) < 0.88, np.maximum(gt_sem, 0), rng.integers(0, 2, size=n))
+        def noisy(seed_shift):
+            r = np.random.default_rng(1000 * t + seed_shift)
+            p = np.where(pred_sem == 0, -1, gt_ins + 50)
+            p = np.where((p >= 0) & (r.random(n) < 0.25) & (gt_ins % 3 == seed_shift % 3), p + 500, p)
+            p = np.where((p >= 0) & (gt_ins % 5 == 1 + seed_shift), 77, p)
+            p = np.where((p >= 0) & (gt_ins % 7 == 3 - seed_shift), -1, p)
+            return p
+        pre_off, pre_emb = noisy(0), noisy(1)
+        if t == 3:
+            pre_emb = np.full(n, -1)                                  # the embedding branch found nothing
+        with tempfile.TemporaryDirectory() as tmp, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ns["final_eval"](pred_sem.copy(), pre_emb.copy(), pre_off.copy(), gt_sem.copy(), gt_ins_lab.copy(), os.path.join(tmp, "ev"))
+            log = open(os.path.join(tmp, "ev.txt")).read()
+        name = "t%d" % t
+        names.append(name)
+        for k, v in (("pred_sem_", pred_sem), ("pre_off_", pre_off), ("pre_emb_", pre_emb), ("gt_sem_", gt_sem), ("gt_ins_", gt_ins_lab)):
+            cases[k + name] = v.astype(np.int64)
+        _parse_log(log, name, cases)
+    cases["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "treeins_eval_cases.npz"), **cases)
+    print("treeins final_eval:", {k: cases[k].tolist() for k in cases if k.startswith("log_t0_") and ("mIoU" in k or "F1" in k or "meanPQ" in k)})
+
+
+def make_tracker_metrics():
+    """Runs the reference tracker's OWN per-batch metrics (_compute_acc / _compute_eval,
+    torch_points3d/metrics/panoptic_tracker_pointgroup_npm3d.py:678-879; static methods extracted with `ast`, instance_iou =
+    the brute-force stand-in of _stub_modules) on synthetic batches: clusters, predicted labels, labels -> the returned scalars."""
+    import ast
+    _stub_modules()
+    path = os.path.join(REF, "torch_points3d/metrics/panoptic_tracker_pointgroup_npm3d.py")
+    tree = ast.parse(open(path).read())
+    fns = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("_compute_acc", "_compute_eval"):
+            node.decorator_list = []
+            fns.append(node)
+    if not hasattr(np, "int"):
+        np.int, np.float = int, float
+    ns = {"np": np, "torch": torch, "instance_iou": sys.modules["torch_points_kernels"].instance_iou}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(123)
+    cases, names = {}, []
+    thing = np.array([2, 3, 4, 6, 7, 8])
+    stuff = np.array([0, 1, 5])
+    for t in range(5):
+        nb = 2 if t < 4 else 1
+        n = 1600
+        batch = np.sort(rng.integers(0, nb, size=n))
+        inst = np.zeros(n, np.int64)
+        y = np.zeros(n, np.int64)
+        num_instances = []
+        for b in range(nb):
+            m = np.nonzero(batch == b)[0]
+            k = int(rng.integers(4, 9))
+            owner = rng.integers(0, k + 2, size=len(m))                 # ids k, k+1 -> no instance (stuff)
+            cls_of = rng.choice(thing if t != 3 else thing[:2], k)
+            inst[m] = np.where(owner < k, owner + 1, 0)
+            y[m] = np.where(owner < k, cls_of[np.minimum(owner, k - 1)], rng.choice(stuff, len(m)))
+            num_instances.append(k)
+        y = np.where(rng.random(n) < 0.02, -1, y)                         # a few unlabelled points
+        pred_labels = np.where(rng.random(n) < 0.85, np.maximum(y, 0), rng.integers(0, 9, size=n))
+        # clusters: the ground-truth instances, some split in two, some merged with a neighbour, some dropped, one of pure stuff
+        clusters = []
+        for b in range(nb):
+            for g in range(1, num_instances[b] + 1):
+                idx = np.nonzero((batch == b) & (inst == g))[0]
+                r = rng.random()
+                if r < 0.15 or len(idx) < 4:
+                    continue
+                if r < 0.4:
+                    cut = len(idx) // 3
+                    clusters += [idx[:cut], idx[cut:]]
+                elif r < 0.55 and clusters and batch[clusters[-1][0]] == b:
+                    clusters[-1] = np.concatenate([clusters[-1], idx])
+                else:
+                    clusters.append(idx[rng.random(len(idx)) < 0.9])
+            extra = np.nonzero((batch == b) & (inst == 0))[0][:25]
+            if len(extra) > 3:
+                clusters.append(extra)
+        clusters = [np.sort(c) for c in clusters if len(c)]
+        labels = types.SimpleNamespace(instance_labels=torch.from_numpy(inst), y=torch.from_numpy(y),
+                                       num_instances=torch.tensor(num_instances))
+        cl_t = [torch.from_numpy(c) for c in clusters]
+        acc = ns["_compute_acc"](cl_t, torch.from_numpy(pred_labels), labels, torch.from_numpy(batch), labels.num_instances, 0.5)
+        ev = ns["_compute_eval"](cl_t, torch.from_numpy(pred_labels), labels, torch.from_numpy(batch), labels.num_instances, 9, 0.5)
+        name = "b%d" % t
+        names.append(name)
+        cases["batch_" + name], cases["inst_" + name], cases["y_" + name] = batch, inst, y
+        cases["pred_" + name], cases["num_instances_" + name] = pred_labels, np.asarray(num_instances)
+        cases["cl_points_" + name] = np.concatenate(clusters)
+        cases["cl_offsets_" + name] = np.concatenate([[0], np.cumsum([len(c) for c in clusters])])
+        cases["acc_" + name] = np.asarray([float(v) for v in acc])
+        cases["eval_" + name] = np.asarray([float(v) for v in ev])
+    cases["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "tracker_metric_cases.npz"), **cases)
+    print("tracker metrics:", {n: (cases["acc_" + n].round(4).tolist(), cases["eval_" + n].round(4).tolist()) for n in names})
+
+
 def make_grid_cylinders():
     """Runs the reference's OWN GridCylinderSampling + CylinderSampling (torch_points3d/core/data_transform/transforms.py:
     182-267, 388-441) on a synthetic rotated strip of points.  The module cannot be imported (torch_geometric, numba, ...),
@@ -650,6 +796,12 @@ if __name__ == "__main__":
     if "--final-eval-only" in sys.argv:
         make_final_eval()
         sys.exit(0)
+    if "--treeins-eval-only" in sys.argv:
+        make_treeins_eval()
+        sys.exit(0)
+    if "--tracker-metrics-only" in sys.argv:
+        make_tracker_metrics()
+        sys.exit(0)
     make_hdbscan()
     if "--hdbscan-only" in sys.argv:
         sys.exit(0)
@@ -658,6 +810,8 @@ if __name__ == "__main__":
     make_mask_losses()
     make_nms()
     make_final_eval()
+    make_treeins_eval()
+    make_tracker_metrics()
     make_grid_cylinders()
     make_block_merging()
     print("proposal_cases.npz: run `python tests/golden/make_golden.py --proposals-only` (single-threaded environment)")

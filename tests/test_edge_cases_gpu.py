@@ -106,3 +106,100 @@ def test_weight_gradient_pair_lists_degenerate_maps():
         model.backward(1)
         assert np.isfinite(float(model.loss.detach()))
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_maps_built_under_no_grad_serve_a_later_training_step(monkeypatch):
+    """A coordinate manager first used under no_grad caches the transposed stride-2 map in its 8-wide inference form ([8, n]);
+    autograd must never see it (the weight gradient and the pair lists index 27 * n entries): the same manager then serves a
+    training step through the dense twin, with the gradients of a manager that was never used under no_grad."""
+    import bruteforce as bf
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, modules as M
+    monkeypatch.setattr(ME, "MAP_ORDER_MIN_ROWS", 500)
+    rng = np.random.default_rng(3)
+    coords = torch.from_numpy(bf.surface_coords(rng, n_batch=2, n=3000, extent=40)).cuda()
+    x0 = torch.randn(len(coords), 16, device="cuda")
+    torch.manual_seed(2)
+    down = M.ResNetDown(down_conv_nn=[16, 32], kernel_size=3, stride=2, N=1).cuda()
+    up = M.ResNetUp(up_conv_nn=[32 + 32, 16], kernel_size=3, stride=2, N=1).cuda()
+    bns = [m for m in list(down.modules()) + list(up.modules()) if isinstance(m, torch.nn.BatchNorm1d)]
+
+    def step(cm=None):
+        for b_ in bns:
+            b_.reset_running_stats()
+        down.train(), up.train()
+        down.zero_grad(), up.zero_grad()
+        if cm is None:
+            x = x0.clone().requires_grad_(True)
+            st = ME.SparseTensor(features=x, coordinates=coords, device="cuda")
+        else:  # features handed over in the manager's internal row order
+            x = cm.to_internal(x0).clone().requires_grad_(True)
+            st = ME.SparseTensor(x, coordinate_manager=cm, tensor_stride=1)
+        h = down(st)
+        y = up(h, h)
+        (y.F ** 2).mean().backward()
+        dx = x.grad if cm is None else cm.to_caller(x.grad)
+        return y.F.detach().clone(), dx.clone(), {n: p.grad.clone() for n, p in list(down.named_parameters()) + list(up.named_parameters())}
+
+    down.eval(), up.eval()
+    with torch.no_grad():  # inference pre-pass: the manager caches the 8-wide map
+        st = ME.SparseTensor(features=x0, coordinates=coords, device="cuda")
+        h = down(st)
+        up(h, h)
+    cm = st.coordinate_manager
+    assert any(getattr(m, "pp_t8", False) for m in cm.maps.values()), "the pre-pass built no 8-wide map: the test is void"
+    y_ref, dx_ref, g_ref = step()        # a fresh manager that never ran under no_grad
+    y, dx, g = step(cm)                  # the manager of the pre-pass
+    assert any(hasattr(m, "pp_dense") for m in cm.maps.values())
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), dx_ref.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    for n in g_ref:
+        np.testing.assert_allclose(g[n].cpu().numpy(), g_ref[n].cpu().numpy(), rtol=2e-4, atol=1e-6, err_msg=n)
+
+
+def test_packed_weight_cache_follows_a_storage_swap():
+    """`p.data = ...` (EMA / SWA swaps, vector_to_parameters, to_empty) replaces a parameter's storage without touching its
+    version counter or the optimizer epoch: the batched packed-weight cache keys on the data pointer as well."""
+    from panopticsegforlargescalepointcloud_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(27, 16, 32, device=dev))
+    q = torch.nn.Parameter(torch.randn(27, 32, 16, device=dev))
+    cache = ops._PackedWeights()
+    a0 = cache.get(p, False, False).clone()
+    cache.get(q, False, False)
+    assert torch.equal(a0, ops.pack_weight(p))
+    new = torch.randn(27, 16, 32, device=dev)
+    v = p._version
+    p.data = new                      # same version, new storage
+    assert p._version == v
+    a1 = cache.get(p, False, False)
+    assert torch.equal(a1, ops.pack_weight(new)) and not torch.equal(a1, a0)
+    assert torch.equal(cache.get(q, False, False), ops.pack_weight(q))      # the other entry was re-packed from ITS storage
+    with torch.no_grad():
+        p.mul_(2.0)                   # in-place: version bump, same storage
+    assert torch.equal(cache.get(p, False, False), ops.pack_weight(new * 2.0))
+
+
+def test_resblock_with_a_frozen_second_batchnorm_counts_the_first_once():
+    """Training-mode ResBlock whose second BatchNorm is in eval mode (partially frozen block): the fused first pair has
+    already updated its running statistics when the second pair turns out not to be the plain case -- the block continues
+    from there module by module instead of running (and counting) the first pair again."""
+    import bruteforce as bf
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME, modules as M
+    rng = np.random.default_rng(5)
+    coords = torch.from_numpy(bf.surface_coords(rng, n_batch=1, n=1500, extent=30)).cuda()
+    x0 = torch.randn(len(coords), 16, device="cuda")
+    torch.manual_seed(1)
+    blk = M.ResBlock(16, 32, ME.MinkowskiConvolution).cuda().train()
+    blk.block[4].eval()               # freeze the second BatchNorm only
+    ref = M.ResBlock(16, 32, ME.MinkowskiConvolution).cuda().train()
+    ref.load_state_dict(blk.state_dict())
+    ref.block[4].eval()
+    st = ME.SparseTensor(features=x0, coordinates=coords, device="cuda")
+    y = blk(st)
+    assert int(blk.block[1].bn.num_batches_tracked) == 1 and int(blk.block[4].bn.num_batches_tracked) == 0
+    # module by module (what the fallback of the whole block does), on a copy
+    h = ref.block(st)
+    y_ref = h + ref.downsample(st)
+    np.testing.assert_allclose(y.F.detach().cpu().numpy(), y_ref.F.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(blk.block[1].bn.running_mean, ref.block[1].bn.running_mean, rtol=1e-6, atol=1e-7)

@@ -146,3 +146,39 @@ def test_block_merging_rules_device(ops):
         assert gpu.ins_pre.cpu().tolist() == cpu.ins_pre.tolist() and gpu.max_instance == cpu.max_instance
     gpu.finish()
     assert cpu.ins_pre[10:13].tolist() == [3, 3, 3]  # the reference allocates max_instance + 1
+
+
+def test_treeins_evaluation_device_matches_reference_log(ops):
+    """FOR-instance final evaluation (two instance predictions, datasets/panoptic/treeins.py:99-497) on device tensors ==
+    the reference's own log (tests/golden/treeins_eval_cases.npz) == the NumPy form."""
+    import test_host_logic as thl
+    from panopticsegforlargescalepointcloud_amd.panoptic.metrics import panoptic_evaluation_treeins
+    z = np.load(os.path.join(GOLD, "treeins_eval_cases.npz"))
+    for name in z["names"].tolist():
+        args = [z[k + name].astype(np.int64) for k in ("pred_sem_", "pre_emb_", "pre_off_", "gt_sem_", "gt_ins_")]
+        r = panoptic_evaluation_treeins(*(dev(a) for a in args))
+        thl.check_treeins_result(z, name, r)
+        h = panoptic_evaluation_treeins(*args)
+        for sec in ("offset", "embed"):
+            for k in h[sec]:
+                np.testing.assert_array_equal(np.asarray(r[sec][k]), np.asarray(h[sec][k]), err_msg="%s %s %s" % (name, sec, k))
+
+
+def test_tracker_batch_metrics_match_reference(ops):
+    """compute_acc / compute_eval == the reference tracker's own _compute_acc / _compute_eval
+    (metrics/panoptic_tracker_pointgroup_npm3d.py:678-879) on the batches of tests/golden/tracker_metric_cases.npz:
+    (tp, fp, acc) and (cov, wcov, mPrecision, mRecall, F1), through pp_instance_iou, pp_histogram2d and pp_pair_counts."""
+    import types
+    from panopticsegforlargescalepointcloud_amd.panoptic.metrics import compute_acc, compute_eval
+    z = np.load(os.path.join(GOLD, "tracker_metric_cases.npz"))
+    for name in z["names"].tolist():
+        off = z["cl_offsets_" + name]
+        pts = dev(z["cl_points_" + name].astype(np.int64))
+        clusters = [pts[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        labels = types.SimpleNamespace(instance_labels=dev(z["inst_" + name].astype(np.int64)), y=dev(z["y_" + name].astype(np.int64)),
+                                       num_instances=dev(z["num_instances_" + name].astype(np.int64)))
+        batch, pred = dev(z["batch_" + name].astype(np.int64)), dev(z["pred_" + name].astype(np.int64))
+        acc = compute_acc(clusters, pred, labels, batch, labels.num_instances, 0.5)
+        np.testing.assert_allclose(np.asarray([float(v) for v in acc]), z["acc_" + name], rtol=1e-6, atol=1e-7, err_msg=name)
+        ev = compute_eval(clusters, pred, labels, batch, labels.num_instances, 9, 0.5)
+        np.testing.assert_allclose(np.asarray([float(v) for v in ev]), z["eval_" + name], rtol=1e-5, atol=1e-6, err_msg=name)

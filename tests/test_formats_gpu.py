@@ -96,17 +96,16 @@ def test_ply_to_device_path_to_eval_ply_matches_the_oracle_chain(tmp_path, oracl
     origin = batch["origin_id"].cpu().numpy()
     ov = syn.synthetic_head_outputs(scene, origin, 0.0, np.random.default_rng(21))
     dev_batch = {k: batch[k] for k in ("pos", "coords", "batch", "x")}
+    _, res0, _ = _run(model, dev_batch, ov, dev)
+    # NO score substitution below: the oracle chain paints with its OWN scores and NMS.  A random-init ScorerHead squeezes
+    # every score into a ~1e-3 band where float rounding decides the paint order, so its logits are spread first (same
+    # features, same proposals -- what test_model_gpu.py::test_instance_labels_match_oracle_without_score_substitution does)
+    spread = bf.spread_scorer_head(model.ScorerHead[0], res0.cluster_scores)
+    spread.__enter__()
     labels, res, counts = _run(model, dev_batch, ov, dev)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    asm = sc.SceneAssemblerGPU(n_full, DS.num_classes, dev)
+    spread.__exit__(None, None, None)
     bt = batch["batch"]
-    for t in range(len(cen)):  # block order = tile order; origin ids of the FULL cloud = the voxel's representative point
-        m = bt == t
-        asm.add_block(rep[batch["origin_id"][m]], labels[m], res.semantic_logits[m])
-    asm.finish()
-    sem_full, ins_full = sc.back_project(xyz_d, asm.votes, asm.prediction_count, asm.ins_pre, syn.NPM3D_STUFF, cell=4 * voxel)
-    out_sem = pio.to_eval_ply(raw, sem_full.cpu().numpy(), cls, str(tmp_path / "Semantic_results_forEval"))
-    out_ins = pio.to_eval_ply(raw, ins_full.cpu().numpy(), inst, str(tmp_path / "Instance_results_forEval"))
     # ---- the same chain through the oracle
     wc, wr, _ = oracle.voxelize(raw, voxel)
     assert np.array_equal(rep.cpu().numpy(), wr) and np.array_equal(coords.cpu().numpy(), wc)
@@ -123,11 +122,23 @@ def test_ply_to_device_path_to_eval_ply_matches_the_oracle_chain(tmp_path, oracl
     assert len(got_cl) == len(want["clusters"]) and all(np.array_equal(g, np.sort(w)) for g, w in zip(got_cl, want["clusters"]))
     gaps = [bf.scaled_err("semantic log-probs", res.semantic_logits.cpu().numpy(), want["semantic_logits"]),
             bf.scaled_err("proposal scores", res.cluster_scores.cpu().numpy(), want["cluster_scores"])]
-    # NMS / painting on the SAME scores (a random-init scorer squeezes all scores into a 1e-3 band and proposes every object
-    # twice with nearly the same points: which twin survives is decided by rounding -- test_model_gpu.py / test_forest_gpu.py
-    # compare the labels without this substitution; here the subject is file -> device path -> file)
-    want["cluster_scores"] = res.cluster_scores.cpu().numpy()
+    # NMS / painting with the ORACLE'S OWN scores (spread head, see above).  Points whose label hangs on a comparison closer than
+    # 1e-5 between two overlapping twin proposals are counted, bounded and left unlabelled in BOTH chains
     want_labels = opipe.instance_labels(want, len(host["pos"]), host["batch"])
+    amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(host["pos"]))
+    print("file chain: %d of %d tile points hang on a score near-tie" % (amb.sum(), len(amb)))
+    assert amb.mean() <= 0.05
+    amb_d = torch.from_numpy(amb).to(dev)
+    labels = torch.where(amb_d, torch.full_like(labels, -1), labels)
+    want_labels = np.where(amb, -1, want_labels)
+    asm = sc.SceneAssemblerGPU(n_full, DS.num_classes, dev)
+    for t in range(len(cen)):  # block order = tile order; origin ids of the FULL cloud = the voxel's representative point
+        m = bt == t
+        asm.add_block(rep[batch["origin_id"][m]], labels[m], res.semantic_logits[m])
+    asm.finish()
+    sem_full, ins_full = sc.back_project(xyz_d, asm.votes, asm.prediction_count, asm.ins_pre, syn.NPM3D_STUFF, cell=4 * voxel)
+    out_sem = pio.to_eval_ply(raw, sem_full.cpu().numpy(), cls, str(tmp_path / "Semantic_results_forEval"))
+    out_ins = pio.to_eval_ply(raw, ins_full.cpu().numpy(), inst, str(tmp_path / "Instance_results_forEval"))
     for t in range(len(cen)):
         sel = host["batch"] == t
         assert np.array_equal(bf.canon_partition(labels[bt == t].cpu().numpy()), bf.canon_partition(want_labels[sel]))

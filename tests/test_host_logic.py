@@ -293,6 +293,39 @@ def test_panoptic_evaluation_matches_reference_final_eval():
             np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7, err_msg="%s %s" % (name, mine))
 
 
+TREEINS_KEYS = {"MUCov": "MUCov", "mMUCov": "mMUCov", "MWCov": "MWCov", "mMWCov": "mMWCov", "Precision": "Precision",
+                "mPrecision": "mPrecision", "Recall": "Recall", "mRecall": "mRecall", "F1": "F1_score", "RQ": "RQ", "meanRQ": "meanRQ",
+                "SQ": "SQ", "meanSQ": "meanSQ", "PQ": "PQ", "meanPQ": "meanPQ", "PQStar": "PQ_star", "meanPQStar": "mean_PQ_star",
+                "PQ_things": "PQ_things_", "meanPQ_things": "meanPQ_things_", "meanRQ_things": "meanRQ_things_",
+                "meanSQ_things": "meanSQ_things_", "PQ_stuff": "PQ_stuff_", "meanPQ_stuff": "meanPQ_stuff_",
+                "meanRQ_stuff": "meanRQ_stuff_", "meanSQ_stuff": "meanSQ_stuff_"}
+
+
+def check_treeins_result(z, name, r):
+    """r = panoptic_evaluation_treeins(...) against the reference's log of the same case (nan where the reference logs nan)"""
+    for mine, theirs in (("oAcc", "oAcc"), ("mAcc", "mAcc"), ("IoU", "IoU"), ("mIoU", "mIoU")):
+        np.testing.assert_allclose(np.atleast_1d(np.asarray(r[mine], np.float64)), z["log_%s_Semantic_Segmentation_%s" % (name, theirs)],
+                                   rtol=1e-6, atol=1e-7, err_msg="%s %s" % (name, mine))
+    for section in ("offset", "embed"):
+        for mine, theirs in TREEINS_KEYS.items():
+            want = z["log_%s_%s_Instance_Segmentation_%s" % (name, section, theirs)]
+            got = np.atleast_1d(np.asarray(r[section][mine], np.float64))
+            assert got.shape == want.shape, (name, section, mine, got, want)
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7, equal_nan=True, err_msg="%s %s %s" % (name, section, mine))
+
+
+def test_treeins_evaluation_matches_reference_final_eval():
+    """panoptic_evaluation_treeins vs the numbers the reference's own FOR-instance final_eval logs
+    (datasets/panoptic/treeins.py:99-497; tests/golden/make_golden.py --treeins-eval-only): both instance predictions, incl.
+    the case where the embedding branch finds nothing and the case without stuff instances."""
+    from panopticsegforlargescalepointcloud_amd.panoptic.metrics import panoptic_evaluation_treeins
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "treeins_eval_cases.npz"))
+    for name in z["names"].tolist():
+        r = panoptic_evaluation_treeins(z["pred_sem_" + name], z["pre_emb_" + name], z["pre_off_" + name], z["gt_sem_" + name],
+                                        z["gt_ins_" + name])
+        check_treeins_result(z, name, r)
+
+
 def test_ply_io_and_checkpoint_layout(tmp_path):
     from panopticsegforlargescalepointcloud_amd import io as pio
     gold = os.path.join(os.path.dirname(__file__), "golden")

@@ -399,6 +399,38 @@ def test_inference_switches_do_not_change_results(setup, monkeypatch):
             assert r[-1] == g[-1], name
 
 
+def test_proposal_deduplication_does_not_change_scores(setup):
+    """Eval-time de-duplication of identical proposals (pointgroup3heads.py `dedupe_proposals`: region growing and mean shift
+    often return the SAME point set; one representative per set goes through the ScorerUnet) is a pure saving: a proposal's
+    score depends on its own rows only -- every output row of a convolution is summed in a fixed per-row order whatever else
+    is in the batch, the per-proposal maximum is order-free -- so scores, labels and counts are BIT-identical with it off."""
+    s = setup
+    dev = torch.device("cuda")
+    ov = tuple(torch.from_numpy(a).to(dev) for a in s["override"])
+    model = s["model"]
+    assert model.dedupe_proposals is True
+    labels1, res1, counts1 = s["runner"].run(s["b"], len(s["ids"]), override=ov)
+    sizes = res1.clusters_csr.sizes().cpu().numpy()
+    pts, off = res1.clusters_csr.points.cpu().numpy(), res1.clusters_csr.offsets.cpu().numpy()
+    sets = {}
+    for i in range(len(sizes)):
+        sets.setdefault(pts[off[i]:off[i + 1]].tobytes(), []).append(i)
+    n_dup = sum(len(v) - 1 for v in sets.values())
+    print("%d proposals, %d of them duplicates of an earlier one" % (len(sizes), n_dup))
+    assert n_dup > 0, "no identical proposals in this batch: the test is void"
+    model.dedupe_proposals = False
+    try:
+        labels0, res0, counts0 = s["runner"].run(s["b"], len(s["ids"]), override=ov)
+    finally:
+        model.dedupe_proposals = True
+    assert torch.equal(res0.clusters_csr.points, res1.clusters_csr.points) and torch.equal(res0.clusters_csr.offsets, res1.clusters_csr.offsets)
+    assert torch.equal(res0.cluster_scores, res1.cluster_scores)
+    assert torch.equal(labels0, labels1) and list(counts0) == list(counts1)
+    for group in sets.values():       # identical point sets carry identical scores (what the de-duplication relies on)
+        sc = res0.cluster_scores[torch.tensor(group, device=dev)]
+        assert bool((sc == sc[0]).all())
+
+
 @pytest.mark.parametrize("scorer_type", ["MLP", "encoder"])
 def test_other_scorer_types_match_oracle(setup, scorer_type):
     """scorer_type "MLP" (per-point ScorerMLP + per-proposal maximum) and "encoder" (ScorerEncoder: sparse down path +

@@ -409,3 +409,60 @@ def test_nearest_bruteforce_conventions(oracle):
     assert idx.tolist() == [0, 0, 1, -1] and np.isinf(d2[3])
     idx, _ = oracle.nearest(ref[:0], q)
     assert (idx == -1).all()
+
+
+def test_oracle_matches_minkowskiengine_and_tpk_goldens(oracle):
+    """The pin for the rows DESIGN.md 9 calls "parity unpinned": tests/golden/me_tpk_cases.npz, written by
+    tools/dump_me_tpk_goldens.py on a machine that has MinkowskiEngine / torch-points-kernels (absent from the build
+    container and from /root/reference).  Until that file is committed this test skips -- and the rows stay unpinned."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "me_tpk_cases.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/me_tpk_cases.npz not generated yet (tools/dump_me_tpk_goldens.py needs MinkowskiEngine + tpk)")
+    z = np.load(path)
+
+    def rows_of(coords_out, coords_ref):
+        """row of every coords_out entry inside coords_ref (ME returns outputs in its own order)"""
+        key = {tuple(c): i for i, c in enumerate(coords_ref.tolist())}
+        return np.array([key[tuple(c)] for c in coords_out.tolist()])
+
+    case = 0
+    while "c%d_coords" % case in z:
+        tag = "c%d_" % case
+        coords = z[tag + "coords"]
+        # same level: one-hot kernel k reads 1 + nbr_k(o)
+        want = z[tag + "conv_same_onehot"]
+        perm = rows_of(z[tag + "conv_same_out_coords"], coords)
+        nbr = oracle.kernel_map(coords, coords, 3, 1, 1)
+        got = np.where(nbr >= 0, nbr + 1, 0).astype(np.float32)[:, perm]
+        assert np.array_equal(got, want), "offset order / same-level map differs from MinkowskiEngine (case %d)" % case
+        # stride 2, kernel 3: coordinates and map
+        coarse, _ = oracle.stride_coords(coords, 2)
+        oc = z[tag + "conv_stride2_k3_out_coords"]
+        assert {tuple(c) for c in oc.tolist()} == {tuple(c) for c in coarse.tolist()}
+        perm = rows_of(oc, coarse)
+        down = oracle.kernel_map(coarse, coords, 3, 1, 1)
+        assert np.array_equal(np.where(down >= 0, down + 1, 0).astype(np.float32)[:, perm], z[tag + "conv_stride2_k3_onehot"])
+        # transposed stride 2 back onto the input map (inputs numbered in ME's order of the coarse level)
+        ic = z[tag + "convtr_stride2_k3_in_coords"]
+        me_row_of_coarse = np.empty(len(coarse), np.int64)
+        me_row_of_coarse[rows_of(ic, coarse)] = np.arange(len(ic))
+        up = oracle.kernel_map(coords, coarse, 3, 1, -1)
+        perm = rows_of(z[tag + "convtr_stride2_k3_out_coords"], coords)
+        got = np.where(up >= 0, me_row_of_coarse[np.maximum(up, 0)] + 1, 0).astype(np.float32)[:, perm]
+        assert np.array_equal(got, z[tag + "convtr_stride2_k3_onehot"])
+        # a whole random layer
+        y = oracle.spconv_fwd(z[tag + "conv_random_in"], z[tag + "conv_random_w"], nbr, len(coords))
+        perm = rows_of(z[tag + "conv_random_out_coords"], coords)
+        np.testing.assert_allclose(y[perm], z[tag + "conv_random_out"], rtol=1e-4, atol=1e-5)
+        case += 1
+    assert case > 0
+    case = 0
+    while "rg%d_pos" % case in z:
+        tag = "rg%d_" % case
+        nsample, radius, mcs = z[tag + "params"]
+        got, _ = oracle.region_grow(z[tag + "pos"], z[tag + "labels"], z[tag + "batch"], [0], nsample=int(nsample), radius=float(radius),
+                                    min_cluster_size=int(mcs))
+        off, pts = z[tag + "offsets"], z[tag + "points"]
+        want = [np.sort(pts[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+        assert len(got) == len(want) and all(np.array_equal(np.sort(g), w) for g, w in zip(got, want)), "region_grow case %d" % case
+        case += 1

@@ -21,18 +21,32 @@ def test_scene_labels_and_pq_match_oracle():
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     opt = {"cluster_radius_search": cfg.cluster_radius_search, "cluster_type": cfg.cluster_type, "bandwidth": cfg.bandwidth}
     asm_gpu, asm_cpu = SceneAssembler(len(scene.pos), 9), SceneAssembler(len(scene.pos), 9)
+    import bruteforce as bf
+    n_amb = n_pts = 0
     for t in range(len(tiles)):
         b = syn.tile_batch(scene, tiles, [t])
         ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(50 + t))
-        labels, res, _ = runner.run(b, 1, override=tuple(torch.from_numpy(a).to(dev) for a in ov))
-        want = opipe.forward(sd, b, opt, 9, syn.NPM3D_STUFF, override=ov)
-        want["cluster_scores"] = res.cluster_scores.cpu().numpy()  # same scores -> NMS / paint order is deterministic
+        ovd = tuple(torch.from_numpy(a).to(dev) for a in ov)
+        _, res0, _ = runner.run(b, 1, override=ovd)
+        # NO score substitution: the oracle paints with its OWN scores and NMS.  A random-init ScorerHead squeezes all scores
+        # into a ~1e-3 band where rounding decides the paint order, so its logits are spread first (same features, same
+        # proposals); points that still hang on a comparison closer than 1e-5 between overlapping twins are counted and bounded
+        with bf.spread_scorer_head(model.ScorerHead[0], res0.cluster_scores):
+            labels, res, _ = runner.run(b, 1, override=ovd)
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            want = opipe.forward(sd, b, opt, 9, syn.NPM3D_STUFF, override=ov)
+        assert bf.scaled_err("tile %d proposal scores (spread)" % t, res.cluster_scores.cpu().numpy(), want["cluster_scores"]) < 1e-4
         want_labels = opipe.instance_labels(want, len(b["pos"]), b["batch"])
-        # per-tile labels identical after canonicalisation
-        import bruteforce as bf
-        assert np.array_equal(bf.canon_partition(labels.cpu().numpy()), bf.canon_partition(want_labels))
-        asm_gpu.add_block(b["origin_id"], labels.cpu().numpy())
+        amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"]))
+        n_amb, n_pts = n_amb + int(amb.sum()), n_pts + len(amb)
+        got_labels = labels.cpu().numpy()
+        assert np.array_equal(bf.canon_partition(got_labels[~amb]), bf.canon_partition(want_labels[~amb]))
+        # the scene assembly below sees the ambiguous points unlabelled in both chains
+        got_labels, want_labels = np.where(amb, -1, got_labels), np.where(amb, -1, want_labels)
+        asm_gpu.add_block(b["origin_id"], got_labels)
         asm_cpu.add_block(b["origin_id"], want_labels)
+    print("scene: %d of %d tile points hang on a score comparison closer than 1e-5 (left unlabelled in both chains)" % (n_amb, n_pts))
+    assert n_amb <= 0.05 * n_pts
     # block merging is a function of the (canonical) per-tile partitions in block order
     assert np.array_equal(bf.canon_partition(asm_gpu.ins_pre), bf.canon_partition(asm_cpu.ins_pre))
     pq_gpu = thing_panoptic_quality(scene.cls, asm_gpu.ins_pre, scene.cls, scene.inst, syn.THING_CLASSES)
