@@ -223,13 +223,17 @@ def _scaled_err(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max())) if a.size else 0.0
 
 
-def _near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5):
+def _near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5, other_scores=None):
     """points whose instance label hangs on a score comparison closer than eps: two proposals overlapping by more than the NMS
     threshold (region growing and mean shift propose every object twice, with nearly the same points -- their max-pooled
     scorer features, hence scores, agree to the last bits) or a score within eps of the score filter.  Which of such twins
-    survives is decided by float rounding, legitimately differently in two correct implementations."""
+    survives is decided by float rounding, legitimately differently in two correct implementations.
+    other_scores: the second implementation's scores of the same proposals.  A pair whose scores are EXACTLY equal in both
+    (twins whose differing points never attain a channel's maximum: identical pooled features) is not ambiguous -- equal scores
+    are ordered by the same rule (descending index) in both, so their labels must agree and stay in the comparison."""
     amb = np.zeros(n_points, bool)
     scores = np.asarray(scores, np.float64)
+    other = None if other_scores is None else np.asarray(other_scores, np.float64)
     owner = {}
     for i, c in enumerate(clusters):
         for p in np.asarray(c).tolist():
@@ -241,6 +245,8 @@ def _near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, mi
                 inter[(lst[a], lst[b])] = inter.get((lst[a], lst[b]), 0) + 1
     for (i, j), n in inter.items():
         if n / (len(clusters[i]) + len(clusters[j]) - n) > nms_threshold and abs(scores[i] - scores[j]) < eps:
+            if other is not None and scores[i] == scores[j] and other[i] == other[j]:
+                continue
             amb[np.asarray(clusters[i])] = True
             amb[np.asarray(clusters[j])] = True
     for i in np.nonzero(np.abs(scores - min_score) < eps)[0]:
@@ -334,7 +340,8 @@ def self_check(runner, batches, device, oracle_case):
                 want_sp["cluster_scores"] = sp.oracle_scores(want["cluster_features"])
             e_spread = _scaled_err(rg2.cluster_scores.cpu().numpy(), want_sp["cluster_scores"])
             want_labels = opipe.instance_labels(want_sp, len(b["pos"]), b["batch"])
-            amb = _near_tie_points(want_sp["clusters"], want_sp["cluster_scores"], len(b["pos"]))
+            amb = _near_tie_points(want_sp["clusters"], want_sp["cluster_scores"], len(b["pos"]),
+                                   other_scores=rg2.cluster_scores.cpu().numpy())
             ok_inst = bool(np.array_equal(_canonical(lg.cpu().numpy()[~amb]), _canonical(want_labels[~amb]))) \
                 and e_spread < 1e-4 and amb.mean() <= NEAR_TIE_BOUND
         checks["oracle"] = "pass" if (ok_prop and ok_score and ok_feat and ok_inst) else \

@@ -52,7 +52,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // and rebuilds the descriptor every step: ~25 scalar instructions per step that the 16-channel layers -- 16 MFMAs per step
 // at most -- do not hide).
 template <int NTW, int T, bool BF16, int D, bool C4 = false, bool DS = false, bool S1 = false>
-__global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes) {
+__global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
   const int lane = threadIdx.x & 63;
@@ -64,6 +64,10 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
   const int jt0 = blockIdx.y * NTW;
   unsigned(*off)[R] = s_off[wave];
   const unsigned row_bytes = (unsigned)a.c0 * 4u;
+  // row * row_bytes: v_mul_lo_u32 runs at a quarter of the vector rate (on the pipe the fp32 MFMAs share); the 24-bit form
+  // is full rate and exact while the input has fewer than 2^24 rows (flags bit 0, set by the launcher)
+  const bool m24 = (flags & 1u) != 0u;
+#define F3_ROWOFF(R_) (m24 ? __umul24((unsigned)(R_), row_bytes) : (unsigned)(R_) * row_bytes)
 
   // ---- prologue: neighbour rows -> byte offsets in LDS, per-tile occupancy masks -> SGPRs
   unsigned m[T];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         const int dx = (cls & 1u) ? ((j & 1) ? 2 : 0) : 1, dy = (cls & 2u) ? ((j & 2) ? 2 : 0) : 1, dz = (cls & 4u) ? ((j & 4) ? 2 : 0) : 1;
         const int k = dx + 3 * dy + 9 * dz;
         if (ok) {
-          if (kh == 0) off[k][rr] = ((unsigned)e8[j] & PP_ROW_MASK) * row_bytes;
+          if (kh == 0) off[k][rr] = F3_ROWOFF((unsigned)e8[j] & PP_ROW_MASK);
           mk |= 1u << k;
         }
       }
@@ -116,11 +120,21 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
       for (int tt = 0; tt < T; ++tt) m[tt] = (unsigned)__builtin_amdgcn_readlane((int)mk, tt * 16);
     } else {
     if (a.nbr) {
+      // buffer loads: per-lane 32-bit offset (row and this lane's half of the offsets) + a scalar offset per kk -- no 64-bit
+      // vector address arithmetic in front of the 14 / 28 loads (flags bit 1: the map is smaller than 4 GiB, else plain loads)
+      if (flags & 2u) {
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nbr, 0, (int)((unsigned)a.K * (unsigned)a.n_out * 4u), 0x00020000);
+        const unsigned vrow = ((unsigned)rowc + (unsigned)(NL * kh) * (unsigned)a.n_out) * 4u;
+        const unsigned kstep = (unsigned)a.n_out * 4u;
 #pragma unroll
-      for (int kk = 0; kk < NL; ++kk) {
-        const int k = kk + NL * kh;
-        const int kc = k < a.K ? k : a.K - 1;
-        v[kk] = a.nbr[(int64_t)kc * a.n_out + rowc];
+        for (int kk = 0; kk < NL; ++kk) v[kk] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)vrow, (int)(kk * kstep), 0);  // beyond K: zeros, masked below
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < NL; ++kk) {
+          const int k = kk + NL * kh;
+          const int kc = k < a.K ? k : a.K - 1;
+          v[kk] = a.nbr[(int64_t)kc * a.n_out + rowc];
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk)
@@ -129,11 +143,24 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 #pragma unroll
       for (int kk = 0; kk < NL; ++kk) v[kk] = (rv && kk + NL * kh < a.K) ? (int)row : -1;
     }
+    // (two copies of the loop so that the multiply form is chosen once, not per entry; the product of a missing entry is
+    // computed and discarded by a select -- no branch per offset)
+    if (m24) {
 #pragma unroll
-    for (int kk = 0; kk < NL; ++kk) {
-      const int k = kk + NL * kh;
-      if (k < F2_MAXK) off[k][rr] = v[kk] >= 0 ? (unsigned)v[kk] * row_bytes : F3_MISSING;
-      ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = kk + NL * kh;
+        const unsigned prod = __umul24((unsigned)v[kk], row_bytes);
+        if (k < F2_MAXK) off[k][rr] = v[kk] >= 0 ? prod : F3_MISSING;
+        ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = kk + NL * kh;
+        const unsigned prod = (unsigned)v[kk] * row_bytes;
+        if (k < F2_MAXK) off[k][rr] = v[kk] >= 0 ? prod : F3_MISSING;
+        ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
+      }
     }
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) ml |= (unsigned)__shfl_xor((int)ml, o);
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
       if ((m[tt] >> (KC)) & 1u) {                                                                         \
         const s16x4 ah_ = pp_bf16x4(AX[tt]);                                                              \
         _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                \
-            acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah_, bh_[jt], acc[tt][jt], 0, 0, 0);  \
+            acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh_[jt], ah_, acc[tt][jt], 0, 0, 0);  \
       }                                                                                                   \
     }                                                                                                     \
   } else {                                                                                                \
@@ -239,7 +266,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
       if ((m[tt] >> (KC)) & 1u) {                                                                         \
         _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                \
             _Pragma("unroll") for (int t = 0; t < (C4 ? 1 : 4); ++t)                                      \
-                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AX[tt][t], BX[jt][t], acc[tt][jt], 0, 0, 0); \
+                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(BX[jt][t], AX[tt][t], acc[tt][jt], 0, 0, 0); \
       }                                                                                                   \
     }                                                                                                     \
   }
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
           const s16x4 ah = pp_bf16x4(A2[tt]);
 #pragma unroll
           for (int jt = 0; jt < NTW; ++jt)
-            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pp_bf16x4(B2[jt]), acc2[tt][jt], 0, 0, 0);
+            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pp_bf16x4(B2[jt]), ah, acc2[tt][jt], 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -373,52 +400,58 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
           for (int jt = 0; jt < NTW; ++jt)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[tt][t], B2[jt][t], acc2[tt][jt], 0, 0, 0);
+              acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(B2[jt][t], A2[tt][t], acc2[tt][jt], 0, 0, 0);
       }
     }
   }
 
-  if (a.split > 1) {  // raw partial sums; the epilogue runs in k_spconv_split_reduce
-    float* __restrict__ part = a.part + (int64_t)blockIdx.z * a.n_out * a.cout;
+  // ---- epilogue.  The MFMAs above compute out^T = W^T in^T (the weight fragment as the A operand, the gathered rows as B --
+  // the same registers, products commute, the k order of every sum is unchanged: bit-identical to in W), so lane (j, q) holds
+  // out[row j of the tile][16 jt + 4 q .. + 3]: 16 contiguous bytes.  One 16-byte store (and residual load) per (tile, column
+  // tile) and ONE row address per tile, instead of four 4-byte accesses with an address each: the 16-channel layers spent a
+  // tenth of their vector-ALU time -- the pipe the fp32 MFMAs run on -- in this part.
+  const bool vec = (a.cout & 3) == 0;
+  float* __restrict__ dst = a.split > 1 ? a.part + (int64_t)blockIdx.z * a.n_out * a.cout : a.out;
 #pragma unroll
-    for (int jt = 0; jt < NTW; ++jt) {
-      const int col = (jt0 + jt) * 16 + i;
-      if (jt0 + jt < a.NT && col < a.cout) {
+  for (int rt = 0; rt < T; ++rt) {
+    const int64_t slot = row_base + rt * 16 + i;
+    if (slot < a.n_out) {
+      const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
+      const int64_t e0 = row * a.cout + (jt0 * 16 + q * 4);
 #pragma unroll
-        for (int rt = 0; rt < T; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t slot = row_base + rt * 16 + q * 4 + r;
-            if (slot < a.n_out) {
-              const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
-              part[row * a.cout + col] = acc[rt][jt][r];
-            }
+      for (int jt = 0; jt < NTW; ++jt) {
+        const int col = (jt0 + jt) * 16 + q * 4;
+        if (jt0 + jt < a.NT && col < a.cout) {
+          f32x4 v = acc[rt][jt];
+          if (a.split > 1) {  // raw partial sums; scale / shift / ReLU / residual are applied by k_spconv_split_reduce
+            if (vec) *(f32x4*)(dst + e0 + jt * 16) = v;
+            else
+              for (int r = 0; r < 4; ++r)
+                if (col + r < a.cout) dst[e0 + jt * 16 + r] = v[r];
+            continue;
           }
-      }
-    }
-    return;
-  }
-  // epilogue: lane (col = i, row group = q) holds rows 4q+r of each 16-row tile
-#pragma unroll
-  for (int jt = 0; jt < NTW; ++jt) {
-    const int col = (jt0 + jt) * 16 + i;
-    if (jt0 + jt < a.NT && col < a.cout) {
-      const float sc = a.scale ? a.scale[col] : 1.f;
-      const float sh = a.shift ? a.shift[col] : 0.f;
-      const float sc2 = DS && a.ds_scale ? a.ds_scale[col] : 1.f;
-      const float sh2 = DS && a.ds_shift ? a.ds_shift[col] : 0.f;
-#pragma unroll
-      for (int rt = 0; rt < T; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t slot = row_base + rt * 16 + q * 4 + r;
-          if (slot < a.n_out) {
-            const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
-            float v = acc[rt][jt][r] * sc + sh;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.residual) v += a.residual[row * a.cout + col];
-            if constexpr (DS) v += acc2[rt][jt][r] * sc2 + sh2;
-            a.out[row * a.cout + col] = v;
+          if (vec) {
+            if (a.scale) v *= *(const f32x4*)(a.scale + col);
+            if (a.shift) v += *(const f32x4*)(a.shift + col);
+            if (a.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            if (a.residual) v += *(const f32x4*)(a.residual + e0 + jt * 16);
+            if constexpr (DS) {
+              f32x4 w = acc2[rt][jt];
+              if (a.ds_scale) w *= *(const f32x4*)(a.ds_scale + col);
+              if (a.ds_shift) w += *(const f32x4*)(a.ds_shift + col);
+              v += w;
+            }
+            *(f32x4*)(dst + e0 + jt * 16) = v;
+          } else {  // output widths that are not a multiple of 4 (none of the published networks): element by element
+            for (int r = 0; r < 4; ++r) {
+              if (col + r >= a.cout) break;
+              float x = v[r] * (a.scale ? a.scale[col + r] : 1.f) + (a.shift ? a.shift[col + r] : 0.f);
+              if (a.relu) x = fmaxf(x, 0.f);
+              if (a.residual) x += a.residual[e0 + jt * 16 + r];
+              if constexpr (DS)
+                x += acc2[rt][jt][r] * (a.ds_scale ? a.ds_scale[col + r] : 1.f) + (a.ds_shift ? a.ds_shift[col + r] : 0.f);
+              dst[e0 + jt * 16 + r] = x;
+            }
           }
         }
       }
@@ -427,22 +460,22 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 }
 
 template <int T, bool BF16>
-static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, hipStream_t s) {
+static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, unsigned a_bytes, unsigned w_bytes, unsigned flags, hipStream_t s) {
   dim3 grid(pp_blocks(a.n_out, 16 * T * F3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
   const bool s1 = a.c0 == 16 && a.c1 == 0;
   if (a.ds_in) {  // fused shortcut: the per-shape loop variant only (3 for <= 2 column tiles, 1 otherwise)
     if (s1 && ntw <= 2) {
-      if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
-      else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+      if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+      else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
       return PP_OK;
     }
     switch (ntw) {
-      case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-      case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-      case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-      case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-      case 5: hipLaunchKernelGGL((k_spconv_fwd3<5, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-      case 6: hipLaunchKernelGGL((k_spconv_fwd3<6, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+      case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 5: hipLaunchKernelGGL((k_spconv_fwd3<5, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 6: hipLaunchKernelGGL((k_spconv_fwd3<6, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
       default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
     }
     return PP_OK;
@@ -450,10 +483,10 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
   if constexpr (!BF16) {
     if (a.c0 == 4) {  // the input layer: one column-tile count per launch is enough (cout = 16 in every published model)
       switch (ntw) {
-        case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-        case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-        case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
-        case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+        case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, false, 3, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
         default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
       }
       return PP_OK;
@@ -463,12 +496,12 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
   // before the MFMAs of the current step -- pays on launches with <= 2 column tiles per wave (16->16 at 2.5 M rows:
   // 374 -> 343 us), nothing on wider ones
   if (s1 && depth == 3 && ntw <= 2) {
-    if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
-    else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes);
+    if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+    else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
     return PP_OK;
   }
 #define F3_CASE(N, D) \
-  case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes); break;
+  case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
   switch (10 * depth + ntw) {
     F3_CASE(1, 1) F3_CASE(2, 1) F3_CASE(3, 1) F3_CASE(4, 1) F3_CASE(5, 1) F3_CASE(6, 1)
     F3_CASE(1, 3) F3_CASE(2, 3) F3_CASE(3, 3) F3_CASE(4, 3)
@@ -510,13 +543,16 @@ int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned g
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = a.c0 == 4 ? (unsigned)((uint64_t)a.K * a.NT * 256u)
                                      : (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
+  // bit 0: fewer than 2^24 input rows (24-bit multiplies); bit 1: the dense map fits 32-bit byte offsets (buffer loads)
+  const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u) |
+                         (!a.t8 && a.nbr && (double)a.K * (double)a.n_out * 4.0 < 4294967000.0 ? 2u : 0u);
   if (T != 2 && T != 4) {
     pp_set_error("pp_spconv_fwd3: rows per wave must be 32 or 64");
     return PP_ERR_INVALID;
   }
   if (a.bf16)
-    return T == 4 ? launch3_t<4, true>(a, ntw, depth, groups, a_bytes, w_bytes, s)
-                  : launch3_t<2, true>(a, ntw, depth, groups, a_bytes, w_bytes, s);
-  return T == 4 ? launch3_t<4, false>(a, ntw, depth, groups, a_bytes, w_bytes, s)
-                : launch3_t<2, false>(a, ntw, depth, groups, a_bytes, w_bytes, s);
+    return T == 4 ? launch3_t<4, true>(a, ntw, depth, groups, a_bytes, w_bytes, flags, s)
+                  : launch3_t<2, true>(a, ntw, depth, groups, a_bytes, w_bytes, flags, s);
+  return T == 4 ? launch3_t<4, false>(a, ntw, depth, groups, a_bytes, w_bytes, flags, s)
+                : launch3_t<2, false>(a, ntw, depth, groups, a_bytes, w_bytes, flags, s);
 }

@@ -146,13 +146,16 @@ class spread_scorer_head:
         return False
 
 
-def near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5):
+def near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min_score=0.5, other_scores=None):
     """Points whose instance label is decided by a score comparison closer than `eps`: two overlapping proposals
     (IoU > nms_threshold; region growing and mean shift often return NEARLY the same point set for one object, whose
     max-pooled scorer features -- hence scores -- then agree to the last bits whatever the scorer head's scale) with
     |score_i - score_j| < eps, or a score within eps of the `min_score` filter.  Which of such a pair survives the NMS is
-    decided by float rounding, legitimately differently in two correct implementations; everything else must agree."""
+    decided by float rounding, legitimately differently in two correct implementations; everything else must agree.
+    other_scores: the second implementation's scores; a pair that is EXACTLY tied in both is ordered by the same rule in both
+    (descending index) and stays in the comparison."""
     amb = np.zeros(n_points, bool)
+    other = None if other_scores is None else np.asarray(other_scores, np.float64)
     if not clusters:
         return amb
     scores = np.asarray(scores, np.float64)
@@ -168,6 +171,8 @@ def near_tie_points(clusters, scores, n_points, nms_threshold=0.3, eps=1e-5, min
     for (i, j), inter in pairs.items():
         iou = inter / (len(clusters[i]) + len(clusters[j]) - inter)
         if iou > nms_threshold and abs(scores[i] - scores[j]) < eps:
+            if other is not None and scores[i] == scores[j] and other[i] == other[j]:
+                continue
             amb[np.asarray(clusters[i])] = True
             amb[np.asarray(clusters[j])] = True
     for i in np.nonzero(np.abs(scores - min_score) < eps)[0]:

@@ -169,15 +169,16 @@ def test_packed_weight_cache_follows_a_storage_swap():
     cache.get(q, False, False)
     assert torch.equal(a0, ops.pack_weight(p))
     new = torch.randn(27, 16, 32, device=dev)
+    new0 = new.clone()                # (p shares `new`'s storage from here on)
     v = p._version
     p.data = new                      # same version, new storage
     assert p._version == v
     a1 = cache.get(p, False, False)
-    assert torch.equal(a1, ops.pack_weight(new)) and not torch.equal(a1, a0)
+    assert torch.equal(a1, ops.pack_weight(new0)) and not torch.equal(a1, a0)
     assert torch.equal(cache.get(q, False, False), ops.pack_weight(q))      # the other entry was re-packed from ITS storage
     with torch.no_grad():
         p.mul_(2.0)                   # in-place: version bump, same storage
-    assert torch.equal(cache.get(p, False, False), ops.pack_weight(new * 2.0))
+    assert torch.equal(cache.get(p, False, False), ops.pack_weight(new0 * 2.0))
 
 
 def test_resblock_with_a_frozen_second_batchnorm_counts_the_first_once():

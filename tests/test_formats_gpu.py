@@ -125,7 +125,7 @@ def test_ply_to_device_path_to_eval_ply_matches_the_oracle_chain(tmp_path, oracl
     # NMS / painting with the ORACLE'S OWN scores (spread head, see above).  Points whose label hangs on a comparison closer than
     # 1e-5 between two overlapping twin proposals are counted, bounded and left unlabelled in BOTH chains
     want_labels = opipe.instance_labels(want, len(host["pos"]), host["batch"])
-    amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(host["pos"]))
+    amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(host["pos"]), other_scores=res.cluster_scores.cpu().numpy())
     print("file chain: %d of %d tile points hang on a score near-tie" % (amb.sum(), len(amb)))
     assert amb.mean() <= 0.05
     amb_d = torch.from_numpy(amb).to(dev)

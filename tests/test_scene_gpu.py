@@ -37,7 +37,7 @@ def test_scene_labels_and_pq_match_oracle():
             want = opipe.forward(sd, b, opt, 9, syn.NPM3D_STUFF, override=ov)
         assert bf.scaled_err("tile %d proposal scores (spread)" % t, res.cluster_scores.cpu().numpy(), want["cluster_scores"]) < 1e-4
         want_labels = opipe.instance_labels(want, len(b["pos"]), b["batch"])
-        amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"]))
+        amb = bf.near_tie_points(want["clusters"], want["cluster_scores"], len(b["pos"]), other_scores=res.cluster_scores.cpu().numpy())
         n_amb, n_pts = n_amb + int(amb.sum()), n_pts + len(amb)
         got_labels = labels.cpu().numpy()
         assert np.array_equal(bf.canon_partition(got_labels[~amb]), bf.canon_partition(want_labels[~amb]))
