@@ -47,6 +47,8 @@ MAP_PREFETCH = os.environ.get("PP_MAP_PREFETCH", "1") != "0"
 # inference: the map of a stride-2 transposed convolution in its 8-wide form (a fine row has <= 8 coarse neighbours, fixed by
 # its parity class): 32 instead of 108 bytes per row through transpose, mask, sort, permute and the convolution's prologue
 MAP_T8 = os.environ.get("PP_MAP_T8", "1") != "0"
+# strided maps are slot-ordered when the fine level has fewer than this many rows per coarse row (0 = never; A/B runs)
+STRIDED_ORDER_RATIO = float(os.environ.get("PP_STRIDED_ORDER_RATIO", "1.7"))
 _SIDE_STREAMS = {}
 
 
@@ -401,6 +403,12 @@ class CoordinateManager:
                     # transposed maps built by lookup are slot-ordered like the scattered ones; strided maps are not: their
                     # convolutions gain 8 % from it (152 vs 165 us at 1.3 M rows), less than the sort + permute cost
                     ordered = MAP_ORDER and ts_from > ts_to and dst.n >= MAP_ORDER_MIN_ROWS
+                    # ... except "dust": a coarse level with nearly as many rows as its fine level (the proposal scorer's
+                    # levels: 5.3 M -> 4.9 M -> 3.3 M rows) has 1.5 - 3.6 pairs per row, i.e. one or two of 27 offsets per row --
+                    # unordered, a 16-row tile then walks ~15 offsets for ~20 pairs; ordered by mask its rows share theirs
+                    if (MAP_ORDER and not ordered and ts_from < ts_to and dst.n >= MAP_ORDER_MIN_ROWS
+                            and src.n < STRIDED_ORDER_RATIO * dst.n):
+                        ordered = True
                     if ordered:
                         m = ops.kernel_map_bi(dst.coords, src.index, ksize, min(ts_from, ts_to), sign, want_mask=True)
                         order = ops.map_order(m.pp_mask)

@@ -290,7 +290,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
   PP_REQUIRE((c0 + c1) % 4 == 0, "pp_spconv_fwd: cin must be a multiple of 4");
   PP_REQUIRE(rows_per_wave == 0 || rows_per_wave == 32 || rows_per_wave == 64, "pp_spconv_fwd_ex: rows_per_wave in {0, 32, 64}");
-  PP_REQUIRE(pipeline == 0 || pipeline == 1 || pipeline == 3, "pp_spconv_fwd_ex: pipeline in {0, 1, 3}");
+  PP_REQUIRE(pipeline == 0 || pipeline == 1 || pipeline == 3 || pipeline == 5, "pp_spconv_fwd_ex: pipeline in {0, 1, 3, 5}");
   PP_REQUIRE(split_k == 0 || split_k == 1 || split_k == 2 || split_k == 4 || split_k == 8, "pp_spconv_fwd_ex: split_k in {0, 1, 2, 4, 8}");
   const bool mode16 = ((c0 + c1) % 16 == 0);
   if (mode16) PP_REQUIRE(c0 % 16 == 0, "pp_spconv_fwd: with cin % 16 == 0 both sources must be multiples of 16");
@@ -320,7 +320,16 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     // work, which 64 rows halve per row -- 32 on wider ones (the extra accumulators cost occupancy: 48->48 660 vs 690 us)
     // and on smaller ones (halving the number of waves costs more: one rank's share at 8 GPUs 34.1 vs 34.6 ms)
     const int T = rows_per_wave ? rows_per_wave / 16 : (ntw <= 2 && n_out >= 2000000 ? 4 : 2);
-    const int depth = pipeline ? pipeline : (ntw <= 2 ? 3 : 1);
+    // loop form: 3 (one step of loads in flight, load side advanced early) on <= 2 column tiles; 5 = the depth-3 register ring
+    // (two steps in flight, inline-asm loads with hand-counted waits) on same-level / strided launches with 3 - 4 column tiles
+    // per wave: 48->48 1.90 -> 1.79 ms, 64->64 1.02 -> 0.97, 128->48 4.97 -> 4.73, 80->80 0.48 -> 0.42; the <= 32-channel
+    // layers LOSE 3 - 7 % with it (they are bound by the texture path's gather rate, not by latency) and so do the transposed
+    // launches (profiles/r04_ab_ring.txt).  PP_CONV_RING=0 / 1: never / wherever it is instantiated (A/B runs).
+    static const int env_ring = getenv("PP_CONV_RING") ? atoi(getenv("PP_CONV_RING")) : -1;
+    int depth = pipeline ? pipeline : (ntw <= 2 ? 3 : 1);
+    if (!pipeline && !c4 && ntw <= 4) {
+      if (env_ring == 1 || (env_ring < 0 && ntw >= 3 && !row_order)) depth = 5;
+    }
     // small launches (fewer waves than SIMD slots) are bound by the latency of one wave's walk over the 27 offsets:
     // split the offsets over up to 8 waves and add the partials in a fixed order (deterministic)
     const int64_t waves = ((n_out + 16 * T - 1) / (16 * T)) * groups;

@@ -33,6 +33,16 @@
 // ---------------------------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F3_MISSING 0xFFFFFFFFu
+
+// OR of a value over the 16 lanes of every row (a 16-row MFMA tile): four DPP rotations inside the row instead of four
+// ds_bpermute round trips through the LDS crossbar (each with its own wait)
+__device__ __forceinline__ unsigned pp_row_or16(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);  // row_ror:2
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);  // row_ror:1
+  return v;
+}
 // F3_ABLATE (profiling builds only, profiles/ablate_conv.sh): 1 = no step loop (prologue + epilogue), 2 = loads but no
 // MFMAs, 3 = no feature gathers, 4 = no weight loads.  Results are wrong by construction; never defined in the product.
 #ifndef F3_ABLATE
@@ -93,8 +103,15 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
       // Every (k, row) slot is filled with MISSING first (each lane its own half of the offsets, as below), then one lane
       // per row overwrites the <= 8 real ones; LDS operations of a wave execute in program order.
       int e8[8];
+      if (flags & 4u) {  // the 8-wide map fits 32-bit byte offsets: buffer loads, one scalar offset per entry
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)a.nbr, 0, (int)(8u * (unsigned)a.n_out * 4u), 0x00020000);
+        const unsigned kstep = (unsigned)a.n_out * 4u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + rowc];
+        for (int j = 0; j < 8; ++j) e8[j] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)((unsigned)rowc * 4u), (int)(j * kstep), 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + rowc];
+      }
       unsigned cls = 0;  // every entry of the row carries the row's parity class in bits 28..30
 #pragma unroll
       for (int j = 0; j < 8; ++j) cls |= e8[j] >= 0 ? (unsigned)e8[j] >> 28 : 0u;
@@ -104,18 +121,19 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         if (k < F2_MAXK) off[k][rr] = F3_MISSING;
       }
       unsigned mk = 0;
+      // (class, j) -> offset index: per axis 1 when the row is even there, else 0 / 2 by the entry's bit.  Entries that do not
+      // exist (or belong to the other lane half) are written to the spare row 27 of the table: no branch per entry
+      const unsigned kx = (cls & 1u) ? 0u : 1u, ky = (cls & 2u) ? 0u : 3u, kz = (cls & 4u) ? 0u : 9u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const bool ok = rv && (((unsigned)j & ~cls) == 0u) && e8[j] >= 0;
-        const int dx = (cls & 1u) ? ((j & 1) ? 2 : 0) : 1, dy = (cls & 2u) ? ((j & 2) ? 2 : 0) : 1, dz = (cls & 4u) ? ((j & 4) ? 2 : 0) : 1;
-        const int k = dx + 3 * dy + 9 * dz;
-        if (ok) {
-          if (kh == 0) off[k][rr] = F3_ROWOFF((unsigned)e8[j] & PP_ROW_MASK);
-          mk |= 1u << k;
-        }
+        const unsigned k = kx + ((j & 1) ? 2u : 0u) * (cls & 1u) + ky + ((j & 2) ? 6u : 0u) * ((cls >> 1) & 1u) + kz +
+                           ((j & 4) ? 18u : 0u) * ((cls >> 2) & 1u);
+        const unsigned prod = m24 ? __umul24((unsigned)e8[j] & PP_ROW_MASK, row_bytes) : ((unsigned)e8[j] & PP_ROW_MASK) * row_bytes;
+        off[(ok && kh == 0) ? k : 27u][rr] = (ok && kh == 0) ? prod : F3_MISSING;
+        mk |= ok ? 1u << k : 0u;
       }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mk |= (unsigned)__shfl_xor((int)mk, o);
+      mk = pp_row_or16(mk);
 #pragma unroll
       for (int tt = 0; tt < T; ++tt) m[tt] = (unsigned)__builtin_amdgcn_readlane((int)mk, tt * 16);
     } else {
@@ -162,8 +180,7 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
       }
     }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) ml |= (unsigned)__shfl_xor((int)ml, o);
+    ml = pp_row_or16(ml);
 #pragma unroll
     for (int tt = 0; tt < T; ++tt) {
       m[tt] = 0;
@@ -352,6 +369,83 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         F3_MFMAS(A1, B1, k1);
         if (!e0) break;
       }
+    } else if constexpr (D == 5) {
+      // ---- register ring of depth 3: the operand loads of step n + 2 are issued before the MFMAs of step n.
+      // PMC on the depth-1 loop (profiles/r02_pmc_c16_s1.md): a wave spends 36 % of its life in s_waitcnt -- a step's loads
+      // are waited for one step (~1300 cycles incl. the other waves' MFMAs) after their issue, and a gathered row takes
+      // ~2000 cycles to arrive while the texture path is busy.  hipcc's own three-set pipelines (round 2) needed 117 - 171
+      // VGPRs and lost the gain to occupancy; here the loads are inline assembly with hand-counted waits (vmcnt is in issue
+      // order: every step issues exactly T + NTW loads, so "at most 2 (T + NTW) outstanding" = the oldest step has landed) and
+      // the three register sets cost exactly 3 (T + NTW) x 4 VGPRs.  hipcc does not count asm loads: no wait of its own is
+      // emitted for them, and nothing else in the loop is a vector memory operation.
+      static_assert(!C4, "the ring loop serves the 16-channel-step layers");
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      const unsigned long long pw_ = (unsigned long long)a.wp;
+      const u32x4_t dw_ = {(unsigned)pw_, (unsigned)(pw_ >> 32) & 0xFFFFu, w_bytes, 0x00020000u};
+      unsigned vw[NTW];
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) vw[jt] = lane16 + (unsigned)jt * WT;
+      f32x4 A2[T], B2[NTW];
+#define R_LOADS(AX, BX)                                                                                              \
+  {                                                                                                                  \
+    const float* src_ = sl < S0 ? a.in0 + sl * 16 : a.in1 + (sl - S0) * 16;                                          \
+    const unsigned long long pa_ = (unsigned long long)src_;                                                         \
+    const u32x4_t da_ = {(unsigned)pa_, (unsigned)(pa_ >> 32) & 0xFFFFu, a_bytes, 0x00020000u};                      \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                                 \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(AX[tt]) : "v"(vo[tt]), "s"(da_));              \
+    const unsigned wso_ = (unsigned)(kl * S + sl) * w_step + w_jt0;                                                  \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                               \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(BX[jt]) : "v"(vw[jt]), "s"(dw_), "s"(wso_)); \
+  }
+      // the step the load side names goes into (AX, BX); KV = its offset, EV = whether it is a real step (after the last one
+      // the load side keeps naming a valid address and the loads are simply repeated: the counts stay exact)
+#define R_STAGE(AX, BX, KV, EV)      \
+  {                                  \
+    R_LOADS(AX, BX);                 \
+    KV = kl;                         \
+    EV = nx;                         \
+    if (nx) { F3_ADVANCE(nx); }      \
+  }
+      // wait until the two youngest steps are the only loads in flight; the operands are named so that no MFMA moves above
+#define R_WAIT(AX, BX)                                                                                               \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(2 * (T + NTW)));                                                       \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) asm volatile("" : "+v"(AX[tt]));                               \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) asm volatile("" : "+v"(BX[jt]));                             \
+  }
+      int nx = 1, k0 = 0, k1 = 0, k2 = 0, e0 = 0, e1 = 0, e2 = 0;
+      R_STAGE(A0, B0, k0, e0);
+      R_STAGE(A1, B1, k1, e1);
+      // ONE loop exit (three exits make hipcc keep the accumulators in different registers per exit and reconcile them with
+      // 16-register copies around every tile branch: 152 VGPRs): steps behind the last real one run with an empty tile mask
+#define R_MFMAS(AX, BX, KC, EV)                                  \
+  {                                                              \
+    unsigned mk_[T];                                             \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) mk_[tt] = m[tt]; \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) m[tt] = EV ? m[tt] : 0u; \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt)             \
+        _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) asm volatile("" : "+v"(acc[tt][jt])); \
+    F3_MFMAS(AX, BX, KC);                                        \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) m[tt] = mk_[tt]; \
+  }
+      for (;;) {
+        R_STAGE(A2, B2, k2, e2);
+        R_WAIT(A0, B0);
+        R_MFMAS(A0, B0, k0, e0);
+        R_STAGE(A0, B0, k0, e0);
+        R_WAIT(A1, B1);
+        R_MFMAS(A1, B1, k1, e1);
+        R_STAGE(A1, B1, k1, e1);
+        R_WAIT(A2, B2);
+        R_MFMAS(A2, B2, k2, e2);
+        if (!e0) break;
+      }
+#undef R_MFMAS
+      asm volatile("s_waitcnt vmcnt(0)");  // the repeated loads behind the last step: their registers die here
+      (void)more;
+#undef R_LOADS
+#undef R_STAGE
+#undef R_WAIT
     }
 #undef F3_LOADS
 #undef F3_ADVANCE
@@ -472,8 +566,14 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
     switch (ntw) {
       case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
       case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
-      case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
-      case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+      case 3:
+        if (depth == 5) hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 5, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+        else hipLaunchKernelGGL((k_spconv_fwd3<3, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+        break;
+      case 4:
+        if (depth == 5) hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 5, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+        else hipLaunchKernelGGL((k_spconv_fwd3<4, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
+        break;
       case 5: hipLaunchKernelGGL((k_spconv_fwd3<5, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
       case 6: hipLaunchKernelGGL((k_spconv_fwd3<6, T, BF16, 1, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
       default: pp_set_error("pp_spconv_fwd3: ntw %d out of range", ntw); return PP_ERR_INVALID;
@@ -495,7 +595,7 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
   // depth: 1 = one step in flight; 3 = one step in flight with the load side advanced (LDS read of the next offsets)
   // before the MFMAs of the current step -- pays on launches with <= 2 column tiles per wave (16->16 at 2.5 M rows:
   // 374 -> 343 us), nothing on wider ones
-  if (s1 && depth == 3 && ntw <= 2) {
+  if (s1 && depth == 3 && ntw <= 2 && !a.ds_in) {
     if (ntw == 1) hipLaunchKernelGGL((k_spconv_fwd3<1, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
     else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
     return PP_OK;
@@ -505,6 +605,7 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
   switch (10 * depth + ntw) {
     F3_CASE(1, 1) F3_CASE(2, 1) F3_CASE(3, 1) F3_CASE(4, 1) F3_CASE(5, 1) F3_CASE(6, 1)
     F3_CASE(1, 3) F3_CASE(2, 3) F3_CASE(3, 3) F3_CASE(4, 3)
+    F3_CASE(1, 5) F3_CASE(2, 5) F3_CASE(3, 5) F3_CASE(4, 5)
     default: pp_set_error("pp_spconv_fwd3: ntw %d / depth %d out of range", ntw, depth); return PP_ERR_INVALID;
   }
 #undef F3_CASE
@@ -543,9 +644,10 @@ int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned g
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = a.c0 == 4 ? (unsigned)((uint64_t)a.K * a.NT * 256u)
                                      : (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
-  // bit 0: fewer than 2^24 input rows (24-bit multiplies); bit 1: the dense map fits 32-bit byte offsets (buffer loads)
+  // bit 0: fewer than 2^24 input rows (24-bit multiplies); bit 1 / 2: the dense / 8-wide map fits 32-bit byte offsets (buffer loads)
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u) |
-                         (!a.t8 && a.nbr && (double)a.K * (double)a.n_out * 4.0 < 4294967000.0 ? 2u : 0u);
+                         (!a.t8 && a.nbr && (double)a.K * (double)a.n_out * 4.0 < 4294967000.0 ? 2u : 0u) |
+                         (a.t8 && (double)a.n_out * 32.0 < 4294967000.0 ? 4u : 0u);
   if (T != 2 && T != 4) {
     pp_set_error("pp_spconv_fwd3: rows per wave must be 32 or 64");
     return PP_ERR_INVALID;

@@ -831,10 +831,10 @@ VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 
 
 @pytest.mark.parametrize("kind,c0,c1,cout", VARIANT_SHAPES)
 @pytest.mark.parametrize("rows_per_wave", [32, 64])
-@pytest.mark.parametrize("pipeline", [1, 3])
+@pytest.mark.parametrize("pipeline", [1, 3, 5])
 def test_spconv_kernel_variants_match_oracle(ops, oracle, kind, c0, c1, cout, rows_per_wave, pipeline):
-    """Every variant of the pipelined kernel the benchmark selects by shape -- 32 / 64 rows per wave, both loop forms,
-    unsplit and split-K -- on >= 20 k-row same-level, strided and transposed maps with the fused second source (ME.cat),
+    """Every variant of the pipelined kernel the benchmark selects by shape -- 32 / 64 rows per wave, the loop forms (1, 3:
+    one step of operand loads in flight; 5: the depth-3 register ring with hand-counted waits), unsplit and split-K -- on >= 20 k-row same-level, strided and transposed maps with the fused second source (ME.cat),
     folded BN, ReLU and residual, in fp32 (1e-4 vs the oracle) and with bfloat16 compute (oracle on rounded operands)."""
     rng = np.random.default_rng(101)
     fine = surface(rng, n=26000, n_batch=3, extent=120)
@@ -1004,7 +1004,8 @@ def test_batched_weight_packing_equals_single_layer_packing(ops):
     got = [cache.get(p, t, k) for p, t, k in combos]          # first request re-packs all of them in one launch
     for (p, t, k), gt, f in zip(combos, got, first):
         assert torch.equal(gt, ops.pack_weight(p, transpose=t, kflip=k)) and not torch.equal(gt, f)
-    assert cache.table is not None and cache.table[2] == len(combos)
+    tab = cache.tables.get(p.device)
+    assert tab is not None and tab[2] == len(combos)
 
 
 def test_transposed_map_8_wide_equals_dense(ops, oracle):
