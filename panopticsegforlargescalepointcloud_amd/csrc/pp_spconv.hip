@@ -290,7 +290,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
   PP_REQUIRE((c0 + c1) % 4 == 0, "pp_spconv_fwd: cin must be a multiple of 4");
   PP_REQUIRE(rows_per_wave == 0 || rows_per_wave == 32 || rows_per_wave == 64, "pp_spconv_fwd_ex: rows_per_wave in {0, 32, 64}");
-  PP_REQUIRE(pipeline == 0 || pipeline == 1 || pipeline == 3 || pipeline == 5, "pp_spconv_fwd_ex: pipeline in {0, 1, 3, 5}");
+  PP_REQUIRE(pipeline == 0 || pipeline == 1 || pipeline == 3 || pipeline == 5 || pipeline == 6, "pp_spconv_fwd_ex: pipeline in {0, 1, 3, 5, 6}");
   PP_REQUIRE(split_k == 0 || split_k == 1 || split_k == 2 || split_k == 4 || split_k == 8, "pp_spconv_fwd_ex: split_k in {0, 1, 2, 4, 8}");
   const bool mode16 = ((c0 + c1) % 16 == 0);
   if (mode16) PP_REQUIRE(c0 % 16 == 0, "pp_spconv_fwd: with cin % 16 == 0 both sources must be multiples of 16");

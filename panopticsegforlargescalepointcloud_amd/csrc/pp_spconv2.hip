@@ -65,6 +65,9 @@ template <int NTW, int T, bool BF16, int D, bool C4 = false, bool DS = false, bo
 __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
   constexpr int R = 16 * T;  // rows per wave
   __shared__ unsigned s_off[F3_WPB][F2_MAXK][R];
+  // D == 6 (LDS-staged feature tiles): per wave a ring of RD6 steps x T tiles x 2 KiB (16 rows x 128 bytes)
+  constexpr int RD6 = NTW <= 2 ? 3 : 2;
+  __shared__ f32x4 s_ring[D == 6 ? F3_WPB * RD6 * T * 128 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -446,6 +449,144 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
 #undef R_LOADS
 #undef R_STAGE
 #undef R_WAIT
+    } else if constexpr (D == 6) {
+      // ---- LDS-staged feature tiles (what north_star names; rows of >= 128 bytes, i.e. inputs with a multiple of 32 channels).
+      // The depth-1 loop gathers the A operand in MFMA fragment shape: one instruction = 16 rows x 64 bytes, so a 128-byte
+      // row is fetched as two HALF cache lines by two instructions.  profiles/r04_gather_forms.txt: that form costs the CU's
+      // texture path 38.6 cycles per KiB from L2 and 179 from HBM, full lines (8 rows x 128 bytes per instruction) 20.5 / 90
+      // -- the cost is per LINE touched, whatever part of it is used.  Full-line loads do not land in fragment layout, so they go
+      // to LDS (buffer_load ... lds: no VGPRs, no ds_write pass) and the fragments are read back with ds_read_b128.
+      //   step      = (offset k, 128-byte segment g of the row = two 16-channel steps)
+      //   staging   = per tile 2 instructions (rows 0-7, 8-15; lane = (row l >> 3, chunk l & 7)); the lane reads source chunk
+      //               (l & 7) ^ ((l >> 3) & 6) so that the linear LDS image is XOR-swizzled and the fragment reads -- lane (i, q)
+      //               takes chunk 4 s + q of row i -- are bank-conflict free in every 16-lane group of ds_read_b128
+      //   ring      = RD6 steps per wave, RD6 - 1 in flight; weights in RD6 register sets; all loads are inline assembly with
+      //               counted waits (2 T + 2 NTW vector memory operations per step, in issue order)
+      static_assert(!C4 && T == 2, "the LDS-staged loop: 32 rows per wave (its ring is 4 KiB per step)");
+      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+      constexpr int LPS = 2 * T + 2 * NTW;
+      const int G0 = S0 >> 1, G = S >> 1;
+      const unsigned long long pw_ = (unsigned long long)a.wp;
+      const u32x4_t dw_ = {(unsigned)pw_, (unsigned)(pw_ >> 32) & 0xFFFFu, w_bytes, 0x00020000u};
+      unsigned vw[NTW];
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) vw[jt] = lane16 + (unsigned)jt * WT;
+      const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      f32x4* ringw = s_ring + wave_u * (RD6 * T * 128);
+      const unsigned ring_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)ringw;
+      const unsigned r8 = (unsigned)lane >> 3;
+      const unsigned dma_c = (((unsigned)lane & 7u) ^ (r8 & 6u)) << 4;
+      const unsigned rdb = ((unsigned)(i >> 3) << 10) + ((unsigned)(i & 7) << 7);
+      const unsigned sw6 = (unsigned)(i & 6);
+      const f32x4* rp0 = (const f32x4*)((const char*)ringw + rdb + (((unsigned)q ^ sw6) << 4));
+      const f32x4* rp1 = (const f32x4*)((const char*)ringw + rdb + ((((unsigned)q + 4u) ^ sw6) << 4));
+      unsigned vo2[T][2];
+      int gl = 0;
+#define L_OFFS()                                                                                          \
+  _Pragma("unroll") for (int tt = 0; tt < T; ++tt) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
+      vo2[tt][j] = off[kl][tt * 16 + 8 * j + r8] | dma_c;
+      L_OFFS();
+#define L_ADVANCE(VALID)           \
+  {                                \
+    VALID = 1;                     \
+    ++gl;                          \
+    if (gl == G) {                 \
+      gl = 0;                      \
+      rem &= rem - 1;              \
+      if (rem) {                   \
+        kl = __builtin_ctz(rem);   \
+        L_OFFS();                  \
+      } else                       \
+        VALID = 0;                 \
+    }                              \
+  }
+#define L_LOADS(SLOT, BX)                                                                                            \
+  {                                                                                                                  \
+    const float* src_ = gl < G0 ? a.in0 + gl * 32 : a.in1 + (gl - G0) * 32;                                          \
+    const unsigned long long pa_ = (unsigned long long)src_;                                                         \
+    const u32x4_t da_ = {(unsigned)pa_, (unsigned)(pa_ >> 32) & 0xFFFFu, a_bytes, 0x00020000u};                      \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                 \
+      const unsigned lds_ = ring_lds + (unsigned)(((SLOT) * T + tt) * 2048 + j * 1024);                              \
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"                       \
+                   ::"v"(vo2[tt][j]), "s"(lds_), "s"(da_) : "memory");                                               \
+    }                                                                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                               \
+      const unsigned wso_ = (unsigned)(kl * S + 2 * gl + s2) * w_step + w_jt0;                                       \
+      _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                             \
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(BX[s2][jt]) : "v"(vw[jt]), "s"(dw_), "s"(wso_)); \
+    }                                                                                                                \
+  }
+#define L_STAGE(SLOT, BX, KV, EV)  \
+  {                                \
+    L_LOADS(SLOT, BX);             \
+    KV = kl;                       \
+    EV = nx;                       \
+    if (nx) { L_ADVANCE(nx); }     \
+  }
+#define L_WAIT(BX)                                                                                                    \
+  {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%c0)" ::"n"((RD6 - 1) * LPS) : "memory");                                           \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)               \
+        asm volatile("" : "+v"(BX[s2][jt]));                                                                          \
+  }
+#define L_MFMAS(SLOT, BX, KC, EV)                                                                                     \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)               \
+        asm volatile("" : "+v"(acc[tt][jt]));                                                                         \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                                \
+      if (EV && ((m[tt] >> (KC)) & 1u)) {                                                                             \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
+          const f32x4 av_ = (s2 ? rp1 : rp0)[((SLOT) * T + tt) * 128];                                                \
+          if constexpr (BF16) {                                                                                       \
+            const s16x4 ah_ = pp_bf16x4(av_);                                                                         \
+            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                        \
+                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pp_bf16x4(BX[s2][jt]), ah_, acc[tt][jt], 0, 0, 0); \
+          } else {                                                                                                    \
+            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) _Pragma("unroll") for (int t = 0; t < 4; ++t)          \
+                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(BX[s2][jt][t], av_[t], acc[tt][jt], 0, 0, 0);      \
+          }                                                                                                           \
+        }                                                                                                             \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+      f32x4 BA[2][NTW], BB[2][NTW], BC[2][NTW];
+      int nx = 1, k0 = 0, k1 = 0, k2 = 0, e0 = 0, e1 = 0, e2 = 0;
+      if constexpr (RD6 == 3) {
+        L_STAGE(0, BA, k0, e0);
+        L_STAGE(1, BB, k1, e1);
+        for (;;) {
+          L_STAGE(2, BC, k2, e2);
+          L_WAIT(BA);
+          L_MFMAS(0, BA, k0, e0);
+          L_STAGE(0, BA, k0, e0);
+          L_WAIT(BB);
+          L_MFMAS(1, BB, k1, e1);
+          L_STAGE(1, BB, k1, e1);
+          L_WAIT(BC);
+          L_MFMAS(2, BC, k2, e2);
+          if (!e0) break;
+        }
+      } else {
+        L_STAGE(0, BA, k0, e0);
+        for (;;) {
+          L_STAGE(1, BB, k1, e1);
+          L_WAIT(BA);
+          L_MFMAS(0, BA, k0, e0);
+          L_STAGE(0, BA, k0, e0);
+          L_WAIT(BB);
+          L_MFMAS(1, BB, k1, e1);
+          if (!e0) break;
+        }
+        (void)BC; (void)k2; (void)e2;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      (void)more; (void)sl; (void)vo;
+#undef L_OFFS
+#undef L_ADVANCE
+#undef L_LOADS
+#undef L_STAGE
+#undef L_WAIT
+#undef L_MFMAS
     }
 #undef F3_LOADS
 #undef F3_ADVANCE
@@ -600,6 +741,21 @@ static int launch3_t(const SpconvArgs& a, int ntw, int depth, unsigned groups, u
     else hipLaunchKernelGGL((k_spconv_fwd3<2, T, BF16, 3, false, false, true>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags);
     return PP_OK;
   }
+  if (depth == 6) {  // LDS-staged feature tiles: 32 rows per wave only (pp_spconv_fwd3_launch has checked the shape)
+    if constexpr (T == 2) {
+      switch (ntw) {
+        case 1: hipLaunchKernelGGL((k_spconv_fwd3<1, 2, BF16, 6>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 2: hipLaunchKernelGGL((k_spconv_fwd3<2, 2, BF16, 6>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 3: hipLaunchKernelGGL((k_spconv_fwd3<3, 2, BF16, 6>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        case 4: hipLaunchKernelGGL((k_spconv_fwd3<4, 2, BF16, 6>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
+        default: pp_set_error("pp_spconv_fwd3: ntw %d out of range for the LDS-staged loop", ntw); return PP_ERR_INVALID;
+      }
+      return PP_OK;
+    } else {
+      pp_set_error("pp_spconv_fwd3: the LDS-staged loop runs with 32 rows per wave");
+      return PP_ERR_INVALID;
+    }
+  }
 #define F3_CASE(N, D) \
   case 10 * D + N: hipLaunchKernelGGL((k_spconv_fwd3<N, T, BF16, D>), grid, dim3(64 * F3_WPB), 0, s, a, a_bytes, w_bytes, flags); break;
   switch (10 * depth + ntw) {
@@ -648,6 +804,10 @@ int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned g
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u) |
                          (!a.t8 && a.nbr && (double)a.K * (double)a.n_out * 4.0 < 4294967000.0 ? 2u : 0u) |
                          (a.t8 && (double)a.n_out * 32.0 < 4294967000.0 ? 4u : 0u);
+  if (depth == 6 && (T != 2 || a.c0 % 32 != 0 || a.c1 % 32 != 0 || a.ds_in || ntw > 4)) {
+    pp_set_error("pp_spconv_fwd3: the LDS-staged loop needs 32 rows per wave, channel counts that are multiples of 32 and <= 4 column tiles");
+    return PP_ERR_INVALID;
+  }
   if (T != 2 && T != 4) {
     pp_set_error("pp_spconv_fwd3: rows per wave must be 32 or 64");
     return PP_ERR_INVALID;

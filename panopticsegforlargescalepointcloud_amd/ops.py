@@ -5,6 +5,7 @@ gfx950 kernels in csrc/.  All tensors must live on a HIP device; there is no CPU
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -136,6 +137,34 @@ PROFILER = None
 PROFILE_TAG = "fwd"  # what the next pp_spconv_fwd launches are (the autograd backward sets "dgrad" around its launch)
 
 
+
+class _CounterPool(threading.local):
+    """Small zero-initialised device counters (pair counts, overflow flags, sizes ...) handed out as slices of one zeroed block
+    per thread -- every `torch.zeros(2)` was a fill launch of its own (~80 per bench step on the two builder threads and the
+    main thread; the small configurations are paced by their dispatches).  A block is never reused: when it is exhausted a
+    fresh one is allocated, so a counter stays valid for as long as its tensor lives.  Per thread = per stream: the fill of a
+    block is ordered on the stream the thread launches on."""
+
+    def __init__(self):
+        self.blocks = {}
+
+    def take(self, n, dtype, device):
+        key = (dtype, device)
+        blk = self.blocks.get(key)
+        if blk is None or blk[1] + n > blk[0].numel():
+            blk = self.blocks[key] = [torch.zeros(2048, dtype=dtype, device=device), 0]
+        out = blk[0][blk[1]: blk[1] + n]
+        blk[1] += (n + 3) & ~3  # 16-byte granules: neighbours never share a 64-bit word that a kernel updates atomically
+        return out
+
+
+_COUNTERS = _CounterPool()
+
+
+def _zeros(n, dtype, device):
+    return _COUNTERS.take(n, dtype, device)
+
+
 def _pairs_of(nbr):
     """device scalar holding the number of pairs of a kernel map (None = identity map); never keeps the map alive"""
     if nbr is None:
@@ -212,7 +241,7 @@ def hash_build(coords):
     coords = _need(coords, torch.int32, "coords")
     n = coords.shape[0]
     table = HashTable(n, coords.device)
-    info = torch.zeros(2, dtype=torch.int32, device=coords.device)
+    info = _zeros(2, torch.int32, coords.device)
     _lib.check(lib.pp_hash_build(_ptr(coords), n, _ptr(table.keys), _ptr(table.vals), table.cap, _ptr(info), _stream()),
                "pp_hash_build")
     ndup, nrange = info.tolist()
@@ -229,9 +258,9 @@ def stride_coords(coords, ts_out):
     dev = coords.device
     table = HashTable(n, dev)
     out = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
-    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_out = _zeros(1, torch.int32, dev)
     f2c = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    info = _zeros(2, torch.int32, dev)
     wsb = lib.pp_stride_coords_workspace(n)
     ws = _ws(wsb, dev)
     _lib.check(lib.pp_stride_coords(_ptr(coords), n, int(ts_out), _ptr(table.keys), _ptr(table.vals), table.cap, _ptr(out),
@@ -249,7 +278,7 @@ def kernel_map(out_coords, table, ksize, step, sign):
     n_out = out_coords.shape[0]
     K = ksize ** 3
     nbr = torch.empty((K, n_out), dtype=torch.int32, device=out_coords.device)
-    pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
+    pairs = _zeros(1, torch.int64, out_coords.device)
     _lib.check(lib.pp_kernel_map(_ptr(out_coords), n_out, _ptr(table.keys), _ptr(table.vals), table.cap, ksize, int(step),
                                  int(sign), _ptr(nbr), _ptr(pairs), _stream()), "pp_kernel_map")
     nbr.pp_pairs = pairs  # device scalar: number of (in, out) pairs (flops / density bookkeeping, no sync here)
@@ -270,7 +299,7 @@ def block_index_build(coords_sorted, unit, block_bits):
     n = coords.shape[0]
     dev = coords.device
     row_block = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    counts = _zeros(4, torch.int32, dev)
     wsb = lib.pp_block_index_workspace(n)
     ws = _ws(wsb, dev, tag="block_index")
     _lib.check(lib.pp_block_index_count(_ptr(coords), n, int(unit), int(block_bits), _ptr(row_block), _ptr(counts), _ptr(ws),
@@ -309,7 +338,7 @@ def block_index_coarsen(fine, n_fine_rows):
     bi.rec = torch.empty(max(nbf, 1) * 128, dtype=torch.int64, device=dev)
     bi.bkey_ord = torch.empty(max(nbf, 1), dtype=torch.int64, device=dev)
     coords = torch.empty((max(int(n_fine_rows), 1), 4), dtype=torch.int32, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = _zeros(2, torch.int32, dev)
     wsb = lib.pp_block_index_coarsen_workspace(nbf)
     ws = _ws(wsb, dev)
     _lib.check(lib.pp_block_index_coarsen(_ptr(fine.bkey_ord), _ptr(fine.rec), nbf, bi.unit, bi.block_bits, _ptr(bi.bkeys),
@@ -329,7 +358,7 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, transla
     out_coords = _need(out_coords, torch.int32, "out_coords")
     n_out = out_coords.shape[0]
     nbr = torch.empty((27, n_out), dtype=torch.int32, device=out_coords.device)
-    pairs = torch.zeros(1, dtype=torch.int64, device=out_coords.device)
+    pairs = _zeros(1, torch.int64, out_coords.device)
     mask = torch.empty(max(n_out, 1), dtype=torch.int32, device=out_coords.device) if want_mask else None
     _lib.check(lib.pp_kernel_map_bi(_ptr(out_coords), n_out, _ptr(index.bkeys), _ptr(index.bvals), index.cap,
                                     _ptr(index.rec), index.unit, index.block_bits, int(step), int(sign),
@@ -347,7 +376,7 @@ def exclusive_scan(x, want_total=False):
     x = _need(x, torch.int32, "x")
     n = x.shape[0]
     out = torch.empty_like(x)
-    total = torch.zeros(1, dtype=torch.int32, device=x.device) if want_total else None
+    total = _zeros(1, torch.int32, x.device) if want_total else None
     wsb = lib.pp_exclusive_scan_workspace(n)
     ws = _ws(wsb, x.device, tag="scan")
     _lib.check(lib.pp_exclusive_scan(_ptr(x), _ptr(out), n, _ptr(total), _ptr(ws), wsb, _stream()), "pp_exclusive_scan")
@@ -483,7 +512,7 @@ def morton_order(coords, unit=1, block_bits=0, want_sorted=False, raw=False):
     n = coords.shape[0]
     dev = coords.device
     perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    info = _zeros(2, torch.int32, dev)
     wsb = lib.pp_morton_order_workspace(n)
     ws = _ws(wsb, dev)
     srt = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev) if want_sorted else None
@@ -871,7 +900,7 @@ def heads(x, specs, index=None):
     dev = x.device
     flag = _GATHER_ERR.get(dev)
     if flag is None:
-        flag = _GATHER_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag = _GATHER_ERR[dev] = _zeros(1, torch.int32, dev)
     arr = (_lib.HeadDesc * len(specs))()
     outs, keep = [], []
     for d, (w1, scale, shift, w2, b2, log_softmax, want_argmax) in zip(arr, specs):
@@ -907,7 +936,7 @@ class ClusterCSR:
         """CSR of the proposals `ids` (int64 tensor), in that order."""
         dev = self.offsets.device
         sz = self.sizes()[ids]
-        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(sz, 0)])
+        offs = torch.cat([_zeros(1, torch.int64, dev), torch.cumsum(sz, 0)])
         starts = self.offsets[:-1].long()[ids]
         rep = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), sz)
         within = torch.arange(rep.numel(), device=dev) - offs[rep]  # (rep already has the total length: no second host read)
@@ -924,14 +953,14 @@ class ClusterCSR:
         sizes = torch.tensor([0] + [int(c.numel()) for c in clusters], dtype=torch.int64)
         offsets = torch.cumsum(sizes, 0).to(torch.int32).to(device)
         points = (torch.cat([c.reshape(-1).to(device=device, dtype=torch.int64) for c in clusters]) if n else
-                  torch.zeros(0, dtype=torch.int64, device=device))
+                  _zeros(0, torch.int64, device))
         return ClusterCSR(offsets, points.contiguous(), n)
 
     @staticmethod
     def concat(parts):
         parts = [p for p in parts if p is not None]
         dev = parts[0].offsets.device
-        offs = [torch.zeros(1, dtype=torch.int32, device=dev)]
+        offs = [_zeros(1, torch.int32, dev)]
         base = 0
         for p in parts:
             offs.append(p.offsets[1: p.n + 1] + base)
@@ -974,8 +1003,8 @@ def proposal_pairs(csr, n_points):
     a = torch.empty(cap, dtype=torch.int32, device=dev)
     b = torch.empty(cap, dtype=torch.int32, device=dev)
     inter = torch.empty(cap, dtype=torch.int32, device=dev)
-    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
-    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    n_pairs = _zeros(1, torch.int32, dev)
+    info = _zeros(4, torch.int32, dev)
     poe = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
     wsb = lib.pp_proposal_pairs_workspace(total, int(n_points), P)
     ws = _ws(wsb, dev, tag="proposal_pairs")
@@ -1048,8 +1077,8 @@ def pair_counts(a, b, nb, capacity=None):
         pa = torch.empty(cap, dtype=torch.int64, device=dev)
         pb = torch.empty(cap, dtype=torch.int64, device=dev)
         cnt = torch.empty(cap, dtype=torch.int64, device=dev)
-        n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
-        info = torch.zeros(2, dtype=torch.int32, device=dev)
+        n_pairs = _zeros(1, torch.int32, dev)
+        info = _zeros(2, torch.int32, dev)
         wsb = lib.pp_pair_counts_workspace(cap)
         ws = _ws(wsb, dev, tag="pair_counts")
         _lib.check(lib.pp_pair_counts(_ptr(a), _ptr(b), n, int(nb), cap, _ptr(pa), _ptr(pb), _ptr(cnt), _ptr(n_pairs), _ptr(info),
@@ -1078,7 +1107,7 @@ def block_merge(origin_ids, block_labels, scene_labels, max_instance, state=None
     dev = scene_labels.device
     n = origin_ids.shape[0]
     if state is None:
-        state = torch.zeros(8, dtype=torch.int32, device=dev)
+        state = _zeros(8, torch.int32, dev)
     wsb = lib.pp_block_merge_workspace(n)
     ws = _ws(wsb, dev, tag="block_merge")
     _lib.check(lib.pp_block_merge(_ptr(origin_ids), _ptr(block_labels), n, _ptr(scene_labels), scene_labels.shape[0],
@@ -1122,7 +1151,7 @@ def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_clus
     pc = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     offs = torch.empty(n + 2, dtype=torch.int32, device=dev)
     pts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = _zeros(2, torch.int32, dev)
     def run(ws, wsb):
         return lib.pp_region_grow(_ptr(pos), _ptr(labels), _ptr(batch), n, _ptr(ign), ign.numel(), int(num_classes),
                                   int(nsample), float(radius), int(min_cluster_size), _ptr(pc), _ptr(offs), _ptr(pts),
@@ -1196,7 +1225,7 @@ def voxelize(pos, voxel_size, batch=None):
     coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
     rep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = _zeros(2, torch.int32, dev)
     wsb = lib.pp_voxelize_workspace(n)
     ws = _ws(wsb, dev, tag="voxelize")
     _lib.check(lib.pp_voxelize(_ptr(pos), _ptr(batch), n, float(voxel_size), _ptr(coords), _ptr(rep), _ptr(inv), _ptr(counts),
@@ -1214,7 +1243,7 @@ def cylinder_tiles(pos, centres_xy, radius):
     cen = _need(centres_xy, torch.float32, "centres_xy")
     n, nc = pos.shape[0], cen.shape[0]
     dev = pos.device
-    n_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_pairs = _zeros(1, torch.int32, dev)
     wsb = lib.pp_cylinder_pairs_workspace(n)
     ws = _ws(wsb, dev, tag="cylinders")
     _lib.check(lib.pp_cylinder_pairs(_ptr(pos), n, _ptr(cen), nc, float(radius), None, None, 0, _ptr(n_pairs), _ptr(ws), wsb,
@@ -1244,7 +1273,7 @@ def gather_rows(src, index):
     dev = src.device
     flag = _GATHER_ERR.get(dev)
     if flag is None:
-        flag = _GATHER_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag = _GATHER_ERR[dev] = _zeros(1, torch.int32, dev)
     out = torch.empty((index.shape[0], src.shape[1]), dtype=torch.float32, device=dev)
     _lib.check(lib.pp_gather_rows(_ptr(src), src.shape[0], src.shape[1], _ptr(index), index.shape[0], _ptr(out),
                                   _ptr(flag), _stream()), "pp_gather_rows")
@@ -1293,7 +1322,7 @@ def group_by_key(key, n_groups, ids=None):
     ids = _need(ids, torch.int64, "ids")
     offs = torch.empty(n_groups + 1, dtype=torch.int32, device=dev)
     out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
-    total = torch.zeros(2, dtype=torch.int32, device=dev)  # [kept, keys >= n_groups (caller error, see group_by_key_check)]
+    total = _zeros(2, torch.int32, dev)  # [kept, keys >= n_groups (caller error, see group_by_key_check)]
     wsb = lib.pp_group_by_key_workspace(max(n, n_groups))
     ws = _ws(wsb, dev)
     _lib.check(lib.pp_group_by_key(_ptr(key), _ptr(ids), n, int(n_groups), _ptr(offs), _ptr(out), _ptr(total),

@@ -14,3 +14,7 @@ s = io.StringIO()
 ps = pstats.Stats(pr, stream=s).sort_stats("tottime")
 ps.print_stats(45)
 print(s.getvalue()[:9000])
+for fn in ("_cuda_getDeviceCount", "is_available", "_get_available_device_type", "_get_device_attr"):
+    s2 = io.StringIO()
+    pstats.Stats(pr, stream=s2).sort_stats("tottime").print_callers(fn)
+    print(s2.getvalue()[:3500])
