@@ -229,8 +229,11 @@ int pp_spconv_fwd_shortcut(const float* in0, int32_t c0, const float* in1, int32
  * v_mfma_f32_16x16x16_bf16 -- torch.autocast(bfloat16) semantics for the convolution.  Needs cin % 16 == 0 per source,
  * K <= 28 and < 4 GiB per source (PP_ERR_INVALID otherwise; callers keep the fp32 entry for those layers). */
 /* Explicit variants of the pipelined kernel (parity tests, A/B measurements): rows_per_wave in {0, 32, 64} (16-row MFMA
- * tiles per wave x 16), pipeline in {0, 1, 3} (1: loads of step n+1 issued before the MFMAs of step n; 3: additionally
- * the LDS read of the step after that), split_k in {0, 1, 2, 4, 8} (kernel offsets split over that many waves, partial
+ * tiles per wave x 16), pipeline in {0, 1, 3, 5, 6} (1: loads of step n+1 issued before the MFMAs of step n; 3: additionally
+ * the LDS read of the step after that; 5: register ring of depth 3 -- the loads of step n+2 before the MFMAs of step n,
+ * inline-assembly loads with hand-counted waits, <= 4 column tiles per wave; 6: LDS-staged feature tiles -- full 128-byte
+ * line gathers by buffer_load ... lds into an XOR-swizzled ring, fragments by ds_read_b128; channel counts that are
+ * multiples of 32, 32 rows per wave, <= 4 column tiles), split_k in {0, 1, 2, 4, 8} (kernel offsets split over that many waves, partial
  * sums added in a fixed order; needs pp_spconv_set_scratch); 0 = the per-shape choice pp_spconv_fwd makes.  bf16 != 0
  * selects the bfloat16 compute variant.  PP_ERR_INVALID for shapes the pipelined kernel does not take. */
 /* pp_spconv_fwd on the 8-wide transposed map (pp_kernel_map_transpose8 -> pp_map_permute(K = 8)); bit-identical
@@ -278,6 +281,14 @@ int pp_wgrad_pairs_build(const int32_t* nbr, int32_t K, int64_t n_out, const int
 int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout, int64_t n_out,
                                const int32_t* pairs, const int32_t* tile_start, int32_t K, int64_t map_rows, float* dw,
                                int32_t bf16, pp_stream_t stream);
+/* The same weight gradient without float atomics: every block stores its tile sum in `workspace`
+ * (pp_spconv_bwd_weight_pairs_det_workspace bytes) and a second launch adds the blocks of an offset in a fixed order, so dw -- and
+ * with it the loss trajectory of a training run -- is bit-identical from run to run.  replaces: the same ME backward as above
+ * (torch_points3d/models/panoptic/PointGroup3heads.py:552-639 -> loss.backward()). */
+size_t pp_spconv_bwd_weight_pairs_det_workspace(int32_t cin, int32_t cout, int32_t K, int64_t map_rows);
+int pp_spconv_bwd_weight_pairs_det(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout, int64_t n_out,
+                                   const int32_t* pairs, const int32_t* tile_start, int32_t K, int64_t map_rows, float* dw,
+                                   int32_t bf16, void* workspace, size_t workspace_bytes, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K6  batch-norm pieces on [n,C]  replaces: ME.MinkowskiBatchNorm (= BatchNorm1d on F), api_modules.py:40,53,269

@@ -52,6 +52,26 @@ STRIDED_ORDER_RATIO = float(os.environ.get("PP_STRIDED_ORDER_RATIO", "1.7"))
 _SIDE_STREAMS = {}
 
 
+_STREAM_TLS = threading.local()
+
+
+def _raw_stream():
+    """raw handle of the calling thread's current HIP stream (two C calls, no Python objects)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _current_stream():
+    """torch.cuda.current_stream() without its cost: the public call resolves the device index through
+    torch._utils._get_current_device_index -> torch.cuda.is_available() -> a device-count query, ~12 us each, and this module
+    asked for it ~200 times per step (once per map / level access and per readiness event: 2.4 ms of host time per step of a
+    dispatch-paced configuration).  The Stream object is cached per thread and re-made only when the raw handle changes."""
+    raw = _raw_stream()
+    c = getattr(_STREAM_TLS, "cur", None)
+    if c is None or c[0] != raw:
+        c = _STREAM_TLS.cur = (raw, torch.cuda.current_stream())
+    return c[1]
+
+
 def _side_stream(device):
     """the stream the coordinate levels / kernel maps are prefetched on (PP_SIDE_PRIORITY=high|default, A/B runs)."""
     s = _SIDE_STREAMS.get(device)
@@ -208,7 +228,7 @@ class CoordinateManager:
 
     def _built(self, key):
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(_current_stream())
         self._ready[key] = ev
 
     def _use(self, key):
@@ -217,7 +237,7 @@ class CoordinateManager:
             if ev.query():  # complete: no barrier packet in front of the consumer (each costs ~10 us of an idle queue)
                 self._ready[key] = None
             else:
-                torch.cuda.current_stream().wait_event(ev)
+                _current_stream().wait_event(ev)
 
     def prefetch(self, plan, early=False):
         """replay `plan` (the request log of an earlier forward of the same model) on the side stream.  early (from the
@@ -264,11 +284,11 @@ class CoordinateManager:
         calling stream reads it too, so that the block is not handed out again while this stream's kernels are pending"""
         if not self._side_built:
             return
-        cur = torch.cuda.current_stream()
+        raw = _raw_stream()
         for t in tensors:
-            if t is not None and t.is_cuda and getattr(t, "pp_seen_by", None) != cur.cuda_stream:
-                t.record_stream(cur)
-                t.pp_seen_by = cur.cuda_stream
+            if t is not None and t.is_cuda and getattr(t, "pp_seen_by", None) != raw:
+                t.record_stream(_current_stream())
+                t.pp_seen_by = raw
 
     def level(self, ts):
         self._use(("level", ts))

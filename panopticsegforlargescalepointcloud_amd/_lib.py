@@ -77,6 +77,8 @@ SIGNATURES = {
     "pp_wgrad_pairs_workspace": (sz, [i32, i64]),
     "pp_wgrad_pairs_build": (C.c_int, [vp, i32, i64, vp, vp, vp, vp, sz, vp]),
     "pp_spconv_bwd_weight_pairs": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, vp, i32, i64, vp, i32, vp]),
+    "pp_spconv_bwd_weight_pairs_det_workspace": (sz, [i32, i32, i32, i64]),
+    "pp_spconv_bwd_weight_pairs_det": (C.c_int, [vp, i32, i64, vp, i32, i64, vp, vp, i32, i64, vp, i32, vp, sz, vp]),
     "pp_channel_stats": (C.c_int, [vp, i64, i32, vp, vp, vp]),
     "pp_affine_act": (C.c_int, [vp, i64, i32, vp, vp, i32, f32, vp, vp, vp]),
     "pp_bn_bwd_reduce": (C.c_int, [vp, vp, i64, i32, vp, vp, vp]),

@@ -17,6 +17,15 @@ __device__ __forceinline__ s16x4 pp_bf16x4(f32x4 v) {
   return __builtin_bit_cast(s16x4, p);
 }
 
+// 2 x 4 floats -> 8 bfloat16 = the A / B operand of v_mfma_f32_16x16x32_bf16 (lane (i, q) supplies k = 8q .. 8q+7)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t pp_bf16x8(f32x4 lo, f32x4 hi) {
+  const s16x4 a = pp_bf16x4(lo), b = pp_bf16x4(hi);
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 struct SpconvArgs {
   const float* in0;
   const float* in1;

@@ -535,13 +535,15 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
         asm volatile("" : "+v"(acc[tt][jt]));                                                                         \
     _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                                \
       if (EV && ((m[tt] >> (KC)) & 1u)) {                                                                             \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                            \
-          const f32x4 av_ = (s2 ? rp1 : rp0)[((SLOT) * T + tt) * 128];                                                \
-          if constexpr (BF16) {                                                                                       \
-            const s16x4 ah_ = pp_bf16x4(av_);                                                                         \
-            _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                        \
-                acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pp_bf16x4(BX[s2][jt]), ah_, acc[tt][jt], 0, 0, 0); \
-          } else {                                                                                                    \
+        if constexpr (BF16) {                                                                                         \
+          /* the two 16-channel steps of the segment as ONE v_mfma_f32_16x16x32_bf16 (gfx950: twice the k of the CDNA3 form): */ \
+          /* lane (i, q) supplies k = 8 q + t, t < 4 from the first step, t >= 4 from the second -- the same map for both operands */ \
+          const bf16x8_t a8_ = pp_bf16x8(rp0[((SLOT) * T + tt) * 128], rp1[((SLOT) * T + tt) * 128]);                  \
+          _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt)                                                          \
+              acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pp_bf16x8(BX[0][jt], BX[1][jt]), a8_, acc[tt][jt], 0, 0, 0); \
+        } else {                                                                                                      \
+          _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
+            const f32x4 av_ = (s2 ? rp1 : rp0)[((SLOT) * T + tt) * 128];                                              \
             _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) _Pragma("unroll") for (int t = 0; t < 4; ++t)          \
                 acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(BX[s2][jt][t], av_[t], acc[tt][jt], 0, 0, 0);      \
           }                                                                                                           \

@@ -269,7 +269,9 @@ extern "C" int pp_wgrad_pairs_build(const int32_t* nbr, int32_t K, int64_t n_out
   return PP_OK;
 }
 
-template <int MT, int NTO, bool BF16, int WPB>
+// DET: the block's tile sum is STORED as a partial (part[k][z][block x][tile][256]) instead of added to dw with float atomics;
+// k_wgrad_reduce then adds the partials of an offset in block order -- the same bits run after run
+template <int MT, int NTO, bool BF16, int WPB, bool DET = false>
 __global__ __launch_bounds__(WPB * 64) void k_spconv_bww4(const float* __restrict__ in, int cin, u32 in_bytes,
                                                      const float* __restrict__ dout, int cout, u32 dout_bytes,
                                                      const int2* __restrict__ pairs, const int32_t* __restrict__ tile_start,
@@ -386,10 +388,33 @@ __global__ __launch_bounds__(WPB * 64) void k_spconv_bww4(const float* __restric
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WPB; ++w) v += red[w][tile][e * 64 + ln];
-    const int mt = tile / NTO, jt = tile - mt * NTO;
-    const int ci = ci0 + mt * 16 + 4 * (ln >> 4) + e, co = jt * 16 + (ln & 15);
-    if (ci < cin && co < cout && v != 0.f) atomicAdd(&dw[((int64_t)k * cin + ci) * cout + co], v);
+    if constexpr (DET) {  // dw = the partial buffer here: [k][z][x][MT * NTO tiles][256]
+      const int64_t slot = ((int64_t)k * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x;
+      dw[slot * (MT * NTO * 256) + x] = v;
+    } else {
+      const int mt = tile / NTO, jt = tile - mt * NTO;
+      const int ci = ci0 + mt * 16 + 4 * (ln >> 4) + e, co = jt * 16 + (ln & 15);
+      if (ci < cin && co < cout && v != 0.f) atomicAdd(&dw[((int64_t)k * cin + ci) * cout + co], v);
+    }
   }
+}
+
+// dw[k][ci][co] = sum over the blocks x = 0 .. nb_k - 1 of offset k, in that order, of their partial tiles (blocks past the end
+// of the offset's pair list wrote nothing and are not read)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, const int32_t* __restrict__ tile_start,
+                                                      int tiles_per_k, int per_block, int gx, int gz, int mt, int nto, int cin,
+                                                      int cout, float* __restrict__ dw) {
+  const int k = blockIdx.y, z = blockIdx.z, tile = blockIdx.x;
+  const int cnt = tile_start[(k + 1) * tiles_per_k] - tile_start[k * tiles_per_k];
+  const int nb = (cnt + per_block - 1) / per_block;
+  const int e = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int m = tile / nto, jt = tile - m * nto;
+  const int ci = z * (16 * mt) + m * 16 + 4 * (ln >> 4) + e, co = jt * 16 + (ln & 15);
+  const int tiles = mt * nto;
+  const float* p = part + (((int64_t)k * gz + z) * gx) * ((int64_t)tiles * 256) + (int64_t)tile * 256 + threadIdx.x;
+  float v = 0.f;
+  for (int x = 0; x < nb; ++x) v += p[(int64_t)x * tiles * 256];
+  if (ci < cin && co < cout) dw[((int64_t)k * cin + ci) * cout + co] = v;
 }
 
 #ifndef BWW4_WPB
@@ -398,7 +423,16 @@ __global__ __launch_bounds__(WPB * 64) void k_spconv_bww4(const float* __restric
 template <int MT, int NTO>
 static void bww4_go(dim3 grid, hipStream_t s, const float* in, int cin, u32 in_bytes, const float* dout, int cout,
                     u32 dout_bytes, const int2* pairs, const int32_t* tile_start, int tiles_per_k, int chunk, float* dw,
-                    int bf16) {
+                    int bf16, bool det = false) {
+  if (det) {
+    if (bf16)
+      hipLaunchKernelGGL((k_spconv_bww4<MT, NTO, true, BWW4_WPB, true>), grid, dim3(BWW4_WPB * 64), 0, s, in, cin, in_bytes, dout, cout,
+                         dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
+    else
+      hipLaunchKernelGGL((k_spconv_bww4<MT, NTO, false, BWW4_WPB, true>), grid, dim3(BWW4_WPB * 64), 0, s, in, cin, in_bytes, dout, cout,
+                         dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
+    return;
+  }
   if (bf16)
     hipLaunchKernelGGL((k_spconv_bww4<MT, NTO, true, BWW4_WPB>), grid, dim3(BWW4_WPB * 64), 0, s, in, cin, in_bytes, dout, cout,
                        dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
@@ -407,31 +441,37 @@ static void bww4_go(dim3 grid, hipStream_t s, const float* in, int cin, u32 in_b
                        dout_bytes, pairs, tile_start, tiles_per_k, chunk, dw);
 }
 
-extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
-                                          int64_t n_out, const int32_t* pairs, const int32_t* tile_start, int32_t K,
-                                          int64_t map_rows, float* dw, int32_t bf16, pp_stream_t stream) {
-  PP_REQUIRE(dw && tile_start, "pp_spconv_bwd_weight_pairs: null pointer");
-  PP_REQUIRE(cin >= 1 && cout >= 1 && cout <= 192, "pp_spconv_bwd_weight_pairs: cout must be in [1,192]");
-  PP_REQUIRE((double)n_in * cin * 4.0 < 4294967040.0 && (double)n_out * cout * 4.0 < 4294967040.0,
-             "pp_spconv_bwd_weight_pairs: in and dout must be < 4 GiB each (32-bit buffer offsets)");
-  hipStream_t s = pp_s(stream);
-  PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
-  if (map_rows == 0 || n_in == 0 || n_out == 0) return PP_OK;
-  PP_REQUIRE(in && dout && pairs, "pp_spconv_bwd_weight_pairs: null pointer");
-  const int tiles_per_k = (int)((map_rows + WP_TILE - 1) / WP_TILE);
-  const int nto = (cout + 15) / 16, ntiles = (cin + 15) / 16;
-  int mt = nto <= 2 ? 4 : (nto <= 6 ? 2 : 1);
-  while (mt > 1 && ntiles % mt != 0) mt >>= 1;
-  const unsigned gz = (unsigned)(ntiles / mt);
+// launch plan of the pair-major weight gradient: ci tiles per wave (mt), pairs per wave (chunk), grid
+struct Bww4Plan {
+  int mt, nto, chunk, tiles_per_k;
+  unsigned gx, gz;
+};
+static Bww4Plan bww4_plan(int cin, int cout, int K, int64_t map_rows) {
+  Bww4Plan p;
+  p.tiles_per_k = (int)((map_rows + WP_TILE - 1) / WP_TILE);
+  p.nto = (cout + 15) / 16;
+  const int ntiles = (cin + 15) / 16;
+  p.mt = p.nto <= 2 ? 4 : (p.nto <= 6 ? 2 : 1);
+  while (p.mt > 1 && ntiles % p.mt != 0) p.mt >>= 1;
+  p.gz = (unsigned)(ntiles / p.mt);
   // an offset holds at most map_rows pairs; blocks past the end of their offset's list leave at once
   static const int chunk_env = [] { const char* e = getenv("PP_WGRAD_CHUNK"); return e ? atoi(e) : 0; }();
-  int chunk = 256;  // pairs per wave: 128 / 256 / 384 measured within 5 % of each other, 512 and 64 slower
-  if (((map_rows + 4 * chunk - 1) / (4 * chunk)) * (int64_t)K * gz < 2048) chunk = 128;
-  if (chunk_env > 0) chunk = chunk_env;
-  dim3 grid((unsigned)((map_rows + BWW4_WPB * chunk - 1) / (BWW4_WPB * chunk)), (unsigned)K, gz);
+  p.chunk = 256;  // pairs per wave: 128 / 256 / 384 measured within 5 % of each other, 512 and 64 slower
+  if (((map_rows + 4 * p.chunk - 1) / (4 * p.chunk)) * (int64_t)K * p.gz < 2048) p.chunk = 128;
+  if (chunk_env > 0) p.chunk = chunk_env;
+  p.gx = (unsigned)((map_rows + BWW4_WPB * p.chunk - 1) / (BWW4_WPB * p.chunk));
+  return p;
+}
+
+static int bww4_launch(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout, int64_t n_out,
+                       const int32_t* pairs, const int32_t* tile_start, int32_t K, const Bww4Plan& pl, float* target,
+                       int32_t bf16, bool det, hipStream_t s) {
+  const int mt = pl.mt, nto = pl.nto, tiles_per_k = pl.tiles_per_k, chunk = pl.chunk;
+  dim3 grid(pl.gx, (unsigned)K, pl.gz);
   const u32 in_bytes = (u32)((uint64_t)n_in * cin * 4u), dout_bytes = (u32)((uint64_t)n_out * cout * 4u);
+  float* dw = target;
 #define BWW4(M, N) \
-  bww4_go<M, N>(grid, s, in, cin, in_bytes, dout, cout, dout_bytes, (const int2*)pairs, tile_start, tiles_per_k, chunk, dw, bf16); break;
+  bww4_go<M, N>(grid, s, in, cin, in_bytes, dout, cout, dout_bytes, (const int2*)pairs, tile_start, tiles_per_k, chunk, dw, bf16, det); break;
   switch (mt * 16 + nto) {
     case 4 * 16 + 1: BWW4(4, 1)
     case 4 * 16 + 2: BWW4(4, 2)
@@ -455,6 +495,52 @@ extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t 
     default: BWW4(1, 12)
   }
 #undef BWW4
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                          int64_t n_out, const int32_t* pairs, const int32_t* tile_start, int32_t K,
+                                          int64_t map_rows, float* dw, int32_t bf16, pp_stream_t stream) {
+  PP_REQUIRE(dw && tile_start, "pp_spconv_bwd_weight_pairs: null pointer");
+  PP_REQUIRE(cin >= 1 && cout >= 1 && cout <= 192, "pp_spconv_bwd_weight_pairs: cout must be in [1,192]");
+  PP_REQUIRE((double)n_in * cin * 4.0 < 4294967040.0 && (double)n_out * cout * 4.0 < 4294967040.0,
+             "pp_spconv_bwd_weight_pairs: in and dout must be < 4 GiB each (32-bit buffer offsets)");
+  hipStream_t s = pp_s(stream);
+  PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
+  if (map_rows == 0 || n_in == 0 || n_out == 0) return PP_OK;
+  PP_REQUIRE(in && dout && pairs, "pp_spconv_bwd_weight_pairs: null pointer");
+  return bww4_launch(in, cin, n_in, dout, cout, n_out, pairs, tile_start, K, bww4_plan(cin, cout, K, map_rows), dw, bf16, false, s);
+}
+
+// ---- deterministic form: block partials in a caller-provided workspace + an ordered reduction (no float atomics)
+extern "C" size_t pp_spconv_bwd_weight_pairs_det_workspace(int32_t cin, int32_t cout, int32_t K, int64_t map_rows) {
+  if (cin < 1 || cout < 1 || K < 1 || map_rows <= 0) return 256;
+  const Bww4Plan pl = bww4_plan(cin, cout, K, map_rows);
+  return (size_t)pl.gx * (size_t)K * pl.gz * (size_t)(pl.mt * pl.nto) * 256u * sizeof(float) + 256;
+}
+
+extern "C" int pp_spconv_bwd_weight_pairs_det(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
+                                              int64_t n_out, const int32_t* pairs, const int32_t* tile_start, int32_t K,
+                                              int64_t map_rows, float* dw, int32_t bf16, void* ws, size_t ws_bytes,
+                                              pp_stream_t stream) {
+  PP_REQUIRE(dw && tile_start, "pp_spconv_bwd_weight_pairs_det: null pointer");
+  PP_REQUIRE(cin >= 1 && cout >= 1 && cout <= 192, "pp_spconv_bwd_weight_pairs_det: cout must be in [1,192]");
+  PP_REQUIRE((double)n_in * cin * 4.0 < 4294967040.0 && (double)n_out * cout * 4.0 < 4294967040.0,
+             "pp_spconv_bwd_weight_pairs_det: in and dout must be < 4 GiB each (32-bit buffer offsets)");
+  hipStream_t s = pp_s(stream);
+  if (map_rows == 0 || n_in == 0 || n_out == 0) {
+    PP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)K * cin * cout, s));
+    return PP_OK;
+  }
+  PP_REQUIRE(in && dout && pairs && ws, "pp_spconv_bwd_weight_pairs_det: null pointer");
+  PP_REQUIRE(ws_bytes >= pp_spconv_bwd_weight_pairs_det_workspace(cin, cout, K, map_rows),
+             "pp_spconv_bwd_weight_pairs_det: workspace too small");
+  const Bww4Plan pl = bww4_plan(cin, cout, K, map_rows);
+  int rc = bww4_launch(in, cin, n_in, dout, cout, n_out, pairs, tile_start, K, pl, (float*)ws, bf16, true, s);
+  if (rc != PP_OK) return rc;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(pl.mt * pl.nto), (unsigned)K, pl.gz), dim3(256), 0, s, (const float*)ws,
+                     tile_start, pl.tiles_per_k, BWW4_WPB * pl.chunk, (int)pl.gx, (int)pl.gz, pl.mt, pl.nto, cin, cout, dw);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

@@ -767,6 +767,11 @@ def wgrad_pairs(nbr, K, row_order=None):
     return WgradPairs(pairs, tile_start, K, rows, _pairs_of(nbr))
 
 
+# weight gradients without float atomics (PP_WGRAD_DETERMINISTIC=0: the atomic form; workspaces above the cap fall back to it)
+WGRAD_DETERMINISTIC = os.environ.get("PP_WGRAD_DETERMINISTIC", "1") != "0"
+WGRAD_DET_MAX_BYTES = int(os.environ.get("PP_WGRAD_DET_MAX_MB", "1024")) << 20
+
+
 def spconv_bwd_weight_pairs(inp, dout, wp, bf16=False):
     """dW [K, cin, cout] over the pair lists of wgrad_pairs (dout in its own row order)"""
     lib = _lib.load()
@@ -778,9 +783,17 @@ def spconv_bwd_weight_pairs(inp, dout, wp, bf16=False):
     if prof is not None:
         e0, e1 = prof.events()
         e0.record()
-    _lib.check(lib.pp_spconv_bwd_weight_pairs(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, dout.shape[0], _ptr(wp.pairs),
-                                              _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _stream()),
-               "pp_spconv_bwd_weight_pairs")
+    nbytes = lib.pp_spconv_bwd_weight_pairs_det_workspace(cin, cout, wp.K, wp.rows) if WGRAD_DETERMINISTIC else 0
+    if WGRAD_DETERMINISTIC and nbytes <= WGRAD_DET_MAX_BYTES:
+        # block partials + ordered reduction: the same bits run after run (float atomics made the loss differ in its last bits)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)
+        _lib.check(lib.pp_spconv_bwd_weight_pairs_det(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, dout.shape[0], _ptr(wp.pairs),
+                                                      _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _ptr(ws), nbytes,
+                                                      _stream()), "pp_spconv_bwd_weight_pairs_det")
+    else:
+        _lib.check(lib.pp_spconv_bwd_weight_pairs(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, dout.shape[0], _ptr(wp.pairs),
+                                                  _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _stream()),
+                   "pp_spconv_bwd_weight_pairs")
     if prof is not None:
         e1.record()
         prof.records_w.append((e0, e1, inp.shape[0], dout.shape[0], cin, cout, wp.K, wp.n_pairs))

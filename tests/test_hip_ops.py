@@ -172,6 +172,38 @@ def test_spconv_weight_gradient_shapes(ops, oracle, cin, cout):
         np.testing.assert_allclose(ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp).cpu().numpy(), want, rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (96, 96), (20, 40)])
+def test_weight_gradient_without_atomics_is_bit_reproducible(ops, oracle, monkeypatch, cin, cout):
+    """pp_spconv_bwd_weight_pairs_det (block partials in a workspace + ordered reduction, the default of the training path) gives
+    the same BITS run after run and agrees with the float-atomic form and the float64 reference; offsets without pairs and
+    blocks past the end of an offset's list contribute nothing."""
+    rng = np.random.default_rng(7 + cin)
+    fine = surface(rng, n=9000, n_batch=2, extent=60)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    for out_c, in_c, sign in [(fine, fine, 1), (coarse, fine, 1)]:
+        nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
+        nbr[5] = -1                                             # an offset without a single pair
+        x = rng.normal(size=(len(in_c), cin)).astype(np.float32)
+        g = rng.normal(size=(len(out_c), cout)).astype(np.float32)
+        want = np.zeros((27, cin, cout))
+        for k in range(27):
+            m = nbr[k] >= 0
+            want[k] = x[nbr[k][m]].astype(np.float64).T @ g[m].astype(np.float64)
+        wp = ops.wgrad_pairs(dev(nbr), 27)
+        assert ops.WGRAD_DETERMINISTIC is True
+        runs = [ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp) for _ in range(4)]
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0])
+        np.testing.assert_allclose(runs[0].cpu().numpy(), want, rtol=2e-4, atol=2e-3)
+        assert float(runs[0][5].abs().max()) == 0.0
+        monkeypatch.setattr(ops, "WGRAD_DETERMINISTIC", False)
+        atomic = ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp)
+        monkeypatch.setattr(ops, "WGRAD_DETERMINISTIC", True)
+        np.testing.assert_allclose(atomic.cpu().numpy(), runs[0].cpu().numpy(), rtol=1e-4, atol=1e-3)
+        bf = [ops.spconv_bwd_weight_pairs(dev(x), dev(g), wp, bf16=True) for _ in range(2)]
+        assert torch.equal(bf[0], bf[1])
+
+
 @pytest.mark.parametrize("cin,cout,n", [(96, 96, 900), (112, 112, 300), (64, 80, 4000), (16, 16, 40), (160, 64, 2500)])
 def test_spconv_split_k_small_launches(ops, oracle, cin, cout, n):
     """small launches take the split-K path (offsets spread over several waves, partials added in a fixed order by

@@ -269,6 +269,55 @@ def test_full_model_training_step(setup, fused):
     assert set(("loss", "semantic_loss", "offset_norm_loss", "ins_loss")) <= set(cur)
 
 
+def test_training_gradients_run_to_run(setup):
+    """Two forward + backward passes from the SAME model state and batch.  The convolutions' weight gradients no longer use
+    float atomics (pp_spconv_bwd_weight_pairs_det: block partials added in a fixed order; bit-reproducible for identical inputs,
+    tests/test_hip_ops.py::test_weight_gradient_without_atomics_is_bit_reproducible), BatchNorm statistics are float64 block
+    partials, every convolution row is summed in a fixed order -- what is left are the float-atomic segment sums inside the
+    losses (instance means of the discriminative loss, the backward of row gathers), so the loss and the gradients that flow
+    back from it agree run to run only to float rounding.  Asserted: losses equal to 1e-6, gradients to 1e-4 of their magnitude;
+    whether the loss bits agree and the share of bit-identical gradient tensors are printed."""
+    import bench
+    from panopticsegforlargescalepointcloud_amd import ops
+    from panopticsegforlargescalepointcloud_amd.applications import Data
+    s = setup
+    dev = torch.device("cuda")
+    assert ops.WGRAD_DETERMINISTIC is True
+    scene, b = s["scene"], s["b"]
+    oid = b["origin_id"]
+    inst = scene.inst[oid]
+    inst_local = np.zeros_like(inst)
+    for t in np.unique(b["batch"]):
+        m = (b["batch"] == t) & (inst > 0)
+        _, inv = np.unique(inst[m], return_inverse=True)
+        inst_local[m] = inv + 1
+    vote = (scene.inst_center[inst] - scene.pos[oid]).astype(np.float32)
+    data = Data(pos=torch.from_numpy(b["pos"]), coords=torch.from_numpy(b["coords"]), x=torch.from_numpy(b["x"]),
+                batch=torch.from_numpy(b["batch"]), y=torch.from_numpy(scene.cls[oid]),
+                instance_labels=torch.from_numpy(inst_local), instance_mask=torch.from_numpy(inst > 0),
+                vote_label=torch.from_numpy(vote), center_label=torch.from_numpy(scene.inst_center[inst]),
+                num_instances=torch.tensor([int(inst_local.max())]))
+    model = bench.build_model(dev, 0.05)[0].train()
+    for m_ in model.modules():
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            m_.momentum = 0.0                                  # (the two passes must see the same running statistics)
+    runs = []
+    for rep in range(2):
+        model.set_input(data, dev)
+        model.zero_grad(set_to_none=True)
+        model.forward(epoch=1)
+        model.backward(1)
+        runs.append((model.loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert abs(float(runs[0][0]) - float(runs[1][0])) <= 1e-6 * abs(float(runs[0][0]))
+    same = [n for n in runs[0][1] if torch.equal(runs[0][1][n], runs[1][1][n])]
+    print("loss %.7f vs %.7f (bits equal: %s); %d of %d gradient tensors bit-identical run to run" % (
+        float(runs[0][0]), float(runs[1][0]), bool(torch.equal(runs[0][0], runs[1][0])), len(same), len(runs[0][1])))
+    for n, g0 in runs[0][1].items():
+        g1 = runs[1][1][n]
+        scale = max(float(g0.abs().max()), 1e-12)
+        assert float((g0 - g1).abs().max()) <= 1e-4 * scale, n
+
+
 def test_bf16_conv_autocast_training_step_close_to_fp32():
     """ME.conv_autocast(): one training step of the full model with bfloat16 convolution compute gives a loss and
     gradients close to the fp32 step (bf16 operand rounding only), and differs from it (the bf16 kernels really ran)."""
