@@ -1041,6 +1041,10 @@ def nms_paint(csr, n_points, batch, n_groups, scores, nms_threshold=0.3, min_clu
     rank = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
     if pairs is None and P:
         pairs = proposal_pairs(csr, n_points)
+    ev = getattr(pairs, "ready", None)
+    if ev is not None:  # the table was built on another stream (PointGroup3heads._pairs_async)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        pairs.ready = None
     scores = None if scores is None else _need(scores.detach().float(), torch.float32, "scores")
     batch = _need(batch, torch.int64, "batch")
     cap = pairs.capacity if pairs is not None else 0

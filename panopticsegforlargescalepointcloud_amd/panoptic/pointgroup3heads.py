@@ -33,6 +33,63 @@ FUSE_HEADS = os.environ.get("PP_FUSE_HEADS", "1") != "0"  # all heads in one pas
 OVERLAP_CLUSTERING = os.environ.get("PP_CLUSTER_OVERLAP", "1") != "0"  # mean shift on a side stream next to region growing
 
 
+DEDUPE_HASH = os.environ.get("PP_DEDUPE_HASH", "1") != "0"
+
+
+def _duplicate_representatives_from_pairs(csr, n_points):
+    """the first form: two proposals are identical when their intersection equals both sizes (ops.proposal_pairs)"""
+    pairs = ops.proposal_pairs(csr, n_points)  # device-side; reused by the NMS of this batch
+    sz = csr.sizes()
+    n_prop = csr.n
+    valid = torch.arange(pairs.capacity, device=sz.device) < pairs.n_pairs
+    a = torch.where(valid, pairs.a.long(), 0)
+    b = torch.where(valid, pairs.b.long(), 0)
+    inter = pairs.inter.long()
+    dup = valid & (inter == sz[a]) & (inter == sz[b])
+    # non-duplicates go to private slots behind the proposals (one shared dump slot would serialise ~10^5 atomics)
+    slot = torch.arange(pairs.capacity, device=sz.device)
+    rep = torch.arange(n_prop + pairs.capacity, device=sz.device)
+    rep.scatter_reduce_(0, torch.where(dup, b, n_prop + slot), torch.where(dup, a, n_prop + slot), "amin", include_self=True)
+    return rep[:n_prop]
+
+
+def _duplicate_representatives(csr):
+    """rep int64 [P]: the smallest index of a proposal with exactly the same point list (rep[p] == p for the first of its kind).
+    Device only, no host synchronisation.  Candidates = equal (size, hash1, hash2) with two independent 64-bit sum hashes of the
+    point ids (order-free, exact integer arithmetic); each candidate is verified entry by entry against its representative."""
+    dev = csr.points.device
+    n = csr.n
+    sz = csr.sizes().long()
+    pts = csr.points.long()
+    total = int(pts.numel())
+    ids = torch.arange(n, device=dev)
+    owner = torch.repeat_interleave(ids, sz, output_size=total)
+    m1 = (pts + 0x165667B19E3779F9) * -0x61C8864680B583EB          # (int64 arithmetic wraps: that is the hash)
+    m1 = m1 ^ (m1 >> 29)
+    m2 = (pts ^ 0x27D4EB2F165667C5) * -0x3A8F057B4E4F7C2B
+    m2 = m2 ^ (m2 >> 31)
+    offs = csr.offsets.long()
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def seg_sum(v):  # per-proposal sums as differences of one prefix sum (wrapping int64 arithmetic: exact); an index_add_ would
+        cs = torch.cat([zero, torch.cumsum(v, 0)])  # serialise ~10^3 atomics per address
+        return cs[offs[1:]] - cs[offs[:-1]]
+    h1, h2 = seg_sum(m1), seg_sum(m2)
+    key = h1 ^ (h2 * -0x4B47B4E4F7C2B1D5) ^ (sz * -0x61C8864680B583EB)
+    skey, order = torch.sort(key, stable=True)                       # equal keys keep ascending proposal index
+    same_as_prev = torch.zeros(n, dtype=torch.bool, device=dev)
+    same_as_prev[1:] = (skey[1:] == skey[:-1]) & (sz[order][1:] == sz[order][:-1]) & (h1[order][1:] == h1[order][:-1]) \
+        & (h2[order][1:] == h2[order][:-1])
+    start_pos = torch.cummax(torch.where(same_as_prev, torch.zeros_like(ids), ids), 0)[0]   # position of the group's first member
+    rep = torch.empty(n, dtype=torch.int64, device=dev)
+    rep[order] = order[start_pos]
+    # exact verification: entry j of p against entry j of rep[p]
+    pos_in = torch.arange(total, device=dev) - offs[owner]
+    other = pts[(offs[rep[owner]] + pos_in).clamp_(max=total - 1)]
+    mismatch = seg_sum((other != pts).long())
+    return torch.where(mismatch > 0, ids, rep)
+
+
 class PointGroup3heads(nn.Module):
     HEADS = ("Semantic", "Offset", "Embed")  # the 2-head classes of settings I-III narrow this (panoptic/variants.py)
     __REQUIRED_DATA__ = ["pos"]
@@ -285,29 +342,43 @@ class PointGroup3heads(nn.Module):
             raise NotImplementedError("scorer_type %s (the reference knows 'unet', 'MLP' and 'encoder')" % self._scorer_type)
         if self.dedupe_proposals and not torch.is_grad_enabled() and csr.n > 1 and not self.mask_supervise:
             # Region growing and mean shift often return the SAME point set for a well-separated instance; identical
-            # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set
-            # (results unchanged; the overlap pairs are reused by NMS).
-            pairs = ops.proposal_pairs(csr, backbone_features.shape[0])  # device-side; reused by the NMS of this batch
-            sz = csr.sizes()
-            n_prop = csr.n
-            valid = torch.arange(pairs.capacity, device=sz.device) < pairs.n_pairs
-            a = torch.where(valid, pairs.a.long(), 0)
-            b = torch.where(valid, pairs.b.long(), 0)
-            inter = pairs.inter.long()
-            dup = valid & (inter == sz[a]) & (inter == sz[b])
-            # non-duplicates go to private slots behind the proposals (one shared dump slot would serialise ~10^5 atomics
-            # on a single address: 1.6 ms per step)
-            slot = torch.arange(pairs.capacity, device=sz.device)
-            rep = torch.arange(n_prop + pairs.capacity, device=sz.device)
-            rep.scatter_reduce_(0, torch.where(dup, b, n_prop + slot), torch.where(dup, a, n_prop + slot), "amin", include_self=True)
-            rep = rep[:n_prop]
-            uniq_ids = torch.nonzero(rep == torch.arange(csr.n, device=sz.device)).view(-1)
+            # proposals get identical ScorerUnet inputs, hence identical scores: score one representative per set.
+            # Round 4: duplicates are found through (size, two 64-bit sum hashes of the point ids) -- three passes over the
+            # CSR entries and a sort of the ~10^3 proposals -- and every candidate is then verified entry by entry against its
+            # representative, so the result is exact (a mismatch, i.e. a hash collision or differently ordered lists, simply
+            # keeps the proposal).  The overlap-pair pass the first form was built on (0.9 ms, needed by NMS anyway) no longer
+            # sits in front of the scorer: it runs on a side stream next to the scorer's convolutions.
+            if DEDUPE_HASH:
+                rep = _duplicate_representatives(csr)
+                self._pairs_async(csr, backbone_features.shape[0])
+            else:  # round-3 form (A/B runs): duplicates from the overlap pairs, on the scorer's critical path
+                rep = _duplicate_representatives_from_pairs(csr, backbone_features.shape[0])
+            uniq_ids = torch.nonzero(rep == torch.arange(csr.n, device=rep.device)).view(-1)
             if uniq_ids.numel() < csr.n:
-                pos_of = torch.empty(csr.n, dtype=torch.int64, device=sz.device)
-                pos_of[uniq_ids] = torch.arange(uniq_ids.numel(), device=sz.device)
+                pos_of = torch.empty(csr.n, dtype=torch.int64, device=rep.device)
+                pos_of[uniq_ids] = torch.arange(uniq_ids.numel(), device=rep.device)
                 scores_u, _ = self._score_unique(csr.select(uniq_ids), backbone_features)
                 return scores_u[pos_of[rep]], None
         return self._score_unique(csr, backbone_features, epoch)
+
+    def _pairs_async(self, csr, n_points):
+        """ops.proposal_pairs(csr) on the clustering side stream: NMS (scene.instance_labels_per_tile -> ops.nms_paint) finds the
+        table cached on the csr; its consumer stream waits for the event recorded here."""
+        if getattr(csr, "_pairs", None) is not None or not csr.points.is_cuda or not OVERLAP_CLUSTERING:
+            return
+        dev = csr.points.device
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams.get(dev)
+        if side is None:
+            side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pairs = ops.proposal_pairs(csr, n_points)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in (pairs.a, pairs.b, pairs.inter, pairs.n_pairs, pairs.prop_of_entry, pairs.info):
+            t.record_stream(main)  # allocated on the side stream, read by the NMS kernels of the main stream
+        pairs.ready = ev
 
     def _score_unique(self, csr, backbone_features, epoch=-1):
         sizes = csr.sizes()
