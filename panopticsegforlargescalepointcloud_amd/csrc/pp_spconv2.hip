@@ -53,8 +53,8 @@ __device__ __forceinline__ unsigned pp_row_or16(unsigned v) {
 #define F3_WPB 4
 #endif
 
-// C4: the 4-channel input layer (rows of 16 bytes).  A step is one kernel offset with ONE fp32 MFMA per tile (k = the four
-// channels): lane (i, q) loads channel q of its row and weight [q][column i] as single dwords.
+// C4: the 4-channel input layer (rows of 16 bytes).  A step is a GROUP of four kernel offsets: lane (i, q) loads the whole row
+// of offset 4 g + q with one dwordx4; the MFMA's k index is the offset inside the group, its four issues are the channels.
 // DS: fused 1x1 shortcut (SpconvArgs::ds_*): after the offset loop the wave multiplies ITS OWN rows of ds_in (no gather: a
 // same-level map's output row is the input row) with the packed 1x1 weights into a second set of accumulators.
 // S1: the input has ONE 16-channel step (c0 == 16, no second source): a step is a kernel offset, the source descriptor is
@@ -293,7 +293,62 @@ __global__ __launch_bounds__(64 * F3_WPB, 2) void k_spconv_fwd3(SpconvArgs a, un
     int more = 1;  // an int, not a bool: hipcc keeps bools as 64-bit lane masks (4 scalar instructions per test)
     // The loads are unconditional: after the last step the load side simply re-reads a valid step.  (A branch around
     // them makes hipcc merge the two paths' outstanding-load counts and wait for the NEW loads before the MFMAs.)
-    if constexpr (S1) {
+    if constexpr (C4) {
+      // ---- the 4-channel input layer, FOUR kernel offsets per step (round 4).  A row is 16 bytes: lane (i, q) loads the whole
+      // row of neighbour offset 4 g + q of its row i with ONE dwordx4, so the MFMA's k index is the offset inside the group and
+      // its four issues t are the four channels: D^T[col][row] += sum_q W[4g+q][t][col] * in[nbr_{4g+q}(row)][t].  7 steps instead
+      // of 27, each with T 16-byte gathers instead of 4 T 4-byte ones (the layer was bound by its load instructions: 0.06 of
+      // the MFMA peak).  The weights keep the mode-4 packing: lane (col i, q) reads W[4g+q][t][col] as four dwords.
+      (void)sl; (void)more; (void)vo; (void)kl;
+      if (a.split > 1) {
+        // split-K: a group may straddle this block's offset range; the offsets outside it are made absent in the table (the
+        // group mask below only drops whole groups).  LDS operations of a wave execute in program order
+#pragma unroll 1
+        for (int k = 0; k < F2_MAXK; ++k)
+          if (!((kmask >> k) & 1u))
+            for (int r = lane; r < R; r += 64) off[k][r] = F3_MISSING;
+      }
+      const unsigned wrow = (unsigned)a.NT * 256u;                       // bytes of packed weights per offset
+      const unsigned vb = (unsigned)q * wrow + (unsigned)i * 4u;         // lane part of the weight address
+      const __amdgpu_buffer_rsrc_t rc4 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)a_bytes, 0x00020000);
+      unsigned remg = 0;
+#pragma unroll
+      for (int g = 0; g < 7; ++g) remg |= ((rem >> (4 * g)) & 15u) ? 1u << g : 0u;
+#define C4_LOADS(G, AX, BX)                                                                                       \
+  {                                                                                                               \
+    _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                              \
+        AX[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc4, (int)off[4 * (G) + q][tt * 16 + i], 0, 0)); \
+    _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) _Pragma("unroll") for (int t = 0; t < 4; ++t)              \
+        BX[jt][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                               \
+            rw, (int)(vb + t * 64u), (int)((unsigned)(4 * (G) * a.NT + jt0 + jt) * 256u), 0));                    \
+  }
+#define C4_MFMAS(G, AX, BX)                                                                                       \
+  _Pragma("unroll") for (int tt = 0; tt < T; ++tt) {                                                              \
+    if ((m[tt] >> (4 * (G))) & 15u) {                                                                             \
+      _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) _Pragma("unroll") for (int t = 0; t < 4; ++t)            \
+          acc[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(BX[jt][t], AX[tt][t], acc[tt][jt], 0, 0, 0);         \
+    }                                                                                                             \
+  }
+      int g0 = __builtin_ctz(remg), g1 = g0;
+      unsigned rg = remg & (remg - 1u);
+      C4_LOADS(g0, A0, B0);
+      for (;;) {
+        const int h1 = rg != 0u;
+        g1 = h1 ? __builtin_ctz(rg) : g0;
+        rg &= rg - 1u;
+        C4_LOADS(g1, A1, B1);
+        C4_MFMAS(g0, A0, B0);
+        if (!h1) break;
+        const int h0 = rg != 0u;
+        g0 = h0 ? __builtin_ctz(rg) : g1;
+        rg &= rg - 1u;
+        C4_LOADS(g0, A0, B0);
+        C4_MFMAS(g1, A1, B1);
+        if (!h0) break;
+      }
+#undef C4_LOADS
+#undef C4_MFMAS
+    } else if constexpr (S1) {
       static_assert(!C4 && D == 3, "S1 is the depth-3 loop of the 16-channel layers");
       const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in0, 0, (int)a_bytes, 0x00020000);
 #define S1_LOADS(AX, BX, KK)                                                                                     \
