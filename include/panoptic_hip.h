@@ -162,9 +162,12 @@ int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* b
  *                    are stored in the level's own row order, so their convolutions need no indirection)
  * Cross-level maps stay slot-major and pp_spconv_fwd takes `order` as row_order.  Results never depend on the order. */
 int32_t pp_map_window(void);
-int pp_map_set_window(int32_t window /*1024 | 2048 | 4096 | 8192 (default)*/);
+int pp_map_set_window(int32_t window /*a power of two in [1024, 32768]; 8192 by default*/);
 int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, pp_stream_t stream);
 int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_stream_t stream);
+/* the same with an explicit window (a power of two in [1024, 32768]): the levels' own (same-level) maps take larger windows than
+ * the cross-level ones, whose convolutions scatter output rows inside a window; pp_map_permute takes the window used here */
+int pp_map_order_window(const uint32_t* mask, int64_t n, int32_t window, int32_t* order, pp_stream_t stream);
 int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
                    int32_t window, int32_t* out, pp_stream_t stream);
 int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,

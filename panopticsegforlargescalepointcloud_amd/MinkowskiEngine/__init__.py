@@ -35,6 +35,12 @@ COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
 # maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
 MAP_ORDER = os.environ.get("PP_MAP_ORDER", "1") != "0"
 MAP_ORDER_MIN_ROWS = int(os.environ.get("PP_MAP_ORDER_MIN_ROWS", "50000"))  # smaller levels gain nothing from it
+# rows per sort window of a level's OWN order (its same-level map; 1024 .. 32768).  Purer 16-row tiles with larger windows
+# (executed / useful tile rows at tensor stride 1: 2.00 at 8192, 1.82 at 32768, profiles/r03_row_cache_model.txt) while the
+# rows one XCD has in flight (~40 k) span the window either way.  Cross-level maps keep pp_map_window().
+# PP_SAME_WINDOW = "<tensor stride 1>,<coarser levels>" (or one number for both).
+_sw = [int(v) for v in os.environ.get("PP_SAME_WINDOW", "16384,32768").split(",")]
+SAME_WINDOW = (_sw[0], _sw[-1])
 if os.environ.get("PP_MAP_WINDOW"):  # rows per sort window (1024 | 2048 | 4096 | 8192), A/B runs
     ops._lib.check(ops._lib.load().pp_map_set_window(int(os.environ["PP_MAP_WINDOW"])), "pp_map_set_window")
 # compute dtype of the sparse convolutions: "fp32" (the reference's; parity runs) or "bf16" (BASELINE.json configs[4]):
@@ -124,7 +130,7 @@ def _order_level(coords_m, index, ts):
     onto the level only needs its row order, so the caller can build it first (the scorer's first convolution is strided
     and waits for exactly that chain)."""
     nbr_m = ops.kernel_map_bi(coords_m, index, 3, ts, 1, want_mask=True)
-    order = ops.map_order(nbr_m.pp_mask)
+    order = ops.map_order(nbr_m.pp_mask, window=SAME_WINDOW[0 if ts == 1 else 1])
     del nbr_m.pp_mask
     coords_p, phys_of = ops.level_permute(coords_m, order)
     return coords_p, order, phys_of, lambda: ops.map_permute(nbr_m, order, translate=phys_of)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "pp_map_window": (i32, []),
     "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
     "pp_map_order": (C.c_int, [vp, i64, vp, vp]),
+    "pp_map_order_window": (C.c_int, [vp, i64, i32, vp, vp]),
     "pp_map_set_window": (C.c_int, [i32]),
     "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i32, vp, vp]),
     "pp_level_permute": (C.c_int, [vp, i64, vp, vp, vp, vp]),

@@ -425,12 +425,16 @@ __device__ inline int hd_find(int32_t* uf, int x) {
   return r;
 }
 
-__global__ __launch_bounds__(HD_TPB) void k_hd_tree(HDTree T) {
+// One WAVE per sample: the tree phases are a serial walk (lane 0), the fills before and the label gather after it use the 64
+// lanes.  (The first version launched 256 threads per sample: three of a workgroup's four waves only took part in the fills and
+// held their slots for the whole serial walk -- a CU ran 8 samples at a time instead of 32.)
+#define HD_TREE_TPB 64
+__global__ __launch_bounds__(HD_TREE_TPB) void k_hd_tree(HDTree T) {
   const int s = blockIdx.x;
   const int lo = T.offs[s], n = T.offs[s + 1] - lo;
   int32_t* labels = T.labels + lo;
   if (!T.sample_ok[s]) {
-    for (int i = threadIdx.x; i < n; i += HD_TPB) labels[i] = -1;
+    for (int i = threadIdx.x; i < n; i += HD_TREE_TPB) labels[i] = -1;
     if (threadIdx.x == 0) T.n_clusters[s] = 0;
     return;
   }
@@ -449,11 +453,11 @@ __global__ __launch_bounds__(HD_TPB) void k_hd_tree(HDTree T) {
   double* stab = T.stab + lo;
   double* csum = T.csum + lo;
   const int nn = 2 * n - 1;
-  for (int i = threadIdx.x; i < nn; i += HD_TPB) {
+  for (int i = threadIdx.x; i < nn; i += HD_TREE_TPB) {
     uf[i] = i;
     size[i] = i < n ? 1 : 0;
   }
-  for (int i = threadIdx.x; i < n; i += HD_TPB) {
+  for (int i = threadIdx.x; i < n; i += HD_TREE_TPB) {
     stab[i] = 0.0;
     csum[i] = 0.0;
     flags[i] = 0;
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(HD_TPB) void k_hd_tree(HDTree T) {
     T.n_clusters[s] = nl;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += HD_TPB) labels[i] = lab[pclus[i]];
+  for (int i = threadIdx.x; i < n; i += HD_TREE_TPB) labels[i] = lab[pclus[i]];
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
@@ -740,7 +744,7 @@ extern "C" int pp_hdbscan(const float* x, int64_t m, int32_t dim, const int64_t*
   T.n_clusters = n_clusters;
   T.min_cluster_size = min_cluster_size;
   T.eps = cluster_selection_epsilon;
-  k_hd_tree<<<ns, HD_TPB, 0, st>>>(T);
+  k_hd_tree<<<ns, HD_TREE_TPB, 0, st>>>(T);
   PP_LAUNCH_CHECK();
   return PP_OK;
 }

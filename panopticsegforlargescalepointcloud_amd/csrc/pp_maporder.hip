@@ -19,7 +19,6 @@
 // convolution do not depend on the row order (every output row is still written exactly once, same summation order).
 #include "pp_common.h"
 
-#define MO_IDX_BITS 13           // rows per window <= 8192
 #define MO_MASK_BITS 27
 static int g_window = 8192;      // rows per window = keys per workgroup (8 B of LDS each); pp_map_set_window
 
@@ -161,10 +160,168 @@ __global__ __launch_bounds__(W / 8) void k_window_sort(const uint32_t* __restric
   }
 }
 
+
+// ---- window sort, 16384 / 32768 rows per window -------------------------------------------------------------------------
+// The same stable LSD radix sort with W / 1024 rows per thread.  Keys and row indices no longer fit the LDS side by side
+// (6 bytes x 32768), and a workgroup that takes most of a CU's LDS waits for the convolution workgroups it runs beside to
+// drain: the exchange goes through ONE 16-bit buffer (64 KiB at 32768 rows) in up to three rounds per pass -- the row index,
+// the high half of the key, and the low half while later passes still need it (from bit 16 on they do not).
+template <int W, int NT>
+__global__ __launch_bounds__(NT) void k_window_sort_big(const uint32_t* __restrict__ mask, int64_t n, int32_t* __restrict__ order) {
+  constexpr int RPT = W / NT, NW = NT / 64;
+  static_assert(RPT % 8 == 0 && W <= 32768, "rows per thread in groups of eight; 15-bit row index");
+  __shared__ __attribute__((aligned(16))) unsigned short xl[W];
+  __shared__ unsigned long long wtot[NW];
+  __shared__ int fcnt[MO_MASK_BITS];
+  __shared__ int fpos[MO_MASK_BITS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t base = (int64_t)blockIdx.x * W;
+  const int cnt = (int)((n - base) < W ? (n - base) : W);
+  // per row: the key and one word holding the row index (low half) and, during a pass, the row's new position (high half).
+  // 32768 rows run as 512 threads x 64 rows: a 1024-thread workgroup has 128 registers per thread, 32 rows x (key, index /
+  // position) + the 64-bit packed counters do not fit them (121 spilled registers), a 512-thread one has 256
+  uint32_t key[RPT], ip[RPT];
+  if (t < MO_MASK_BITS) fcnt[t] = 0;
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int e = t * RPT + r;
+    const uint32_t m = mask[base + (e < cnt ? e : 0)] & 0x7FFFFFFu;  // branch-free: a select, not a guarded load
+    key[r] = e < cnt ? m : 0u;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < MO_MASK_BITS; ++k) {
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) c += __popcll(__ballot((key[r] >> k) & 1u));
+    if (lane == 0 && c) atomicAdd(&fcnt[k], c);
+  }
+  __syncthreads();
+  if (t < MO_MASK_BITS) {  // rarest offset of the window = most significant key bit (k_window_sort)
+    const int f = fcnt[t];
+    int p = 0;
+    for (int j = 0; j < MO_MASK_BITS; ++j) {
+      const int fj = fcnt[j];
+      p += (fj > f || (fj == f && j < t)) ? 1 : 0;
+    }
+    fpos[t] = p;
+  }
+  __syncthreads();
+  int nbits = 0;
+  for (int k = 0; k < MO_MASK_BITS; ++k) nbits += fcnt[k] > 0 ? 1 : 0;
+  nbits = __builtin_amdgcn_readfirstlane(nbits);
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) ip[r] = 0u;
+#pragma unroll 1
+  for (int k = 0; k < MO_MASK_BITS; ++k) {
+    const int p = __builtin_amdgcn_readfirstlane(fpos[k]);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) ip[r] |= ((key[r] >> k) & 1u) << p;
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    key[r] = (t * RPT + r) < cnt ? ip[r] : 0x7FFFFFFu;  // padding: the largest key, behind its equals
+    ip[r] = (uint32_t)(t * RPT + r);
+  }
+
+  // one exchange round: every row's 16-bit value goes to its new position, the thread reads back its RPT consecutive ones
+#define MOB_EXCHANGE(PUT, GET)                                                              \
+  {                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < RPT; ++r) {                                       \
+      asm volatile("" : "+v"(ip[r])); /* the address is re-derived per round, not kept (a register per row) */ \
+      xl[ip[r] >> 16] = (unsigned short)(PUT);                                              \
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0); /* keeps the 32 addresses from being formed at once */ \
+    }                                                                                       \
+    __syncthreads();                                                                        \
+    _Pragma("unroll") for (int v = 0; v < RPT / 8; ++v) {                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      const uint4 x_ = *(const uint4*)&xl[t * RPT + 8 * v];                                 \
+      const uint32_t w_[4] = {x_.x, x_.y, x_.z, x_.w};                                      \
+      _Pragma("unroll") for (int h = 0; h < 8; ++h) {                                       \
+        const int r = 8 * v + h;                                                            \
+        const uint32_t g_ = (w_[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;                       \
+        GET;                                                                                \
+      }                                                                                     \
+    }                                                                                       \
+    __syncthreads();                                                                        \
+  }
+#pragma unroll 1
+  for (int bit = 0; bit < nbits; bit += 2) {
+    unsigned long long c = 0;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int sh = (int)((key[r] >> bit) & 3u) * 16;
+      ip[r] = (ip[r] & 0xFFFFu) | ((uint32_t)((c >> sh) & 0xFFFFull) << 16);
+      c += 1ull << sh;
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (hipcc would form all 32 shifted ones first: 64 registers)
+    }
+    unsigned long long incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long v = (unsigned long long)__shfl_up((long long)incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned long long v = wtot[w];
+      if (w < wave) woff += v;
+      total += v;
+    }
+    const unsigned long long t0 = total & 0xFFFFull, t1 = (total >> 16) & 0xFFFFull, t2 = (total >> 32) & 0xFFFFull;
+    const unsigned long long pb = incl - c + woff + ((t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48));
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      asm volatile("" : "+v"(key[r]));  // the digit is re-derived, not kept from the counting loop (a register per row)
+      const int sh = (int)((key[r] >> bit) & 3u) * 16;
+      ip[r] += (uint32_t)((pb >> sh) & 0xFFFFull) << 16;  // position < W <= 2^15: no carry out of the word
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // the new row indices land in the low halves only after every old one has been sent: a second word per row would be
+    // the third array, so they wait in the exchange buffer's readback (g_) and replace the low half in place -- the high
+    // half (position) is still needed by the key rounds
+    MOB_EXCHANGE(ip[r], ip[r] = (ip[r] & 0xFFFF0000u) | g_);
+    const bool lo = bit + 2 < 16 && bit + 2 < nbits;  // a later pass still reads the low half
+    if (nbits > 16) {
+      if (lo) {
+        // the received high half replaces the one just sent; the low half of the word is still the OLD row's until its round
+        MOB_EXCHANGE(key[r] >> 16, key[r] = (g_ << 16) | (key[r] & 0xFFFFu));
+        MOB_EXCHANGE(key[r], key[r] = (key[r] & 0xFFFF0000u) | g_);
+      } else {
+        MOB_EXCHANGE(key[r] >> 16, key[r] = g_ << 16);
+      }
+    } else if (lo) {
+      MOB_EXCHANGE(key[r], key[r] = g_);
+    }
+  }
+#undef MOB_EXCHANGE
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int e = t * RPT + r;
+    if (e < cnt) order[base + e] = (int32_t)(base + (ip[r] & 0xFFFFu));
+  }
+}
+
+static bool map_window_ok(int w) { return w >= 1024 && w <= 32768 && (w & (w - 1)) == 0; }
 extern "C" int32_t pp_map_window(void) { return g_window; }
 extern "C" int pp_map_set_window(int32_t window) {
-  PP_REQUIRE(window == 1024 || window == 2048 || window == 4096 || window == 8192, "pp_map_set_window: 1024, 2048, 4096 or 8192");
+  PP_REQUIRE(map_window_ok(window), "pp_map_set_window: a power of two in [1024, 32768]");
   g_window = window;
+  return PP_OK;
+}
+
+static int map_order_launch(const uint32_t* mask, int64_t n, int window, int32_t* order, hipStream_t s) {
+  switch (window) {
+    case 1024: hipLaunchKernelGGL(k_window_sort<1024>, dim3(pp_blocks(n, 1024)), dim3(128), 0, s, mask, n, order); break;
+    case 2048: hipLaunchKernelGGL(k_window_sort<2048>, dim3(pp_blocks(n, 2048)), dim3(256), 0, s, mask, n, order); break;
+    case 4096: hipLaunchKernelGGL(k_window_sort<4096>, dim3(pp_blocks(n, 4096)), dim3(512), 0, s, mask, n, order); break;
+    case 8192: hipLaunchKernelGGL(k_window_sort<8192>, dim3(pp_blocks(n, 8192)), dim3(1024), 0, s, mask, n, order); break;
+    case 16384: hipLaunchKernelGGL((k_window_sort_big<16384, 1024>), dim3(pp_blocks(n, 16384)), dim3(1024), 0, s, mask, n, order); break;
+    default: hipLaunchKernelGGL((k_window_sort_big<32768, 512>), dim3(pp_blocks(n, 32768)), dim3(512), 0, s, mask, n, order); break;
+  }
+  PP_LAUNCH_CHECK();
   return PP_OK;
 }
 
@@ -172,15 +329,16 @@ extern "C" int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_
   PP_REQUIRE((mask && order) || n == 0, "pp_map_order: null pointer");
   PP_REQUIRE(n < (1ll << 31), "pp_map_order: more than 2^31 rows");
   if (n == 0) return PP_OK;
-  hipStream_t s = pp_s(stream);
-  switch (g_window) {
-    case 1024: hipLaunchKernelGGL(k_window_sort<1024>, dim3(pp_blocks(n, 1024)), dim3(128), 0, s, mask, n, order); break;
-    case 2048: hipLaunchKernelGGL(k_window_sort<2048>, dim3(pp_blocks(n, 2048)), dim3(256), 0, s, mask, n, order); break;
-    case 4096: hipLaunchKernelGGL(k_window_sort<4096>, dim3(pp_blocks(n, 4096)), dim3(512), 0, s, mask, n, order); break;
-    default: hipLaunchKernelGGL(k_window_sort<8192>, dim3(pp_blocks(n, 8192)), dim3(1024), 0, s, mask, n, order); break;
-  }
-  PP_LAUNCH_CHECK();
-  return PP_OK;
+  return map_order_launch(mask, n, g_window, order, pp_s(stream));
+}
+// the same with an explicit window (1024 .. 32768 rows, a power of two): the levels' same-level maps take larger windows than
+// the cross-level ones, whose convolutions scatter their output rows inside a window
+extern "C" int pp_map_order_window(const uint32_t* mask, int64_t n, int32_t window, int32_t* order, pp_stream_t stream) {
+  PP_REQUIRE((mask && order) || n == 0, "pp_map_order_window: null pointer");
+  PP_REQUIRE(n < (1ll << 31), "pp_map_order_window: more than 2^31 rows");
+  PP_REQUIRE(map_window_ok(window), "pp_map_order_window: window must be a power of two in [1024, 32768]");
+  if (n == 0) return PP_OK;
+  return map_order_launch(mask, n, window, order, pp_s(stream));
 }
 
 // ---- applying an order -----------------------------------------------------------------------------------------------------
@@ -243,6 +401,72 @@ __global__ __launch_bounds__(1024) void k_map_permute_win(const int32_t* __restr
     }
   }
 }
+// 16384 / 32768 rows per window: the window's slice of one offset (64 / 128 KiB) does not fit the LDS beside the convolution's
+// workgroups, so it passes through a 32 KiB buffer in quarters of 8192 source rows; every thread keeps the (window-local)
+// source rows of its W / 1024 slots in registers and picks its values out of the quarter that holds them.  Translation is a
+// global gather (the window's slice of `translate` would be another 128 KiB).
+template <int W>
+__global__ __launch_bounds__(1024) void k_map_permute_big(const int32_t* __restrict__ nbr, int K, int64_t n,
+                                                          const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
+                                                          int32_t* __restrict__ out) {
+  constexpr int NT = 1024, PER = W / NT, QW = 8192, SPT = QW / NT;
+  __shared__ int32_t cur[QW];
+  const int t = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * W;
+  const int cnt = (int)((n - base) < W ? (n - base) : W);
+  const int nq = (cnt + QW - 1) / QW;
+  uint32_t ord2[PER / 2];  // two 16-bit window-local source rows per word
+#pragma unroll
+  for (int u = 0; u < PER / 2; ++u) ord2[u] = 0u;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int j = t + NT * u;
+    // slots past the end: 0xFFFF, a row of the last quarter that the stores below skip
+    ord2[u >> 1] |= (j < cnt ? (uint32_t)(order[base + j] - (int32_t)base) : 0xFFFFu) << ((u & 1) * 16);
+  }
+  int32_t stage[SPT];
+#pragma unroll
+  for (int v = 0; v < SPT; ++v) {
+    const int e = t + NT * v;
+    stage[v] = e < cnt ? nbr[base + e] : -1;
+  }
+  for (int k = 0; k < K; ++k) {
+    int32_t val[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) val[u] = -1;
+    for (int q = 0; q < nq; ++q) {
+      __syncthreads();  // the previous quarter has been read
+#pragma unroll
+      for (int v = 0; v < SPT; ++v) cur[t + NT * v] = stage[v];
+      __syncthreads();
+      // next quarter's (or next offset's first quarter's) loads in flight while this one is picked apart
+      const int qn = q + 1 < nq ? q + 1 : 0, kn = q + 1 < nq ? k : k + 1;
+      if (kn < K) {
+        const int32_t* src = nbr + (int64_t)kn * n + base;
+#pragma unroll
+        for (int v = 0; v < SPT; ++v) {
+          const int e = qn * QW + t + NT * v;
+          stage[v] = e < cnt ? src[e] : -1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t o = (ord2[u >> 1] >> ((u & 1) * 16)) & 0xFFFFu;
+        if ((o >> 13) == (uint32_t)q) val[u] = cur[o & (QW - 1)];
+      }
+    }
+    int32_t* dst = out + (int64_t)k * n + base;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int j = t + NT * u;
+      if (j < cnt) {
+        int32_t v = val[u];
+        if (translate && v >= 0) v = translate[v];
+        dst[j] = v;
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void k_map_permute(const int32_t* __restrict__ nbr, int K, int64_t n,
                                                      const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
                                                      int32_t* __restrict__ out) {
@@ -264,9 +488,11 @@ extern "C" int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, cons
   if (n_out == 0) return PP_OK;
   hipStream_t s = pp_s(stream);
   if (order && window > 0) {
-    PP_REQUIRE(window == 1024 || window == 2048 || window == 4096 || window == 8192, "pp_map_permute: bad window");
+    PP_REQUIRE(map_window_ok(window), "pp_map_permute: bad window");
     const dim3 grid(pp_blocks(n_out, window));
     switch (window) {
+      case 16384: hipLaunchKernelGGL(k_map_permute_big<16384>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
+      case 32768: hipLaunchKernelGGL(k_map_permute_big<32768>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
       case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
       case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
       case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;

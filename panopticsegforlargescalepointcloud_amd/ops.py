@@ -410,16 +410,20 @@ def map_mask(nbr):
     return mask[:n_out]
 
 
-def map_order(mask):
+def map_order(mask, window=None):
     """slot order of a kernel map (csrc/pp_maporder.hip): order[s] = output row taking slot s.  Rows are sorted by
-    (neighbour mask, row) inside windows of pp_map_window() consecutive rows."""
+    (neighbour mask, row) inside windows of `window` (default pp_map_window()) consecutive rows."""
     lib = _lib.load()
     mask = _need(mask, torch.int32, "mask")
     n = mask.shape[0]
     order = torch.empty(max(n, 1), dtype=torch.int32, device=mask.device)
-    _lib.check(lib.pp_map_order(_ptr(mask), n, _ptr(order), _stream()), "pp_map_order")
+    if window is None:
+        window = int(lib.pp_map_window())
+        _lib.check(lib.pp_map_order(_ptr(mask), n, _ptr(order), _stream()), "pp_map_order")
+    else:
+        _lib.check(lib.pp_map_order_window(_ptr(mask), n, int(window), _ptr(order), _stream()), "pp_map_order_window")
     order = order[:n]
-    order.pp_window = int(lib.pp_map_window())  # map_permute stages window slices in LDS
+    order.pp_window = int(window)  # map_permute stages window slices in LDS
     return order
 
 

@@ -49,3 +49,6 @@ print(s.getvalue()[:8000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats(35)
 print(s.getvalue()[:7000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_callers(r"method '(to|tolist|item|cpu)' of")
+print(s.getvalue()[:6000])

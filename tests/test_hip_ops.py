@@ -857,6 +857,32 @@ def test_map_order_and_slot_ordered_maps(ops, oracle):
             np.testing.assert_allclose(b.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("window", [16384, 32768])
+def test_map_order_large_windows(ops, oracle, window):
+    """pp_map_order_window with 16384 / 32768 rows per window (the levels' own order): a window-local permutation sorted by
+    (remapped neighbour mask, row); pp_map_permute with that window restates the same-level map in the new row ids."""
+    rng = np.random.default_rng(33)
+    for n_pts, n_batch in [(70000, 2), (window // 30, 1)]:
+        fine = surface(rng, n=n_pts, n_batch=n_batch, extent=160)
+        fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+        n = len(fine)
+        idx, _ = ops.block_index_build(dev(fine), 1, 4)
+        nbr = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1, want_mask=True)
+        mask = nbr.pp_mask.cpu().numpy().astype(np.int64)
+        order = ops.map_order(nbr.pp_mask, window=window)
+        assert order.pp_window == window
+        o = order.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(o), np.arange(n))
+        assert np.array_equal(o // window, np.arange(n) // window)
+        key = ((np.arange(n) // window) << 50) | (_mask_sort_rank(mask, window)[o] << 15) | (o % window)
+        assert np.all(np.diff(key) > 0)
+        coords_p, phys_of = ops.level_permute(dev(fine), order)
+        same = ops.map_permute(nbr, order, translate=phys_of).cpu().numpy()
+        assert np.array_equal(same, oracle.kernel_map(fine[o], fine[o], 3, 1, 1))
+        plain = ops.map_permute(nbr, order).cpu().numpy()                       # no translation: old row ids
+        assert np.array_equal(plain, nbr.cpu().numpy()[:, o])
+
+
 VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
                   ("transposed", 48, 48, 32)]
 
