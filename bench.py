@@ -368,6 +368,8 @@ def main():
     ap.add_argument("--tiles-per-batch", type=int, default=env_int("PP_BENCH_TPB", 64))
     ap.add_argument("--voxel", type=float, default=0.05)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-input-prefetch", action="store_true",
+                    help="build every batch's coordinate manager at the start of its own pass (no overlap with the previous batch)")
     ap.add_argument("--no-checks", action="store_true", help="skip the untimed self-check (batch invariance, oracle parity)")
     ap.add_argument("--layer-table", default=None, help="write the per-shape convolution table (markdown) here")
     ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
@@ -412,13 +414,17 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     stats = {"proposals": 0, "instances": 0, "local_ms": [], "exchange_events": []}
+    input_prefetch = not args.no_input_prefetch
 
     def step(profile=False):
         local = {}
         stats["proposals"] = stats["instances"] = 0
         t_local = time.perf_counter()
-        for ids, dev_b, override, starts, sizes in batches:
-            labels, res, counts = runner.run(dev_b, len(ids), override=override)
+        for j, (ids, dev_b, override, starts, sizes) in enumerate(batches):
+            # the job is a stream of tile batches (this scene's next batch, or the first batch of the next scene): the runner
+            # builds the coordinate manager of the batch that follows while this one is in its grouping / scorer stages
+            nxt = batches[(j + 1) % len(batches)][1] if input_prefetch else None
+            labels, res, counts = runner.run(dev_b, len(ids), override=override, next_batch=nxt)
             stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
             stats["instances"] += sum(counts)
             # what the scene assembly needs from a cylinder: origin ids, instance labels, semantic vote contributions
@@ -473,6 +479,10 @@ def main():
         ops.PROFILER = profiler if it < event_steps else None
         result = step()          # (ends with the host read of the per-tile instance counts: the step's own sync point)
         step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
+    # the last step prepared a batch nobody will run: its build is still part of the timed region (K steps = K builds)
+    held = model.Backbone.__dict__.pop("_prepared_input", None)
+    if held is not None:
+        held[2].take().join_prefetch()
     sync()
     dt = time.perf_counter() - t0
     host1 = host_cpu_state()
@@ -572,6 +582,7 @@ def main():
                                    "(%d unique scene voxels); setting IV: U-Net fwd + heads + region_grow(shifted) + MeanShift(embed) "
                                    "+ ScorerUnet + NMS" % (len(tiles), radius, total_points, len(scene.pos)),
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
+                       "input_prefetch": input_prefetch,  # next batch's coordinate manager built during the current batch
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
                        "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms, "multi_gpu": multi,

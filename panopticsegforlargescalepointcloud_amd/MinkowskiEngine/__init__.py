@@ -87,6 +87,18 @@ def _side_stream(device):
     return s
 
 
+_PREP_STREAMS = {}
+
+
+def _prep_stream(device, which=0):
+    """the streams the NEXT batch's coordinate manager is built on (PreparedCoordinates): 0 = its constructor (input level),
+    1 = its level / map builder"""
+    s = _PREP_STREAMS.get((device, which))
+    if s is None:
+        s = _PREP_STREAMS[(device, which)] = torch.cuda.Stream(device=device, priority=0)
+    return s
+
+
 class conv_autocast:
     """with ME.conv_autocast(): ... -- bfloat16 compute for every sparse convolution launched inside (forward, input
     and weight gradients of the layers the bf16 kernels take; the 4-channel input layer stays fp32)."""
@@ -179,7 +191,7 @@ class CoordinateManager:
     for the input gradient of map(A->B, sign) is map(B->A, -sign).  Only map(ts,ts,+1) and map(ts,2ts,+1) are built
     with hash probes; mirrored and transposed maps are derived (flip along k / pp_kernel_map_transpose)."""
 
-    def __init__(self, coords, reorder=True, prefetch_plan=None):
+    def __init__(self, coords, reorder=True, prefetch_plan=None, side_stream=None):
         """prefetch_plan: the request log of an earlier inference pass of the same model (see `prefetch`).  Given here, the
         builder thread starts as soon as the input level's block index exists: the next coarser level (coarsening, its
         own slot order) depends on nothing else, so it is built on the side stream WHILE this constructor orders the input
@@ -200,6 +212,7 @@ class CoordinateManager:
         self._ready = {}
         self._log = None
         self._worker = None
+        self._side = side_stream  # the builder's stream (None: the device's shared side stream)
         self._side_built = False  # anything built on the prefetch stream? (otherwise no cross-stream bookkeeping is needed)
         self._worker_err = None
         self._input_final = threading.Event()  # set when levels[1] and its same-level map are the final ones
@@ -252,7 +265,7 @@ class CoordinateManager:
         if self._worker is not None:
             return  # started by the constructor
         dev = self.orig_coords.device
-        side = _side_stream(dev)
+        side = self._side if self._side is not None else _side_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
 
         def work():
@@ -280,7 +293,7 @@ class CoordinateManager:
             self._worker.join()
             self._worker = None
             dev = self.orig_coords.device
-            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+            torch.cuda.current_stream(dev).wait_stream(self._side if self._side is not None else _side_stream(dev))
             if self._worker_err is not None:
                 err, self._worker_err = self._worker_err, None
                 raise err
@@ -453,6 +466,64 @@ class CoordinateManager:
 # ------------------------------------------------------------------------------------------------
 # sparse tensor
 # ------------------------------------------------------------------------------------------------
+class PreparedCoordinates:
+    """The coordinate manager of a batch that is not being processed yet, built by a thread of its own on a stream of its own
+    while the GPU works on the previous batch: Morton order, block index, the input level's slot order and same-level map
+    and -- with `prefetch_plan` -- the coarser levels and their maps, i.e. everything between "the batch is in HBM" and "the
+    first convolution can start" (3.5 ms of launches and three host reads at the start of a bench step, during which the
+    main stream has nothing else to run).  `SparseTensor(..., prepared=p)` takes it over if `p.matches(coordinates)`:
+    the consumer's stream waits for the build, and every tensor it reads was allocated from the build stream's pool, so
+    it is marked as used by the consumer's stream like the prefetched maps are (_consumed_here).
+    The caller must not modify `coords` between this call and the SparseTensor that uses it.
+    Inference only (the autograd path keeps to one stream)."""
+
+    def __init__(self, coords, prefetch_plan=None):
+        if coords.dtype != torch.int32:
+            coords = coords.to(torch.int32)
+        self.coords = coords.contiguous()
+        self._key = (self.coords.data_ptr(), tuple(self.coords.shape))
+        self._cm = None
+        self._err = None
+        dev = self.coords.device
+        prep = _prep_stream(dev)
+        prep.wait_stream(torch.cuda.current_stream(dev))  # `coords` may have been written by the caller's stream
+        self._done = torch.cuda.Event()
+
+        def work():
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(prep), torch.no_grad():
+                    # (its level / map builder gets a stream of its own too: the shared side stream is busy with the maps of
+                    # the batch that is being processed, whose convolutions wait for them)
+                    self._cm = CoordinateManager(self.coords, prefetch_plan=prefetch_plan, side_stream=_prep_stream(dev, 1))
+                    self._done.record(prep)
+            except BaseException as e:  # surfaced by take()
+                self._err = e
+
+        self._thread = threading.Thread(target=work, name="pp-input-prepare")
+        self._thread.start()
+
+    def matches(self, coordinates):
+        return (coordinates.dtype == torch.int32 and coordinates.is_contiguous()
+                and (coordinates.data_ptr(), tuple(coordinates.shape)) == self._key)
+
+    def take(self):
+        """-> the coordinate manager, usable on the calling thread's current stream"""
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        cm, self._cm = self._cm, None
+        cur = _current_stream()
+        cur.wait_event(self._done)
+        cm._side_built = True  # every level / map access goes through _consumed_here from now on
+        lv = cm.levels[1]
+        direct = [cm.orig_coords, cm.perm, cm.inv_perm, lv.coords, lv.phys_of, lv.same_map]
+        if lv.index is not None:
+            direct += [t for t in vars(lv.index).values() if torch.is_tensor(t)] if hasattr(lv.index, "__dict__") else \
+                [getattr(lv.index, a) for a in getattr(lv.index, "__slots__", ()) if torch.is_tensor(getattr(lv.index, a, None))]
+        cm._consumed_here(*direct)
+        return cm
+
+
 class GatheredRows:
     """`base[index]` that has not been gathered yet.  Passed as the features of a SparseTensor it is resolved together
     with the internal row permutation in ONE gather (base[index[perm]]) -- the proposal scorer feeds millions of
@@ -491,14 +562,17 @@ class SparseTensor:
     in, applications/minkowski.py:193)."""
 
     def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1, prefetch_plan=None,
-                 **kwargs):
+                 prepared=None, **kwargs):
         if coordinate_manager is None:
             if coordinates is None:
                 raise ValueError("SparseTensor needs coordinates or a coordinate_manager")
             dev = torch.device(device) if device is not None else features.device
             if dev.type != "cuda":
                 raise ops._lib.PanopticHipError("SparseTensor must live on a HIP device (no CPU fallback)")
-            coordinate_manager = CoordinateManager(coordinates.to(dev), prefetch_plan=prefetch_plan)
+            if prepared is not None and prepared.matches(coordinates):
+                coordinate_manager = prepared.take()  # built ahead on the preparation stream (PreparedCoordinates)
+            else:
+                coordinate_manager = CoordinateManager(coordinates.to(dev), prefetch_plan=prefetch_plan)
             if isinstance(features, GatheredRows):
                 features = features.materialise(coordinate_manager.perm)
             else:

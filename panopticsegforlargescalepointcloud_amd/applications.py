@@ -154,12 +154,35 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
             nn.init.ones_(bn.bn.weight)
             nn.init.zeros_(bn.bn.bias)
 
-    def _set_input(self, data):
+    def _plan(self):
+        # (inference: the previous pass's request log lets the coordinate manager start building the coarser levels at once)
+        return getattr(self, "_map_plan", None) if (ME.MAP_PREFETCH and EARLY_PREFETCH and not torch.is_grad_enabled()) else None
+
+    def prepare_input(self, data):
+        """Start building the coordinate manager of a batch this network will be given LATER (ME.PreparedCoordinates: its own
+        thread and stream), e.g. the next tile batch while the current one is in its grouping / scorer stages.  The next
+        forward whose `data.batch` / `data.coords` are these very tensors (unmodified) takes it over; any other input
+        simply builds its own.  Inference only."""
+        if torch.is_grad_enabled():
+            raise RuntimeError("prepare_input is an inference-time overlap (no autograd across streams)")
         dev = self.device
         coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
-        # (inference: the previous pass's request log lets the coordinate manager start building the coarser levels at once)
-        plan = getattr(self, "_map_plan", None) if (ME.MAP_PREFETCH and EARLY_PREFETCH and not torch.is_grad_enabled()) else None
-        self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev, prefetch_plan=plan)
+        key = (data.batch.data_ptr(), data.coords.data_ptr(), int(data.coords.shape[0]))
+        self._prepared_input = (key, coords, ME.PreparedCoordinates(coords, prefetch_plan=self._plan()))
+
+    def _set_input(self, data):
+        dev = self.device
+        prepared = None
+        held = self.__dict__.pop("_prepared_input", None)
+        if held is not None and held[0] == (data.batch.data_ptr(), data.coords.data_ptr(), int(data.coords.shape[0])) \
+                and not torch.is_grad_enabled():
+            coords, prepared = held[1], held[2]
+        else:
+            if held is not None:
+                held[2].take()  # not this batch: let the build finish (its thread and streams) and drop it
+            coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
+        self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev, prefetch_plan=self._plan(),
+                                     prepared=prepared)
         self.xyz = data.pos.to(dev) if getattr(data, "pos", None) is not None else data.coords.to(dev)
 
 

@@ -10,6 +10,8 @@ collective on the data path; ONE exchange step all-gathers the per-tile label ar
 contributions (`exchange_tile_results`) so the merge can run in the original block order on every rank.  torch.distributed backend "nccl" is RCCL
 on ROCm; the same code runs on gloo/CPU tensors for the world_size-2 tests.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -18,6 +20,9 @@ from .applications import Data
 
 # ------------------------------------------------------------------------------------------------ per-tile post-processing
 from . import ops  # noqa: E402
+
+# TileRunner.run(next_batch=...): build the next batch's coordinate manager during the current batch (PP_INPUT_PREFETCH=0: off)
+INPUT_PREFETCH = os.environ.get("PP_INPUT_PREFETCH", "1") != "0"
 
 
 def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
@@ -294,9 +299,12 @@ class TileRunner:
         return t0
 
     @torch.no_grad()
-    def run(self, batch_np, n_tiles, override=None):
+    def run(self, batch_np, n_tiles, override=None, next_batch=None):
         """batch_np: dict of numpy/torch arrays (pos, coords, batch, x, origin_id). override: optional
         (pred int64 [N], offsets [N,3], embeddings [N,D]) device tensors replacing the heads' outputs for grouping.
+        next_batch: the batch the NEXT call will be given (device tensors): its coordinate manager -- Morton order, block index,
+        level chain and kernel maps of the backbone -- is built on a stream of its own while this batch is in its grouping and
+        scorer stages (BaseMinkowski.prepare_input), so the next call's first convolution does not wait for it.
         Returns (labels int32 [N] device, PanopticResults)."""
         dev = self.device
         to = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)  # noqa: E731
@@ -309,6 +317,10 @@ class TileRunner:
         self.model.set_input(data, dev)
         feats, sem, off, emb, pred = self.model.backbone_and_heads()
         t0 = self._tick("backbone+heads", t0)
+        if next_batch is not None and INPUT_PREFETCH:
+            if not all(torch.is_tensor(next_batch[k]) and next_batch[k].is_cuda for k in ("coords", "batch")):
+                raise ValueError("next_batch must hold device tensors (the build reads them on its own stream)")
+            self.model.Backbone.prepare_input(Data(coords=next_batch["coords"], batch=next_batch["batch"]))
         if override is not None:
             pred, off, emb = override
         res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred, timer=self._tick if self.stage_timing else None,

@@ -55,6 +55,47 @@ def test_scene_labels_and_pq_match_oracle():
     assert pq_gpu["PQ"] > 0.5  # synthetic head statistics are good, so grouping must recover most instances
 
 
+def test_prepared_next_batch_does_not_change_results():
+    """TileRunner.run(next_batch=...) builds the next batch's coordinate manager on its own thread and streams during the
+    current batch (ME.PreparedCoordinates); the pass that takes it over gives bit-identical results to one that builds its
+    own, a pass whose batch is NOT the prepared one ignores it, and the environment switch turns it off."""
+    import bench
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    from panopticsegforlargescalepointcloud_amd import scene as scene_mod
+    from panopticsegforlargescalepointcloud_amd.scene import TileRunner
+    dev = torch.device("cuda")
+    scene, tiles, _ = bench.build_scene(120_000, 2, 0.05, 2023)
+    model, cfg, DS = bench.build_model(dev, 0.05)
+    runner = TileRunner(model, dev)
+    batches = []
+    for ids in ([0, 1], [2, 3]):
+        b = syn.tile_batch(scene, tiles, ids)
+        ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(7 + ids[0]))
+        batches.append(({k: torch.from_numpy(v).to(dev) for k, v in b.items()}, tuple(torch.from_numpy(a).to(dev) for a in ov)))
+
+    def run(i, nxt=None):
+        labels, res, counts = runner.run(batches[i][0], 2, override=batches[i][1], next_batch=None if nxt is None else batches[nxt][0])
+        return labels.cpu().numpy(), res.cluster_scores.cpu().numpy(), res.semantic_logits.cpu().numpy(), counts
+
+    for _ in range(2):  # (second round: the map prefetch plan exists, the prepared manager starts its own builder)
+        plain = [run(0), run(1)]
+        a = run(0, nxt=1)                                   # prepares batch 1 ...
+        assert "_prepared_input" in model.Backbone.__dict__
+        b = run(1, nxt=0)                                   # ... which this pass takes over, preparing batch 0
+        c = run(1)                                          # batch 0 was prepared, batch 1 is run: ignored and dropped
+        assert "_prepared_input" not in model.Backbone.__dict__
+        for got, want in ((a, plain[0]), (b, plain[1]), (c, plain[1])):
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            assert got[3] == want[3]
+    scene_mod.INPUT_PREFETCH = False
+    try:
+        d = run(0, nxt=1)
+        assert "_prepared_input" not in model.Backbone.__dict__
+        assert np.array_equal(d[0], plain[0][0])
+    finally:
+        scene_mod.INPUT_PREFETCH = True
+
+
 def test_tile_batch_on_the_gpu_matches_numpy_collation():
     """voxelise -> cut cylinders -> collate on the GPU (row f1) vs the NumPy generator path on the same raw cloud."""
     from oracle import oracle
