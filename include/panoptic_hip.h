@@ -478,6 +478,29 @@ int pp_proposal_intersections(const int32_t* prop_offsets, const int64_t* prop_p
                               pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K14a front end of the proposal scorer (csrc/pp_proposals.hip)
+ *                                 replaces: the per-proposal batch assembly of PointGroup3heads._compute_score,
+ *                                 models/panoptic/PointGroup3heads.py:393-454 (every proposal = one batch element: batch index,
+ *                                 coordinates and features of its points)
+ * Proposals with identical point lists get identical scores; one representative per list is scored.
+ * pp_proposals_unique: rep int64 [n_prop] = smallest index of a proposal with exactly the same list (order included; found by
+ *   (size, two 64-bit sum hashes) and verified entry by entry, so exact), pos_of int64 [n_prop] = position of rep[p] among the
+ *   kept proposals (those with rep[p] == p, in index order), uniq_offsets int32 [n_prop + 1] = CSR offsets of the kept lists
+ *   (first counts[0] + 1 entries valid), counts int32 [3] (device) = {kept proposals, their entries, points outside
+ *   [0, n_points)}.  No host synchronisation.
+ * pp_proposals_emit: the kept lists (out_points int64 [counts[1]]), their batch index (out_batch int64, = position of the
+ *   proposal) and, with coords int32 [n_points][3], the (batch, x, y, z) rows of the scorer's input (out_coords4 int32
+ *   [counts[1]][4]; both NULL to skip).  Call only when counts[2] == 0.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pp_proposals_unique_workspace(int64_t n_prop);
+int pp_proposals_unique(const int32_t* prop_offsets, const int64_t* prop_points, int64_t n_prop, int64_t n_points, int64_t* rep,
+                        int64_t* pos_of, int32_t* uniq_offsets, int32_t* counts, void* workspace, size_t workspace_bytes,
+                        pp_stream_t stream);
+int pp_proposals_emit(const int32_t* prop_offsets, const int64_t* prop_points, int64_t n_prop, const int64_t* rep,
+                      const int64_t* pos_of, const int32_t* uniq_offsets, const int32_t* coords, int64_t* out_points,
+                      int64_t* out_batch, int32_t* out_coords4, pp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K14b proposal overlaps, NMS and painting on the device (csrc/pp_nms.hip)
  *                                 replaces: PanopticResults.get_instances + non_max_suppression,
  *                                 models/panoptic/structure_3heads.py:6-71, and get_cur_ins_pre_label,

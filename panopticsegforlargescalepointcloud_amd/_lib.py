@@ -43,6 +43,9 @@ SIGNATURES = {
     "pp_block_index_coarsen_workspace": (sz, [i64]),
     "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "pp_proposals_unique_workspace": (sz, [i64]),
+    "pp_proposals_unique": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_proposals_emit": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "pp_proposal_pairs_capacity": (i64, [i32]),
     "pp_proposal_pairs_workspace": (sz, [i64, i64, i32]),
     "pp_proposal_pairs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

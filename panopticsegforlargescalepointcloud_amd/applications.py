@@ -180,7 +180,9 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
         else:
             if held is not None:
                 held[2].take()  # not this batch: let the build finish (its thread and streams) and drop it
-            coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
+            c4 = getattr(data, "coords4", None)  # (batch, x, y, z) rows already assembled (ops.proposals_unique)
+            coords = c4 if c4 is not None else \
+                torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
         self.input = ME.SparseTensor(features=data.x.to(dev), coordinates=coords, device=dev, prefetch_plan=self._plan(),
                                      prepared=prepared)
         self.xyz = data.pos.to(dev) if getattr(data, "pos", None) is not None else data.coords.to(dev)

@@ -1006,6 +1006,48 @@ class ProposalPairs:
             raise _lib.PanopticHipError("proposal points / batch elements out of range (%d / %d)" % (bad_pt, bad_grp))
 
 
+class UniqueProposals:
+    """proposals_unique(): `csr` = the kept proposals (one per distinct point list, in index order), `pos_of` int64 [P] = position
+    in `csr` of every original proposal's representative, `batch` int64 / `coords4` int32 [entries, 4] = the scorer's input rows
+    (batch index = position of the proposal; (batch, x, y, z))."""
+
+    def __init__(self, csr, pos_of, batch, coords4):
+        self.csr, self.pos_of, self.batch, self.coords4 = csr, pos_of, batch, coords4
+
+
+def proposals_unique(csr, n_points, coords=None):
+    """Front end of the proposal scorer (csrc/pp_proposals.hip): duplicates of a point list are scored once.  coords int32
+    [n_points, 3] (optional): also emit the (batch, x, y, z) rows of the scorer's input.  ONE host read (the kept counts)."""
+    lib = _lib.load()
+    dev = csr.offsets.device
+    P = csr.n
+    offs = _need(csr.offsets, torch.int32, "offsets")
+    pts = _need(csr.points, torch.int64, "points")
+    rep = torch.empty(max(P, 1), dtype=torch.int64, device=dev)
+    pos_of = torch.empty(max(P, 1), dtype=torch.int64, device=dev)
+    uoffs = torch.empty(P + 1, dtype=torch.int32, device=dev)
+    counts = torch.empty(3, dtype=torch.int32, device=dev)
+    wsb = lib.pp_proposals_unique_workspace(P)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_proposals_unique(_ptr(offs), _ptr(pts), P, int(n_points), _ptr(rep), _ptr(pos_of), _ptr(uoffs), _ptr(counts),
+                                       _ptr(ws), wsb, _stream()), "pp_proposals_unique")
+    nu, total, bad = counts.tolist()
+    if bad:
+        raise _lib.PanopticHipError("proposals_unique: %d proposal points outside [0, %d)" % (bad, n_points))
+    out_pts = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    out_b = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    c4 = None
+    if coords is not None:
+        coords = _need(coords, torch.int32, "coords")
+        if coords.dim() != 2 or coords.shape[1] != 3 or coords.shape[0] != n_points:
+            raise ValueError("coords must be int32 [n_points, 3]")
+        c4 = torch.empty((max(total, 1), 4), dtype=torch.int32, device=dev)
+    _lib.check(lib.pp_proposals_emit(_ptr(offs), _ptr(pts), P, _ptr(rep), _ptr(pos_of), _ptr(uoffs), _ptr(coords), _ptr(out_pts),
+                                     _ptr(out_b), _ptr(c4), _stream()), "pp_proposals_emit")
+    return UniqueProposals(ClusterCSR(uoffs[: nu + 1], out_pts[:total], nu), pos_of[:P], out_b[:total],
+                           None if c4 is None else c4[:total])
+
+
 def proposal_pairs(csr, n_points):
     """Pairs of proposals that share points, with their intersection sizes, from the point -> proposal incidence (the
     sparse form of the dense mask @ mask.T of structure_3heads.py:40-60).  No host synchronisation.  Cached on the csr."""

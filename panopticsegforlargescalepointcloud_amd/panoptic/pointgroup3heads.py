@@ -33,6 +33,8 @@ FUSE_HEADS = os.environ.get("PP_FUSE_HEADS", "1") != "0"  # all heads in one pas
 OVERLAP_CLUSTERING = os.environ.get("PP_CLUSTER_OVERLAP", "1") != "0"  # mean shift on a side stream next to region growing
 
 
+# duplicate proposals + the scorer's input batch from csrc/pp_proposals.hip (PP_DEDUPE_FUSED=0: the tensor-library form, A/B runs)
+DEDUPE_FUSED = os.environ.get("PP_DEDUPE_FUSED", "1") != "0"
 DEDUPE_HASH = os.environ.get("PP_DEDUPE_HASH", "1") != "0"
 
 
@@ -348,6 +350,15 @@ class PointGroup3heads(nn.Module):
             # representative, so the result is exact (a mismatch, i.e. a hash collision or differently ordered lists, simply
             # keeps the proposal).  The overlap-pair pass the first form was built on (0.9 ms, needed by NMS anyway) no longer
             # sits in front of the scorer: it runs on a side stream next to the scorer's convolutions.
+            if DEDUPE_FUSED and csr.n <= MAX_SCORER_BATCH and self._scorer_type == "unet":
+                # the kept lists, their batch index and the scorer's coordinate rows from csrc/pp_proposals.hip: seven launches and
+                # one host read where the tensor-library form below needs ~130 launches (5 ms of the bench step in which the
+                # GPU waits for the host to issue them)
+                coords = self.input.coords if self.input.coords.dtype == torch.int32 else self.input.coords.int()
+                uniq = ops.proposals_unique(csr, backbone_features.shape[0], coords=coords.contiguous())
+                self._pairs_async(csr, backbone_features.shape[0])
+                scores_u, _ = self._score_unique(uniq.csr, backbone_features, prepared=uniq)
+                return scores_u[uniq.pos_of], None
             if DEDUPE_HASH:
                 rep = _duplicate_representatives(csr)
                 self._pairs_async(csr, backbone_features.shape[0])
@@ -380,7 +391,8 @@ class PointGroup3heads(nn.Module):
             t.record_stream(main)  # allocated on the side stream, read by the NMS kernels of the main stream
         pairs.ready = ev
 
-    def _score_unique(self, csr, backbone_features, epoch=-1):
+    def _score_unique(self, csr, backbone_features, epoch=-1, prepared=None):
+        """prepared (ops.UniqueProposals of this very csr, one chunk): batch index and coordinate rows are already there"""
         sizes = csr.sizes()
         offsets = csr.offsets.long()
         scores, masks = [], []
@@ -391,7 +403,9 @@ class PointGroup3heads(nn.Module):
             else:
                 p0, p1 = (int(v) for v in offsets[[lo, hi]].tolist())
             pts = csr.points[p0:p1]
-            b = torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi], output_size=p1 - p0)
+            one_chunk = prepared is not None and lo == 0 and hi == csr.n
+            b = prepared.batch if one_chunk else \
+                torch.repeat_interleave(torch.arange(hi - lo, device=pts.device), sizes[lo:hi], output_size=p1 - p0)
             # one gather for "rows of the proposals" + "internal row order", none for the way back (the max is order-free)
             if self._scorer_type == "MLP":
                 # per-point MLP on the proposals' backbone rows, then the per-proposal maximum (reference :419-423)
@@ -415,6 +429,11 @@ class PointGroup3heads(nn.Module):
                 if self.use_mask_filter_score_feature and epoch > self.use_mask_filter_score_feature_start_epoch:
                     x = x * (torch.sigmoid(mask) >= self.mask_filter_score_feature_thre).to(x.dtype)
                 cluster_feats = scatter(x, b, dim=0, reduce="max", dim_size=hi - lo)
+            elif one_chunk and prepared.coords4 is not None:
+                c4 = prepared.coords4
+                batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=c4[:, 1:], coords4=c4, batch=b, pos=None)
+                out = self.ScorerUnet(batch_cluster, internal_order=True)
+                cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo)
             else:
                 batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
                 out = self.ScorerUnet(batch_cluster, internal_order=True)

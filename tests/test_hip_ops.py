@@ -883,6 +883,49 @@ def test_map_order_large_windows(ops, oracle, window):
         assert np.array_equal(plain, nbr.cpu().numpy()[:, o])
 
 
+def test_proposals_unique_front_end(ops):
+    """pp_proposals_unique / pp_proposals_emit against a dictionary of point lists: representatives are the smallest index of
+    an IDENTICAL list (same points, same order -- a permuted copy has the same hashes and must be kept), kept lists / batch
+    index / coordinate rows are those of the representatives in index order; empty input and a single proposal included."""
+    rng = np.random.default_rng(41)
+    n_points = 5000
+    coords = rng.integers(-300, 300, size=(n_points, 3)).astype(np.int32)
+    for n_prop in [0, 1, 7, 600]:
+        lists, fresh, flipped = [], [], set()
+        for p in range(n_prop):
+            r = rng.random()
+            if fresh and r < 0.3:
+                lists.append(lists[fresh[rng.integers(len(fresh))]].copy())           # exact duplicate of an ascending list
+            elif fresh and r < 0.4 and len(lists[fresh[-1]]) > 1 and fresh[-1] not in flipped:
+                # same set, other order: same hashes, NOT a duplicate.  (A copy of such a list would be compared with the
+                # ascending one -- the smallest index under the signature -- and kept as well: exact, just not deduplicated.)
+                lists.append(lists[fresh[-1]][::-1].copy())
+                flipped.add(fresh[-1])
+            else:
+                lists.append(np.sort(rng.choice(n_points, size=int(rng.integers(1, 400)), replace=False)).astype(np.int64))
+                fresh.append(p)
+        csr = ops.ClusterCSR.from_list([torch.from_numpy(l) for l in lists], torch.device("cuda")) if n_prop else \
+            ops.ClusterCSR(torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 0)
+        u = ops.proposals_unique(csr, n_points, coords=dev(coords))
+        first, rep = {}, []
+        for p, l in enumerate(lists):
+            rep.append(first.setdefault(l.tobytes(), p))
+        kept = [p for p in range(n_prop) if rep[p] == p]
+        assert u.csr.n == len(kept)
+        want_offs = np.concatenate([[0], np.cumsum([len(lists[p]) for p in kept])]).astype(np.int32)
+        assert np.array_equal(u.csr.offsets.cpu().numpy(), want_offs)
+        want_pts = np.concatenate([lists[p] for p in kept]) if kept else np.zeros(0, np.int64)
+        assert np.array_equal(u.csr.points.cpu().numpy(), want_pts)
+        pos = {p: i for i, p in enumerate(kept)}
+        assert np.array_equal(u.pos_of.cpu().numpy(), np.array([pos[r] for r in rep], np.int64))
+        want_b = np.repeat(np.arange(len(kept)), [len(lists[p]) for p in kept])
+        assert np.array_equal(u.batch.cpu().numpy(), want_b)
+        assert np.array_equal(u.coords4.cpu().numpy(), np.concatenate([want_b[:, None].astype(np.int32), coords[want_pts]], 1))
+    bad = ops.ClusterCSR.from_list([torch.tensor([1, n_points])], torch.device("cuda"))
+    with pytest.raises(ops._lib.PanopticHipError):
+        ops.proposals_unique(bad, n_points)
+
+
 VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
                   ("transposed", 48, 48, 32)]
 
