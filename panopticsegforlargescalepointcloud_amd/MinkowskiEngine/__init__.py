@@ -95,7 +95,8 @@ def _prep_stream(device, which=0):
     1 = its level / map builder"""
     s = _PREP_STREAMS.get((device, which))
     if s is None:
-        s = _PREP_STREAMS[(device, which)] = torch.cuda.Stream(device=device, priority=0)
+        # (PP_PREP_PRIORITY: HIP stream priority of the preparation streams, A/B runs; larger = lower)
+        s = _PREP_STREAMS[(device, which)] = torch.cuda.Stream(device=device, priority=int(os.environ.get("PP_PREP_PRIORITY", "0")))
     return s
 
 

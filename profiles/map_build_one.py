@@ -40,9 +40,15 @@ def main():
     perm32, cs = timed("morton_order", lambda: ops.morton_order(coords, 1, ME.ORDER_BLOCK_BITS, want_sorted=True, raw=True), reps, n)
     index, _ = timed("block_index_build", lambda: ops.block_index_build(cs, 1, ME.ORDER_BLOCK_BITS), reps, n)
     nbr = timed("kernel_map_bi (same, +mask)", lambda: ops.kernel_map_bi(cs, index, 3, 1, 1, want_mask=True), reps, n, 124 * n)
+    for w in (16384, 32768):  # the level's own order uses larger windows than the cross-level maps (round 4)
+        ow = timed("map_order (window %d)" % w, lambda: ops.map_order(nbr.pp_mask, window=w), reps, n)
+        _, pw = ops.level_permute(cs, ow)
+        timed("map_permute (+translate, %d)" % w, lambda: ops.map_permute(nbr, ow, translate=pw), reps, n, 216 * n)
+        timed("map_permute (no translate, %d)" % w, lambda: ops.map_permute(nbr, ow), reps, n, 216 * n)
     order = timed("map_order (window sort)", lambda: ops.map_order(nbr.pp_mask), reps, n)
     coords_p, phys_of = timed("level_permute", lambda: ops.level_permute(cs, order), reps, n)
     same = timed("map_permute (+translate)", lambda: ops.map_permute(nbr, order, translate=phys_of), reps, n, 216 * n)
+    timed("map_permute (no translate)", lambda: ops.map_permute(nbr, order), reps, n, 216 * n)
     timed("compose_perm", lambda: ops.compose_perm(perm32, order, n, dev), reps, n)
     cidx, ccoords = timed("block_index_coarsen", lambda: ops.block_index_coarsen(index, n), reps, n)
     nc = ccoords.shape[0]
