@@ -454,6 +454,11 @@ int pp_segment_reduce(const float* src, const int64_t* index, int64_t n, int32_t
 int pp_segment_reduce_unchecked(const float* src, const int64_t* index, int64_t n, int32_t c, int64_t n_seg,
                                 int32_t reduce, float* out, int64_t* arg, void* workspace, size_t workspace_bytes,
                                 pp_stream_t stream);
+/* The same sums / means without atomics: rows int64 [n] = the source rows grouped by segment in ascending row order,
+ * offsets int32 [n_seg + 1] (pp_group_by_key of the segment ids).  One workgroup per segment adds in an order that depends on
+ * (segment size, c) only: bit-reproducible run to run (the atomic form above is not).  Empty segments -> 0. */
+int pp_segment_sum_ordered(const float* src, const int64_t* rows, const int32_t* offsets, int64_t n_seg, int32_t c, int32_t mean,
+                           float* out, pp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K10 instance IoU                replaces: torch_points_kernels.instance_iou,

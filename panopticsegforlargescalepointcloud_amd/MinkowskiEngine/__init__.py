@@ -35,11 +35,13 @@ COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
 # maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
 MAP_ORDER = os.environ.get("PP_MAP_ORDER", "1") != "0"
 MAP_ORDER_MIN_ROWS = int(os.environ.get("PP_MAP_ORDER_MIN_ROWS", "50000"))  # smaller levels gain nothing from it
-# rows per sort window of a level's OWN order (its same-level map; 1024 .. 32768).  Purer 16-row tiles with larger windows
-# (executed / useful tile rows at tensor stride 1: 2.00 at 8192, 1.82 at 32768, profiles/r03_row_cache_model.txt) while the
-# rows one XCD has in flight (~40 k) span the window either way.  Cross-level maps keep pp_map_window().
+# rows per sort window of a level's OWN order (its same-level map; 1024 .. 32768).  Larger windows give purer 16-row tiles
+# (executed / useful tile rows at tensor stride 1: 2.00 at 8192, 1.82 at 32768, profiles/r03_row_cache_model.txt) and gathers that
+# leave the L2 more often: measured per setting in profiles/r04_ab_same_window.txt (time) and r04_window_traffic.txt (HBM bytes).
+# 8192 at tensor stride 1 (16 channels: bound by the gathers) and 16384 at the coarser levels is the fastest; 32768 there costs
+# 16 % more fetched bytes for the same time.  Cross-level maps keep pp_map_window().
 # PP_SAME_WINDOW = "<tensor stride 1>,<coarser levels>" (or one number for both).
-_sw = [int(v) for v in os.environ.get("PP_SAME_WINDOW", "16384,32768").split(",")]
+_sw = [int(v) for v in os.environ.get("PP_SAME_WINDOW", "8192,16384").split(",")]
 SAME_WINDOW = (_sw[0], _sw[-1])
 if os.environ.get("PP_MAP_WINDOW"):  # rows per sort window (1024 | 2048 | 4096 | 8192), A/B runs
     ops._lib.check(ops._lib.load().pp_map_set_window(int(os.environ["PP_MAP_WINDOW"])), "pp_map_set_window")
@@ -147,6 +149,20 @@ def _order_level(coords_m, index, ts):
     del nbr_m.pp_mask
     coords_p, phys_of = ops.level_permute(coords_m, order)
     return coords_p, order, phys_of, lambda: ops.map_permute(nbr_m, order, translate=phys_of)
+
+
+_IDENTITY_PAIRS = {}
+
+
+def _identity_pairs(n, device):
+    """pair lists (ops.wgrad_pairs) of the identity map of n rows: what a 1x1 convolution's weight gradient sums over"""
+    key = (int(n), str(device))
+    wp = _IDENTITY_PAIRS.get(key)
+    if wp is None:
+        if len(_IDENTITY_PAIRS) >= 16:
+            _IDENTITY_PAIRS.clear()
+        wp = _IDENTITY_PAIRS[key] = ops.wgrad_pairs(torch.arange(n, dtype=torch.int32, device=device).view(1, n), 1)
+    return wp
 
 
 class _PermuteRowsFn(torch.autograd.Function):
@@ -693,6 +709,11 @@ def _conv_backward(ctx, feats, kernel, dout, need_in, need_w):
             if wp is None:
                 wp = ctx.nbr.pp_wpairs = ops.wgrad_pairs(ctx.nbr, ctx.K, row_order=order)
             dw = ops.spconv_bwd_weight_pairs(feats, dout, wp, bf16=ctx.bf16)
+        elif (ctx.nbr is None and ctx.K == 1 and WGRAD_PAIRS and ops.WGRAD_DETERMINISTIC and dout.shape[1] <= 192
+              and feats.shape[0] < (1 << 31)):
+            # 1x1 convolution (no map): the pair-list kernel over the identity map -- its block partials are added in a fixed
+            # order, the dense-map kernel below adds with float atomics (the last gradients that differed run to run)
+            dw = ops.spconv_bwd_weight_pairs(feats, dout, _identity_pairs(feats.shape[0], feats.device), bf16=ctx.bf16)
         else:
             # dW[k] = sum_s in[nbr[k][s]]^T dout[order[s]]: a slot-ordered map wants the output gradient in slot order
             dout_s = dout if order is None else ops.gather_rows(dout, order.long())

@@ -109,6 +109,7 @@ SIGNATURES = {
     "pp_segment_reduce_workspace": (sz, [i64]),
     "pp_segment_reduce": (C.c_int, [vp, vp, i64, i32, i64, i32, vp, vp, vp, sz, vp]),
     "pp_segment_reduce_unchecked": (C.c_int, [vp, vp, i64, i32, i64, i32, vp, vp, vp, sz, vp]),
+    "pp_segment_sum_ordered": (C.c_int, [vp, vp, vp, i64, i32, i32, vp, vp]),
     "pp_instance_iou": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
     "pp_proposal_intersections_workspace": (sz, [i64, i64]),
     "pp_proposal_intersections": (C.c_int, [vp, vp, i32, i64, vp, vp, sz, vp]),

@@ -976,3 +976,40 @@ extern "C" int pp_segment_reduce_unchecked(const float* src, const int64_t* inde
                                            size_t workspace_bytes, pp_stream_t stream) {
   return segment_reduce_impl(src, index, n, c, n_seg, reduce, out, arg, workspace, workspace_bytes, false, stream);
 }
+
+// ---- segment sum / mean without atomics (bit-reproducible run to run) -------------------------------------------------------
+// The rows of segment s are rows[offs[s] .. offs[s+1]) in ascending row order (pp_group_by_key: stable).  One workgroup per
+// segment: 256 / cw row lanes x cw columns (cw = min(c, 256)); row lane r adds rows r, r + R, ... in order, the lanes' partials
+// are added in lane order (float64 partials, rounded once).  The summation order is a function of (segment size, c) alone.
+__global__ __launch_bounds__(256) void k_seg_sum_ordered(const float* __restrict__ src, const int64_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ offs, int c, int mean, float* __restrict__ out) {
+  __shared__ double sh[256];
+  const int64_t s = blockIdx.x;
+  const int lo = offs[s], hi = offs[s + 1];
+  const int cw = c < 256 ? c : 256;
+  const int R = 256 / cw;
+  const int t = threadIdx.x, jj = t % cw, r = t / cw;
+  for (int col0 = 0; col0 < c; col0 += cw) {
+    const int j = col0 + jj;
+    double acc = 0.0;  // float64 partials: a lane may add 10^5 rows one after the other
+    if (r < R && j < c)
+      for (int e = lo + r; e < hi; e += R) acc += (double)src[rows[e] * c + j];
+    __syncthreads();  // (sh is read below in the previous column chunk)
+    sh[t] = acc;
+    __syncthreads();
+    if (r == 0 && j < c) {
+      double tot = sh[jj];
+      for (int q = 1; q < R; ++q) tot += sh[q * cw + jj];
+      out[s * c + j] = (float)((mean && hi > lo) ? tot / (double)(hi - lo) : tot);
+    }
+  }
+}
+extern "C" int pp_segment_sum_ordered(const float* src, const int64_t* rows, const int32_t* offsets, int64_t n_seg, int32_t c,
+                                      int32_t mean, float* out, pp_stream_t stream) {
+  PP_REQUIRE(c >= 1, "pp_segment_sum_ordered: c must be positive");
+  if (n_seg <= 0) return PP_OK;
+  PP_REQUIRE(offsets && out, "pp_segment_sum_ordered: null pointer");  // (src / rows may be NULL when every segment is empty)
+  hipLaunchKernelGGL(k_seg_sum_ordered, dim3((unsigned)n_seg), dim3(256), 0, pp_s(stream), src, rows, offsets, (int)c, (int)mean, out);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -1402,6 +1402,35 @@ def group_by_key_check(total):
     return kept
 
 
+# sums / means by segment without float atomics: rows grouped by segment (stable), one workgroup per segment adding in a fixed
+# order -- bit-reproducible run to run (PP_SEGMENT_DETERMINISTIC=0: the atomic kernels; maxima are order-free either way)
+SEGMENT_DETERMINISTIC = os.environ.get("PP_SEGMENT_DETERMINISTIC", "1") != "0"
+
+
+class _GroupingCache(threading.local):
+    """(offsets, rows) of the last few segment-id tensors: a loss uses the same ids for several sums and for the backward of
+    its gathers (the discriminative loss: four times), and the grouping -- a radix sort -- is most of an ordered sum's cost.
+    Entries hold the id tensor itself (address + shape + version counter decide a hit; views made by reshape share all three), so
+    its storage stays alive and a recycled address cannot alias."""
+
+    def __init__(self):
+        self.items = []
+
+
+_GROUPINGS = _GroupingCache()
+
+
+def _grouping_of(index, n_seg):
+    for it in _GROUPINGS.items:
+        if it[0].data_ptr() == index.data_ptr() and it[0].shape == index.shape and it[1] == index._version and it[2] == n_seg:
+            return it[3]
+    g = group_by_key(index.to(torch.int32), n_seg, ids=None)
+    _GROUPINGS.items.append((index, index._version, n_seg, g))
+    if len(_GROUPINGS.items) > 8:
+        del _GROUPINGS.items[0]
+    return g
+
+
 def segment_reduce(src, index, n_seg, reduce, want_arg=False, check=True):
     """check=False: the ids are known to be in range (no validation, no stream synchronisation)"""
     lib = _lib.load()
@@ -1410,6 +1439,15 @@ def segment_reduce(src, index, n_seg, reduce, want_arg=False, check=True):
     n, c = src.shape
     dev = src.device
     out = torch.empty((n_seg, c), dtype=torch.float32, device=dev)
+    if SEGMENT_DETERMINISTIC and _REDUCE[reduce] != 2 and not want_arg and n_seg < (1 << 31) and n < (1 << 31):
+        offs, rows, total = _grouping_of(index, n_seg)
+        if check:
+            kept, bad = total.tolist()
+            if kept != n:
+                raise _lib.PanopticHipError("segment_reduce: %d segment ids outside [0, %d)" % (n - kept, n_seg))
+        _lib.check(lib.pp_segment_sum_ordered(_ptr(src), _ptr(rows), _ptr(offs), int(n_seg), c, 1 if _REDUCE[reduce] == 1 else 0,
+                                              _ptr(out), _stream()), "pp_segment_sum_ordered")
+        return out
     arg = torch.empty((n_seg, c), dtype=torch.int64, device=dev) if want_arg else None
     wsb = lib.pp_segment_reduce_workspace(n_seg)
     ws = _ws(wsb, dev)

@@ -926,6 +926,27 @@ def test_proposals_unique_front_end(ops):
         ops.proposals_unique(bad, n_points)
 
 
+def test_segment_sum_without_atomics_matches_and_repeats(ops):
+    """pp_segment_sum_ordered (the default of ops.segment_reduce for sum / mean): equal to a float64 reference within float
+    rounding, bit-identical over repeated calls (the atomic kernels are not), empty segments 0, out-of-range ids reported."""
+    rng = np.random.default_rng(43)
+    for n, c, n_seg in [(50000, 5, 37), (3000, 16, 2000), (70000, 300, 3), (0, 4, 5)]:
+        x = rng.normal(size=(n, c)).astype(np.float32) * 10
+        idx = rng.integers(0, n_seg, size=n)
+        if n_seg > 3:
+            idx[idx == 2] = 3                                            # an empty segment
+        for reduce in ("sum", "mean"):
+            want = np.zeros((n_seg, c))
+            np.add.at(want, idx, x.astype(np.float64))
+            if reduce == "mean":
+                want /= np.maximum(np.bincount(idx, minlength=n_seg), 1)[:, None]
+            outs = [ops.segment_reduce(dev(x), dev(idx.astype(np.int64)), n_seg, reduce) for _ in range(3)]
+            np.testing.assert_allclose(outs[0].cpu().numpy(), want, rtol=2e-5, atol=2e-3)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with pytest.raises(ops._lib.PanopticHipError):
+        ops.segment_reduce(dev(np.ones((4, 2), np.float32)), dev(np.array([0, 1, 5, 1], np.int64)), 3, "sum")
+
+
 VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
                   ("transposed", 48, 48, 32)]
 
