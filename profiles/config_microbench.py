@@ -69,7 +69,7 @@ def c3(n_points=1_000_000, voxel=0.10, grid=10, steps=5):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        labels, res, counts = runner.run(dev_b, len(ids), override=override)
+        labels, res, counts = runner.run(dev_b, len(ids), override=override, next_batch=dev_b)  # (a stream of batches, as bench.py)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     n = len(b["pos"])
