@@ -168,6 +168,15 @@ int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_stream_t st
 /* the same with an explicit window (a power of two in [1024, 32768]): the levels' own (same-level) maps take larger windows than
  * the cross-level ones, whose convolutions scatter output rows inside a window; pp_map_permute takes the window used here */
 int pp_map_order_window(const uint32_t* mask, int64_t n, int32_t window, int32_t* order, pp_stream_t stream);
+/* Compact form of a SAME-LEVEL map for the convolution's prologue (4 + 6 x pairs bytes per row instead of 108): the present entries
+ * (neighbour rows) grouped by chunks of 32 output rows, offset-major inside a chunk; start int32 [ceil(n_out / 32) + 1] their
+ * offsets (start[last] = pairs of the map), tags uint16 [pairs] = offset index << 6 | output row & 63, mask uint32 [n_out] = the
+ * rows' offsets.  _count fills mask and start, _write the entries and tags (capacity: start[last], at most K * n_out). */
+size_t pp_map_compact_workspace(int64_t n_out);
+int pp_map_compact_count(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, int32_t* start, void* workspace,
+                         size_t workspace_bytes, pp_stream_t stream);
+int pp_map_compact_write(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* start, uint32_t* entries, uint16_t* tags,
+                         pp_stream_t stream);
 int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
                    int32_t window, int32_t* out, pp_stream_t stream);
 int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,
@@ -244,6 +253,13 @@ int pp_spconv_fwd_shortcut(const float* in0, int32_t c0, const float* in1, int32
 int pp_spconv_fwd_t8(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
                      const int32_t* nbr8, int64_t n_out, int32_t cout, const float* scale, const float* shift, int32_t relu,
                      const float* residual, const int32_t* row_order, float* out, int32_t bf16, pp_stream_t stream);
+/* pp_spconv_fwd (ds_in NULL) / pp_spconv_fwd_shortcut on the compact form of a same-level map (pp_map_compact_*; K = 27, rows =
+ * slots): same results bit for bit, the prologue streams the compact map instead of the dense one. */
+int pp_spconv_fwd_cmap(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
+                       const uint32_t* cm_mask, const int32_t* cm_start, const uint32_t* cm_entries, const uint16_t* cm_tags,
+                       int64_t n_out, int32_t cout, const float* scale, const float* shift, int32_t relu, const float* residual,
+                       float* out, int32_t bf16, const float* ds_in, int32_t ds_c, const float* ds_packed, const float* ds_scale,
+                       const float* ds_shift, pp_stream_t stream);
 int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in, const float* packed_weight,
                      const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout, const float* scale, const float* shift,
                      int32_t relu, const float* residual, const int32_t* row_order, float* out, int32_t bf16,

@@ -139,6 +139,28 @@ class _Level:
         self.same_map = same_map
 
 
+# PP_COMPACT_MAPS=1 (off by default): same-level maps also get their compact form (ops.map_compact), which the convolutions'
+# prologue then streams instead of the dense [27, n] map -- 4 + 6 x pairs bytes per row instead of 108.  Built, parity-tested and
+# measured in round 4 (profiles/r04_ab_compact_maps.txt): bit-identical results, a third of the map bytes, and a step that is
+# 12 - 19 ms SLOWER (146 - 153 against 133.5 ms; convolutions at 0.40 instead of 0.44 of the MFMA peak): the prologue is bound
+# by its chain of dependent loads, not by bytes -- chunk offsets, then entries, then a second batch of entries, where the dense
+# map's 28 loads per lane are independent and in flight together -- and the two compaction passes run beside the convolutions.
+COMPACT_MAPS = os.environ.get("PP_COMPACT_MAPS", "0") != "0"
+COMPACT_MIN_ROWS = int(os.environ.get("PP_COMPACT_MIN_ROWS", "65536"))
+
+
+def _cmap_tensors(m):
+    c = getattr(m, "pp_cmap", None)
+    return [] if c is None else [c.mask, c.start, c.entries, c.tags]
+
+
+def _with_compact(m):
+    if COMPACT_MAPS and not torch.is_grad_enabled() and m.shape[0] == 27 and m.shape[1] >= COMPACT_MIN_ROWS \
+            and 27 * m.shape[1] < (1 << 31):
+        m.pp_cmap = ops.map_compact(m)
+    return m
+
+
 def _order_level(coords_m, index, ts):
     """physical order of a level from its same-level map: (coords_p, order, phys_of, finish) -- `finish()` returns the
     same-level map in physical ids.  The level (coords_p, phys_of) is usable before that last pass has run: a strided map
@@ -245,7 +267,7 @@ class CoordinateManager:
                         self.levels[1] = level  # provisional: Morton order + index, enough to derive the coarser level
                         self.prefetch(prefetch_plan, early=True)
                     coords_p, order, phys_of, finish = _order_level(coords, index, 1)
-                    level = _Level(coords_p, index=index, phys_of=phys_of, same_map=finish())
+                    level = _Level(coords_p, index=index, phys_of=phys_of, same_map=_with_compact(finish()))
                 if perm32 is not None:  # internal row p = caller row perm[p]
                     self.perm, self.inv_perm = ops.compose_perm(perm32, order, coords.shape[0], coords.device)
             else:
@@ -389,7 +411,7 @@ class CoordinateManager:
             with self._lock:
                 m = self._kernel_map_locked(key)
         self._use(key)
-        self._consumed_here(m, getattr(m, "pp_order", None))
+        self._consumed_here(m, getattr(m, "pp_order", None), *_cmap_tensors(m))
         if getattr(m, "pp_t8", False) and torch.is_grad_enabled():
             # The 8-wide form is an inference-only layout ([8, n], not [27, n]): the weight gradient and the pair lists index
             # 27 * n entries.  A map built under no_grad (frozen pre-pass, prefetch worker) and then used with grad enabled
@@ -432,7 +454,7 @@ class CoordinateManager:
             dst = self.levels[ts_to]
             finish = self._pending_same.pop(ts_to, None) if (ts_from == ts_to and sign == 1 and ksize == 3) else None
             if finish is not None:
-                m = dst.same_map = finish()
+                m = dst.same_map = _with_compact(finish())
             elif rev is not None and ts_from == ts_to:
                 m = torch.flip(rev, [0]).contiguous()  # mirrored offsets: offset_k -> offset_{K-1-k}
                 if hasattr(rev, "pp_pairs"):
@@ -537,6 +559,7 @@ class PreparedCoordinates:
         if lv.index is not None:
             direct += [t for t in vars(lv.index).values() if torch.is_tensor(t)] if hasattr(lv.index, "__dict__") else \
                 [getattr(lv.index, a) for a in getattr(lv.index, "__slots__", ()) if torch.is_tensor(getattr(lv.index, a, None))]
+        direct += _cmap_tensors(lv.same_map)
         cm._consumed_here(*direct)
         return cm
 

@@ -61,6 +61,10 @@ SIGNATURES = {
     "pp_map_mask": (C.c_int, [vp, i32, i64, vp, vp]),
     "pp_map_order": (C.c_int, [vp, i64, vp, vp]),
     "pp_map_order_window": (C.c_int, [vp, i64, i32, vp, vp]),
+    "pp_map_compact_workspace": (sz, [i64]),
+    "pp_map_compact_count": (C.c_int, [vp, i32, i64, vp, vp, vp, sz, vp]),
+    "pp_map_compact_write": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
+    "pp_spconv_fwd_cmap": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "pp_map_set_window": (C.c_int, [i32]),
     "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i32, vp, vp]),
     "pp_level_permute": (C.c_int, [vp, i64, vp, vp, vp, vp]),

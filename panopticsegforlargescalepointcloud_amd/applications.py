@@ -166,9 +166,14 @@ class BaseMinkowski(UnwrappedUnetBasedModel):
         if torch.is_grad_enabled():
             raise RuntimeError("prepare_input is an inference-time overlap (no autograd across streams)")
         dev = self.device
+        pending = self.__dict__.pop("_prepared_input", None)
+        if pending is not None:
+            pending[2].take()  # never taken over: let its threads finish before it is dropped
         coords = torch.cat([data.batch.unsqueeze(-1).int().to(dev), data.coords.int().to(dev)], -1)
         key = (data.batch.data_ptr(), data.coords.data_ptr(), int(data.coords.shape[0]))
-        self._prepared_input = (key, coords, ME.PreparedCoordinates(coords, prefetch_plan=self._plan()))
+        # (the source tensors are held too: while the build is pending their storage cannot be recycled for another batch of the
+        # same shape, so an equal address means the same tensors)
+        self._prepared_input = (key, coords, ME.PreparedCoordinates(coords, prefetch_plan=self._plan()), (data.batch, data.coords))
 
     def _set_input(self, data):
         dev = self.device

@@ -17,6 +17,8 @@
 // window, rows in registers: ordered by (remapped mask, row in window) -- a total order, hence deterministic.
 // Reference: none -- MinkowskiEngine keeps kernel maps as unordered (in, out) pair lists per offset; results of the
 // convolution do not depend on the row order (every output row is still written exactly once, same summation order).
+#include <algorithm>
+
 #include "pp_common.h"
 
 #define MO_MASK_BITS 27
@@ -339,6 +341,71 @@ extern "C" int pp_map_order_window(const uint32_t* mask, int64_t n, int32_t wind
   PP_REQUIRE(map_window_ok(window), "pp_map_order_window: window must be a power of two in [1024, 32768]");
   if (n == 0) return PP_OK;
   return map_order_launch(mask, n, window, order, pp_s(stream));
+}
+
+// ---- compact form of a same-level map -----------------------------------------------------------------------------------------
+// The convolution's prologue needs, per wave, the (offset, row) -> neighbour row table of its 32 or 64 output rows.  The dense map
+// stores 27 entries per row, of which a surface-like level has 5 - 10: 108 bytes per row where 4 (mask) + 6 per present entry
+// would do, and the map is the largest stream of the <= 32-channel layers (108 of 236 bytes per row at 16 channels).  Compact form:
+// entries grouped by chunks of 32 output rows (offset-major inside a chunk), start[chunk] their offsets, tag[e] = offset << 6 |
+// output row & 63, mask[row] = the row's offsets.
+__global__ __launch_bounds__(256) void k_cmap_mask_count(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask,
+                                                         int32_t* __restrict__ cnt) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t m = 0;
+  if (o < n)
+    for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + o] >= 0 ? 1u : 0u) << k;
+  if (o < n) mask[o] = m;
+  int c = __popc(m);
+  for (int d = 16; d > 0; d >>= 1) c += __shfl_xor(c, d);  // over the 32 lanes of a chunk
+  if ((threadIdx.x & 31) == 0 && o < n) cnt[o >> 5] = c;
+}
+__global__ __launch_bounds__(256) void k_cmap_write(const int32_t* __restrict__ nbr, int K, int64_t n, const int32_t* __restrict__ start,
+                                                    uint32_t* __restrict__ ent, uint16_t* __restrict__ tag) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // lane = row; a wave covers two chunks
+  const int lane = threadIdx.x & 63, half = lane >> 5;
+  const int64_t oc = o < n ? o : n - 1;
+  int run = start[oc >> 5];
+  for (int k = 0; k < K; ++k) {
+    const int v = o < n ? nbr[(int64_t)k * n + o] : -1;
+    const unsigned long long b = __ballot(v >= 0);
+    const uint32_t hb = half ? (uint32_t)(b >> 32) : (uint32_t)b;
+    if (v >= 0) {
+      const int pos = run + __popc(hb & ((1u << (lane & 31)) - 1u));
+      ent[pos] = (uint32_t)v;
+      tag[pos] = (uint16_t)((k << 6) | (int)(o & 63));
+    }
+    run += __popc(hb);
+  }
+}
+extern "C" size_t pp_map_compact_workspace(int64_t n_out) {
+  const int64_t chunks = (std::max<int64_t>(n_out, 1) + 31) / 32;
+  return pp_align((size_t)chunks * 4) + pp_scan_workspace(chunks) + 256;
+}
+// step 1: mask [n_out], start [chunks + 1] (chunks = ceil(n_out / 32); start[chunks] = the map's pairs); the caller reads
+// start[chunks] and allocates entries (uint32) / tags (uint16) for step 2
+extern "C" int pp_map_compact_count(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, int32_t* start, void* workspace,
+                                    size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(nbr && mask && start && n_out > 0, "pp_map_compact_count: null pointer / empty map");
+  PP_REQUIRE(K >= 1 && K <= 27, "pp_map_compact_count: K must be in [1,27]");
+  PP_REQUIRE((double)K * (double)n_out < 2147483000.0, "pp_map_compact_count: more than 2^31 map entries");
+  if (workspace_bytes < pp_map_compact_workspace(n_out)) return PP_ERR_WORKSPACE;
+  const int64_t chunks = (n_out + 31) / 32;
+  hipStream_t s = pp_s(stream);
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* cnt = ar.take<int32_t>((size_t)chunks);
+  PP_REQUIRE(cnt, "pp_map_compact_count: workspace");
+  hipLaunchKernelGGL(k_cmap_mask_count, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, nbr, K, n_out, mask, cnt);
+  PP_LAUNCH_CHECK();
+  return pp_exclusive_scan_i32(cnt, start, chunks, start + chunks, ar.cur(), ar.left(), s);
+}
+extern "C" int pp_map_compact_write(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* start, uint32_t* entries,
+                                    uint16_t* tags, pp_stream_t stream) {
+  PP_REQUIRE(nbr && start && entries && tags && n_out > 0, "pp_map_compact_write: null pointer / empty map");
+  PP_REQUIRE(K >= 1 && K <= 27, "pp_map_compact_write: K must be in [1,27]");
+  hipLaunchKernelGGL(k_cmap_write, dim3(pp_blocks(n_out, 256)), dim3(256), 0, pp_s(stream), nbr, K, n_out, start, entries, tags);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
 }
 
 // ---- applying an order -----------------------------------------------------------------------------------------------------

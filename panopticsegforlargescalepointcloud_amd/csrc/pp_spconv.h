@@ -54,6 +54,12 @@ struct SpconvArgs {
   // 8-wide transposed map (pp_kernel_map_transpose8; v3 kernel only): nbr is [8][n_out] slot-major, every entry = coarse row |
   // parity class of the fine row << 28 -- the prologue expands (class, j) to the offset index k
   int t8;
+  // compact same-level map (pp_map_compact; t8 == 2, v3 kernel only): nbr = the present entries (neighbour rows) grouped by chunks
+  // of 32 output rows, cm_start [chunks + 1] their offsets, cm_tag[e] = offset index << 6 | output row & 63, cm_mask [n_out] the
+  // rows' offset masks -- 4 + 6 x pairs bytes per row instead of 108
+  const uint32_t* cm_mask;
+  const int32_t* cm_start;
+  const uint16_t* cm_tag;
 };
 #define PP_ROW_MASK 0x0FFFFFFFu  // row part of a T8 map entry (bits 28..30: parity class)
 

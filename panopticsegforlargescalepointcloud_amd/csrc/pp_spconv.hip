@@ -284,7 +284,8 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
                            const int32_t* row_order, float* out, int bf16, int rows_per_wave, int pipeline, int split_k,
                            pp_stream_t stream, const float* ds_in = nullptr, int32_t ds_c = 0,
                            const float* ds_packed = nullptr, const float* ds_scale = nullptr,
-                           const float* ds_shift = nullptr, int t8 = 0) {
+                           const float* ds_shift = nullptr, int t8 = 0, const uint32_t* cm_mask = nullptr,
+                           const int32_t* cm_start = nullptr, const uint16_t* cm_tag = nullptr) {
   PP_REQUIRE(in0 && packed_weight && out, "pp_spconv_fwd: null pointer");
   PP_REQUIRE(c0 > 0 && c1 >= 0 && (c1 == 0 || in1), "pp_spconv_fwd: bad channel split");
   PP_REQUIRE(nbr || K == 1, "pp_spconv_fwd: a kernel map is required unless K == 1");
@@ -301,7 +302,11 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   a.NT = pp_nt(cout); a.relu = relu; a.bf16 = bf16; a.split = 1; a.part = nullptr;
   a.ds_in = nullptr; a.ds_wp = nullptr; a.ds_scale = nullptr; a.ds_shift = nullptr; a.ds_c = 0;
   a.t8 = t8;
-  if (t8) PP_REQUIRE(row_order && nbr && K == 27 && !ds_in, "pp_spconv_fwd_t8: needs the 8-wide map, its slot order and K = 27");
+  a.cm_mask = cm_mask; a.cm_start = cm_start; a.cm_tag = cm_tag;
+  if (t8 == 1) PP_REQUIRE(row_order && nbr && K == 27 && !ds_in, "pp_spconv_fwd_t8: needs the 8-wide map, its slot order and K = 27");
+  if (t8 == 2)
+    PP_REQUIRE(!row_order && nbr && cm_mask && cm_start && cm_tag && K == 27 && n_in == n_out,
+               "pp_spconv_fwd_cmap: needs the compact form of a same-level map (pp_map_compact), K = 27 and no slot order");
   const bool c4 = c0 == 4 && c1 == 0;  // the input layer has its own form of the pipelined kernel
   // column tiles per wave: 4, or up to 6 where that saves a column group on a LARGE launch (80 / 96 / 160 / 192 output
   // channels: every group gathers the input rows again) -- 96->96 transposed onto 5.4 M rows 3814 -> 3400 us, 160->160 onto
@@ -364,7 +369,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
   } else {
     if (ds_in) return PP_UNSUPPORTED;
     if (t8) {
-      pp_set_error("pp_spconv_fwd_t8: needs cin %% 16 == 0 and inputs < 4 GiB per source (the pipelined kernel)");
+      pp_set_error("pp_spconv_fwd_t8 / _cmap: needs cin %% 16 == 0 (or the 4-channel input layer) and inputs < 4 GiB per source (the pipelined kernel)");
       return PP_ERR_INVALID;
     }
     // first-version kernel: Cin % 16 != 0 other than the 4-channel input layer, and inputs of 4 GiB or more per source
@@ -427,6 +432,20 @@ extern "C" int pp_spconv_fwd_t8(const float* in0, int32_t c0, const float* in1, 
                                 const int32_t* row_order, float* out, int32_t bf16, pp_stream_t stream) {
   return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, nbr8, 27, n_out, cout, scale, shift, relu, residual,
                          row_order, out, bf16 ? 1 : 0, 0, 0, 0, stream, nullptr, 0, nullptr, nullptr, nullptr, 1);
+}
+/* pp_spconv_fwd / pp_spconv_fwd_shortcut on the COMPACT form of a same-level map (pp_map_compact_count / _write): the kernel's
+ * prologue reads 4 + 6 x pairs bytes per row instead of the dense map's 108.  Same results, bit for bit.  ds_in NULL: no fused
+ * shortcut.  PP_UNSUPPORTED as for pp_spconv_fwd_shortcut. */
+extern "C" int pp_spconv_fwd_cmap(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
+                                  const float* packed_weight, const uint32_t* cm_mask, const int32_t* cm_start,
+                                  const uint32_t* cm_entries, const uint16_t* cm_tags, int64_t n_out, int32_t cout,
+                                  const float* scale, const float* shift, int32_t relu, const float* residual, float* out,
+                                  int32_t bf16, const float* ds_in, int32_t ds_c, const float* ds_packed, const float* ds_scale,
+                                  const float* ds_shift, pp_stream_t stream) {
+  PP_REQUIRE(!ds_in || ds_packed, "pp_spconv_fwd_cmap: null shortcut weights");
+  return spconv_fwd_impl(in0, c0, in1, c1, n_in, packed_weight, (const int32_t*)cm_entries, 27, n_out, cout, scale, shift, relu,
+                         residual, nullptr, out, bf16 ? 1 : 0, 0, 0, 0, stream, ds_in, ds_c, ds_packed, ds_scale, ds_shift, 2,
+                         cm_mask, cm_start, cm_tags);
 }
 extern "C" int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                                 const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,

@@ -99,7 +99,9 @@ class LaunchProfiler:
             if tag is not None and tg != tag:
                 continue
             n_used += 1
-            if mk is not None and K > 1:
+            if mk == -1:
+                map_bytes += 4.125 * n_out + 6.0 * P - 4.0 * K * n_out  # compact map: masks, chunk offsets, 6 bytes per present entry
+            elif mk is not None and K > 1:
                 map_bytes += 4.0 * (mk - K) * n_out  # (corrects the dense estimate below for 8-wide maps)
             map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
             # features read once + written once, weights once, one (in,out) int32 pair per map entry;
@@ -427,6 +429,34 @@ def map_order(mask, window=None):
     return order
 
 
+class CompactMap:
+    """compact form of a same-level kernel map (csrc/pp_maporder.hip): mask int32 [n], start int32 [ceil(n / 32) + 1], entries
+    int32 / tags int16 [capacity] (the first start[-1] valid)"""
+    __slots__ = ("mask", "start", "entries", "tags", "n")
+
+    def __init__(self, mask, start, entries, tags, n):
+        self.mask, self.start, self.entries, self.tags, self.n = mask, start, entries, tags, n
+
+
+def map_compact(nbr):
+    """CompactMap of a dense same-level map [27, n] (row = slot).  No host read: the entry arrays have the map's capacity
+    (they are written and read only up to the number of pairs)."""
+    lib = _lib.load()
+    nbr = _need(nbr, torch.int32, "nbr")
+    K, n = nbr.shape
+    dev = nbr.device
+    chunks = (n + 31) // 32
+    mask = torch.empty(n, dtype=torch.int32, device=dev)
+    start = torch.empty(chunks + 1, dtype=torch.int32, device=dev)
+    wsb = lib.pp_map_compact_workspace(n)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_map_compact_count(_ptr(nbr), K, n, _ptr(mask), _ptr(start), _ptr(ws), wsb, _stream()), "pp_map_compact_count")
+    entries = torch.empty(K * n, dtype=torch.int32, device=dev)
+    tags = torch.empty(K * n, dtype=torch.int16, device=dev)
+    _lib.check(lib.pp_map_compact_write(_ptr(nbr), K, n, _ptr(start), _ptr(entries), _ptr(tags), _stream()), "pp_map_compact_write")
+    return CompactMap(mask, start, entries, tags, n)
+
+
 def map_permute(nbr, order=None, translate=None):
     """out[k][s] = T(nbr[k][order[s]]) with T(v) = -1 if v < 0 else (translate[v] if translate is given else v)"""
     lib = _lib.load()
@@ -692,7 +722,30 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         ntw = (nt + groups - 1) // groups
         variant = (64 if (ntw <= _AB_T4[0] and n_out >= _AB_T4[1]) else 32, 0, 0)
     t8 = bool(getattr(nbr, "pp_t8", False))
-    if t8:
+    cmap = None
+    if variant is None and row_order is None and K == 27 and not t8 and n_out == in0.shape[0]:
+        # (the compact form is read by the pipelined kernel only: 16-channel steps from one source or two equal ones, or the input layer)
+        if ((c0 % 16 == 0 and c1 in (0, c0)) or (c0 == 4 and c1 == 0)) and in0.shape[0] * c0 * 4 < 4294967000:
+            cmap = getattr(nbr, "pp_cmap", None)
+    if cmap is not None:
+        # same-level map in its compact form (map_compact): 4 + 6 x pairs bytes per row in the prologue instead of 108
+        if shortcut is not None:
+            xs, pks, scs, shs = shortcut
+            xs = _need(xs, torch.float32, "shortcut input")
+            ds = (_ptr(xs), xs.shape[1], _ptr(pks), _ptr(_need(scs, torch.float32, "shortcut scale")),
+                  _ptr(_need(shs, torch.float32, "shortcut shift")))
+            bf = int(use_bf16 and xs.shape[1] % 16 == 0)
+        else:
+            ds, bf = (None, 0, None, None, None), int(use_bf16)
+        rc = lib.pp_spconv_fwd_cmap(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(cmap.mask), _ptr(cmap.start),
+                                    _ptr(cmap.entries), _ptr(cmap.tags), n_out, cout, _ptr(scale), _ptr(shift), int(bool(relu)),
+                                    _ptr(residual), _ptr(out), bf, *ds, _stream())
+        if rc == _lib.PP_UNSUPPORTED:
+            if prof is not None:
+                prof._pool.extend((e0, e1))  # nothing was launched: the events go back
+            return None
+        _lib.check(rc, "pp_spconv_fwd_cmap")
+    elif t8:
         if variant is not None or shortcut is not None or K != 27 or row_order is None:
             raise ValueError("spconv_fwd: an 8-wide transposed map takes the default variant, K = 27 and its slot order")
         _lib.check(lib.pp_spconv_fwd_t8(_ptr(in0), c0, _ptr(in1), c1, in0.shape[0], _ptr(packed), _ptr(nbr), n_out, cout,
@@ -720,7 +773,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None,
                              shortcut[0].shape[1] if shortcut is not None else 0))
         prof.tags.append(PROFILE_TAG)
-        prof.map_k.append(8 if t8 else K)
+        prof.map_k.append(-1 if cmap is not None else (8 if t8 else K))  # (-1: compact map, bytes from the pair count)
     return out
 
 

@@ -947,6 +947,57 @@ def test_segment_sum_without_atomics_matches_and_repeats(ops):
         ops.segment_reduce(dev(np.ones((4, 2), np.float32)), dev(np.array([0, 1, 5, 1], np.int64)), 3, "sum")
 
 
+def test_compact_same_level_map(ops, oracle):
+    """pp_map_compact_* against numpy (mask, chunk offsets, entries offset-major inside 32-row chunks, tags) and
+    pp_spconv_fwd_cmap bit-identical to pp_spconv_fwd on the dense map: 16 / 32 / 64 / 96+32 input channels (64 and 32 rows per
+    wave, split-K on the small map, the 4-channel input layer's grouped loop, BN / ReLU / residual / fused shortcut), row counts
+    that are not multiples of 32."""
+    rng = np.random.default_rng(47)
+    for n_pts, n_batch in [(60000, 2), (900, 1), (33, 1)]:
+        fine = surface(rng, n=n_pts, n_batch=n_batch, extent=150)
+        fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+        n = len(fine)
+        idx, _ = ops.block_index_build(dev(fine), 1, 4)
+        nbr = ops.kernel_map_bi(dev(fine), idx, 3, 1, 1)
+        cm = ops.map_compact(nbr)
+        d = nbr.cpu().numpy()
+        present = d >= 0
+        assert np.array_equal(cm.mask.cpu().numpy().astype(np.int64) & 0x7FFFFFF, (present.astype(np.int64) << np.arange(27)[:, None]).sum(0))
+        chunks = (n + 31) // 32
+        cnt = np.add.reduceat(present.sum(0), np.arange(0, n, 32))
+        start = np.concatenate([[0], np.cumsum(cnt)])
+        assert np.array_equal(cm.start.cpu().numpy(), start)
+        P = int(start[-1])
+        ent, tag = cm.entries[:P].cpu().numpy(), cm.tags[:P].cpu().numpy().astype(np.int64) & 0xFFFF
+        want_ent, want_tag = [], []
+        for c in range(chunks):
+            blk = d[:, 32 * c: 32 * c + 32]
+            k, r = np.nonzero(blk >= 0)                       # offset-major, rows ascending
+            want_ent.append(blk[k, r])
+            want_tag.append(k * 64 + ((32 * c + r) & 63))
+        assert np.array_equal(ent, np.concatenate(want_ent)) and np.array_equal(tag, np.concatenate(want_tag))
+        for c0, c1, cout, kw in [(16, 0, 16, {}), (32, 0, 32, {"relu": True}), (64, 0, 64, {}), (96, 32, 48, {}), (32, 32, 48, {}), (4, 0, 16, {}),
+                                 (32, 0, 64, {"shortcut": 32})]:  # (96 + 32: not the pipelined kernel's shape -- dense map)
+            x = dev(rng.normal(size=(n, c0)).astype(np.float32))
+            x1 = dev(rng.normal(size=(n, c1)).astype(np.float32)) if c1 else None
+            w = ops.pack_weight(dev((rng.normal(size=(27, c0 + c1, cout)) * 0.1).astype(np.float32)))
+            sc, sh = dev(rng.uniform(0.5, 1.5, cout).astype(np.float32)), dev(rng.normal(size=cout).astype(np.float32))
+            res = dev(rng.normal(size=(n, cout)).astype(np.float32))
+            args = dict(in1=x1, scale=sc, shift=sh, relu=bool(kw.get("relu")), residual=res)
+            if "shortcut" in kw:
+                xs = dev(rng.normal(size=(n, kw["shortcut"])).astype(np.float32))
+                ws = ops.pack_weight(dev((rng.normal(size=(1, kw["shortcut"], cout)) * 0.1).astype(np.float32)))
+                args["shortcut"] = (xs, ws, sc, sh)
+            plain = torch.empty_like(nbr).copy_(nbr)
+            a = ops.spconv_fwd(x, w, plain, n, cout, 27, **args)
+            nbr.pp_cmap = cm
+            b = ops.spconv_fwd(x, w, nbr, n, cout, 27, **args)
+            del nbr.pp_cmap
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), (n, c0, c1, cout)
+
+
 VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
                   ("transposed", 48, 48, 32)]
 

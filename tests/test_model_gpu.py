@@ -419,12 +419,15 @@ def test_inference_switches_do_not_change_results(setup, monkeypatch):
     """The inference-path fusions and the early start of the map builder are pure scheduling: with each of them off the step
     returns bit-identical network outputs, proposals, scores and labels (fused heads vs one launch per head on
     caller-ordered features, fused 1x1 shortcuts vs their own launches, builder thread started in the coordinate
-    manager's constructor vs at the first layer, mean shift next to region growing vs after it)."""
+    manager's constructor vs at the first layer, mean shift next to region growing vs after it, compact vs dense same-level maps
+    in the convolutions' prologue, scorer front end from the library vs tensor-library ops)."""
     from panopticsegforlargescalepointcloud_amd import applications, modules
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME
     from panopticsegforlargescalepointcloud_amd.panoptic import pointgroup3heads as pg
     s = setup
     dev = torch.device("cuda")
     ov = tuple(torch.from_numpy(a).to(dev) for a in s["override"])
+    monkeypatch.setattr(ME, "COMPACT_MIN_ROWS", 1)  # (every same-level map of this small batch in its compact form too)
 
     def run():
         outs = []
@@ -435,11 +438,13 @@ def test_inference_switches_do_not_change_results(setup, monkeypatch):
         return outs
 
     ref = run()
-    for mod, name in [(pg, "FUSE_HEADS"), (modules, "FUSE_SHORTCUT"), (applications, "EARLY_PREFETCH"), (pg, "OVERLAP_CLUSTERING")]:
-        assert getattr(mod, name) is True
-        monkeypatch.setattr(mod, name, False)
+    for mod, name in [(pg, "FUSE_HEADS"), (modules, "FUSE_SHORTCUT"), (applications, "EARLY_PREFETCH"), (pg, "OVERLAP_CLUSTERING"),
+                      (ME, "COMPACT_MAPS"), (pg, "DEDUPE_FUSED")]:
+        default = name != "COMPACT_MAPS"  # (the compact maps are off by default: measured slower)
+        assert getattr(mod, name) is default
+        monkeypatch.setattr(mod, name, not default)
         got = run()
-        monkeypatch.setattr(mod, name, True)
+        monkeypatch.setattr(mod, name, default)
         for r, g in zip(ref, got):
             for a, b in zip(r[:-1], g[:-1]):
                 assert torch.equal(a, b), name
