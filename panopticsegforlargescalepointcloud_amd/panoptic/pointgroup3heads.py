@@ -433,7 +433,9 @@ class PointGroup3heads(nn.Module):
                 c4 = prepared.coords4
                 batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=c4[:, 1:], coords4=c4, batch=b, pos=None)
                 out = self.ScorerUnet(batch_cluster, internal_order=True)
-                cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo)
+                # (batch ids written by pp_proposals_emit: no range check, i.e. no host synchronisation between the scorer's last
+                # convolution and the head / NMS launches -- the step's one read at its end is the next time the host waits)
+                cluster_feats = scatter(out.x, out.batch.long(), dim=0, reduce="max", dim_size=hi - lo, check=False)
             else:
                 batch_cluster = Data(x=ME.GatheredRows(backbone_features, pts), coords=self.input.coords[pts], batch=b, pos=None)
                 out = self.ScorerUnet(batch_cluster, internal_order=True)

@@ -8,10 +8,10 @@ from . import ops
 
 class _ScatterFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, index, n_seg, reduce):
+    def forward(ctx, src, index, n_seg, reduce, check=True):
         src2 = src.reshape(src.shape[0], -1).contiguous()
         if reduce == "max" and not ctx.needs_input_grad[0]:
-            out = ops.segment_reduce(src2, index, n_seg, "max")  # inference: no arg-max pass
+            out = ops.segment_reduce(src2, index, n_seg, "max", check=check)  # inference: no arg-max pass
         elif reduce == "max":
             out, arg = ops.segment_reduce(src2, index, n_seg, "max", want_arg=True)
             ctx.save_for_backward(arg)
@@ -39,10 +39,12 @@ class _ScatterFn(torch.autograd.Function):
             dsrc = d2[index]
             if ctx.reduce == "mean":
                 dsrc = dsrc / cnt[index].clamp(min=1).unsqueeze(1)
-        return dsrc.reshape(ctx.shape), None, None, None
+        return dsrc.reshape(ctx.shape), None, None, None, None
 
 
-def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
+def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum", check=True):
+    """check=False (not in torch_scatter's signature): the caller built the ids itself, so the range validation -- a stream
+    synchronisation and a host read -- is skipped (inference maxima only)."""
     if dim != 0 or out is not None:
         raise NotImplementedError("only scatter(src, index, dim=0) is used by the reference path")
     if reduce == "add":
@@ -53,7 +55,7 @@ def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
     n_seg = int(dim_size) if dim_size is not None else (int(index.max().item()) + 1 if index.numel() else 0)
     squeeze = src.dim() == 1
     s = src.float().unsqueeze(1) if squeeze else src.float()
-    y = _ScatterFn.apply(s, index, n_seg, reduce)
+    y = _ScatterFn.apply(s, index, n_seg, reduce, bool(check))
     return y.squeeze(1) if squeeze else y
 
 
