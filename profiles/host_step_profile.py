@@ -29,17 +29,17 @@ ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rn
 dev_b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 ovd = tuple(torch.from_numpy(a).to(dev) for a in ov)
 for _ in range(5):
-    runner.run(dev_b, len(ids), override=ovd)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    runner.run(dev_b, len(ids), override=ovd)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
 torch.cuda.synchronize()
 print("unprofiled: %.2f ms per step (%d voxels, %d tiles)" % (1e3 * (time.perf_counter() - t0) / steps, len(b["pos"]), len(ids)))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
-    runner.run(dev_b, len(ids), override=ovd)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
