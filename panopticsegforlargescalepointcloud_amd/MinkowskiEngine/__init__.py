@@ -81,10 +81,13 @@ def _current_stream():
 
 
 def _side_stream(device):
-    """the stream the coordinate levels / kernel maps are prefetched on (PP_SIDE_PRIORITY=high|default, A/B runs)."""
+    """the stream the coordinate levels / kernel maps are prefetched on (PP_SIDE_PRIORITY=high|default, A/B runs).
+    Round 2 measured high priority 1 ms ahead (161.6 vs 162.6 ms per bench step); since the backbone's maps are built during the
+    previous batch (PreparedCoordinates) the default priority gives the same step with 1 % less convolution time
+    (profiles/r04_ab_side_priority.txt: 133.5 vs 133.7 ms, convolutions 106.4 vs 107.5 ms over five alternating pairs)."""
     s = _SIDE_STREAMS.get(device)
     if s is None:
-        prio = -1 if os.environ.get("PP_SIDE_PRIORITY", "high") == "high" else 0  # 161.6 vs 162.6 ms per bench step
+        prio = -1 if os.environ.get("PP_SIDE_PRIORITY", "default") == "high" else 0
         s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device, priority=prio)
     return s
 
