@@ -341,6 +341,12 @@ int pp_bn_train_bwd(const float* x, const float* dy, const float* y_relu, int64_
  * dy^T x, db [cout] = column sums of dy (db nullable).  replaces: the torch.nn.Linear backward (rocBLAS split-K GEMM with
  * K = n) of the heads' layers in the training step, PointGroup3heads.py:69-81 / core/common_modules/base_modules.py:35-45.
  * Block partials in float64, no atomics (run-to-run reproducible). */
+/* Forward / input gradient of the same skinny layers: y [n,cout] = x [n,cin] W^T + bias with weight [cout,cin] (transposed = 0:
+ * torch.nn.Linear's forward) or y = x W with weight [cin,cout] read as stored (transposed = 1: dx = dy W of a layer whose weight is
+ * [cols of dy, cols of dx]).  bias nullable.  cin, cout <= 32; fixed summation order.  replaces: the rocBLAS / hipBLASLt GEMMs
+ * torch.nn.functional.linear and its backward dispatch for the heads' layers in the training step (PointGroup3heads.py:69-81). */
+int pp_linear_rows(const float* x, const float* weight, const float* bias, int64_t n, int32_t cin, int32_t cout, int32_t transposed,
+                   float* y, pp_stream_t stream);
 size_t pp_linear_wgrad_workspace(int64_t n, int32_t cin, int32_t cout);
 int pp_linear_wgrad(const float* x, const float* dy, int64_t n, int32_t cin, int32_t cout, float* dw, float* db,
                     void* ws, size_t ws_bytes, pp_stream_t stream);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pp_bn_train_fwd": (C.c_int, [vp, i64, i32, vp, vp, f64, f64, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
     "pp_bn_train_bwd": (C.c_int, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_head_mlp": (C.c_int, [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "pp_linear_rows": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "pp_linear_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
     "pp_linear_wgrad": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, vp, C.c_size_t, vp]),
     "pp_heads": (C.c_int, [vp, i64, i32, vp, i64, vp, i32, vp, vp]),

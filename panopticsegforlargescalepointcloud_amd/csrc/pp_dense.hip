@@ -977,6 +977,47 @@ extern "C" int pp_segment_reduce_unchecked(const float* src, const int64_t* inde
   return segment_reduce_impl(src, index, n, c, n_seg, reduce, out, arg, workspace, workspace_bytes, false, stream);
 }
 
+// ---- skinny Linear layer, forward and input gradient ----------------------------------------------------------------------------
+// y[r][o] = b[o] + sum_i x[r][i] * W(o, i), W(o, i) = w[o * cin + i] (y = x W^T: torch.nn.Linear's forward) or w[i * cout + o]
+// (transposed = 1: y = x W, the input gradient dx = dy W of a layer whose weight is [cin_of_dx... i.e. [rows of dy's columns]).
+// cin, cout <= 32 and hundreds of thousands of rows: a thread per row, the weights in LDS (read as broadcasts), a fixed summation
+// order (i ascending) -- no library GEMM on the training step's path.
+__global__ __launch_bounds__(256) void k_linear_rows(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                     int64_t n, int cin, int cout, int transposed, float* __restrict__ y) {
+  __shared__ float wl[32 * 33];
+  __shared__ float bl[32];
+  for (int t = threadIdx.x; t < cin * cout; t += 256) {
+    const int o = transposed ? t % cout : t / cin, i = transposed ? t / cout : t % cin;
+    wl[o * 33 + i] = w[t];
+  }
+  if (threadIdx.x < cout) bl[threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  float xr[32];
+  const float* xp = x + r * cin;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) xr[i] = i < cin ? xp[i] : 0.f;
+  float* yp = y + r * cout;
+  for (int o = 0; o < cout; ++o) {
+    float acc = bl[o];
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < cin) acc += xr[i] * wl[o * 33 + i];
+    yp[o] = acc;
+  }
+}
+extern "C" int pp_linear_rows(const float* x, const float* weight, const float* bias, int64_t n, int32_t cin, int32_t cout,
+                              int32_t transposed, float* y, pp_stream_t stream) {
+  PP_REQUIRE(cin >= 1 && cin <= 32 && cout >= 1 && cout <= 32, "pp_linear_rows: cin and cout must be in [1,32]");
+  if (n <= 0) return PP_OK;
+  PP_REQUIRE(x && weight && y, "pp_linear_rows: null pointer");
+  hipLaunchKernelGGL(k_linear_rows, dim3(pp_blocks(n, 256)), dim3(256), 0, pp_s(stream), x, weight, bias, n, (int)cin, (int)cout,
+                     (int)transposed, y);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
 // ---- segment sum / mean without atomics (bit-reproducible run to run) -------------------------------------------------------
 // The rows of segment s are rows[offs[s] .. offs[s+1]) in ascending row order (pp_group_by_key: stable).  One workgroup per
 // segment: 256 / cw row lanes x cw columns (cw = min(c, 256)); row lane r adds rows r, r + R, ... in order, the lanes' partials

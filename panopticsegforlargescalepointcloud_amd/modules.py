@@ -46,22 +46,29 @@ class FastBatchNorm1d(nn.Module):
         raise ValueError("Non supported number of dimensions {}".format(x.dim()))
 
 
+# forward / input gradient of the skinny Linear layers from the library (PP_LINEAR_ROWS=0: torch GEMMs, A/B runs)
+LINEAR_ROWS = os.environ.get("PP_LINEAR_ROWS", "1") != "0"
+
+
 class _SkinnyLinearFn(torch.autograd.Function):
     """y = x W^T + b with the weight gradient as ONE streaming reduction (ops.linear_wgrad): for [millions, <= 32] inputs the
     rocBLAS split-K GEMM torch.nn.Linear's backward dispatches takes 340 - 720 us per layer (2.8 ms of a 43 ms training
-    step for the six layers of the three heads); forward and input gradient stay torch GEMMs (those shapes are fast)."""
+    step for the six layers of the three heads).  Round 4: forward and input gradient are the library's too (ops.linear_rows:
+    a thread per row, fixed summation order) -- the twelve hipBLASLt launches per step the heads still made are gone."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return ops.linear_rows(x.contiguous(), weight, bias) if LINEAR_ROWS else torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_rows(dy, weight, None, transposed=True) if LINEAR_ROWS else dy @ weight
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = ops.linear_wgrad(x.contiguous(), dy, want_bias=ctx.has_bias)

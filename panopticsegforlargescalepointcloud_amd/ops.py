@@ -929,6 +929,22 @@ def affine_act(x, scale=None, shift=None, act=0, slope=0.0, residual=None):
     return y
 
 
+def linear_rows(x, weight, bias=None, transposed=False):
+    """y = x W^T + bias (weight [cout, cin]) or, transposed, y = x W (weight [cin, cout] as stored) for skinny layers (<= 32
+    channels either side): csrc/pp_dense.hip k_linear_rows instead of a library GEMM."""
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    weight = _need(weight, torch.float32, "weight")
+    n, cin = x.shape
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    if (weight.shape[0] if transposed else weight.shape[1]) != cin:
+        raise ValueError("linear_rows: weight %s does not fit %d input channels" % (tuple(weight.shape), cin))
+    y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.pp_linear_rows(_ptr(x), _ptr(weight), _ptr(_need(bias, torch.float32, "bias")), n, cin, cout, int(bool(transposed)),
+                                  _ptr(y), _stream()), "pp_linear_rows")
+    return y
+
+
 def linear_wgrad(x, dy, want_bias=True):
     """(dW [cout, cin], db [cout] or None) of y = x W^T + b for a skinny layer (cin, cout <= 32): one streaming pass over
     x and dy instead of a split-K GEMM with K = rows (csrc/pp_dense.hip)."""

@@ -998,6 +998,23 @@ def test_compact_same_level_map(ops, oracle):
                 assert torch.equal(a, b), (n, c0, c1, cout)
 
 
+def test_linear_rows_matches_float64(ops):
+    """pp_linear_rows (forward and input gradient of the heads' skinny Linear layers in training): y = x W^T + b and y = x W
+    against float64, bias optional, channel counts that are not multiples of four, a row count that is not a multiple of 256."""
+    rng = np.random.default_rng(53)
+    for n, cin, cout in [(70001, 16, 16), (5000, 16, 3), (300, 5, 32), (1, 32, 1), (0, 16, 16)]:
+        x = rng.normal(size=(n, cin)).astype(np.float32)
+        w = rng.normal(size=(cout, cin)).astype(np.float32)
+        b = rng.normal(size=cout).astype(np.float32)
+        y = ops.linear_rows(dev(x), dev(w), dev(b)).cpu().numpy()
+        np.testing.assert_allclose(y, x.astype(np.float64) @ w.T.astype(np.float64) + b, rtol=1e-5, atol=1e-5)
+        y0 = ops.linear_rows(dev(x), dev(w)).cpu().numpy()
+        np.testing.assert_allclose(y0, x.astype(np.float64) @ w.T.astype(np.float64), rtol=1e-5, atol=1e-5)
+        dy = rng.normal(size=(n, cout)).astype(np.float32)
+        dx = ops.linear_rows(dev(dy), dev(w), None, transposed=True).cpu().numpy()
+        np.testing.assert_allclose(dx, dy.astype(np.float64) @ w.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
 VARIANT_SHAPES = [("same", 16, 0, 16), ("same", 32, 32, 48), ("strided", 32, 0, 32), ("transposed", 64, 0, 64),
                   ("transposed", 48, 48, 32)]
 
