@@ -6,6 +6,7 @@ gfx950 kernels in csrc/.  All tensors must live on a HIP device; there is no CPU
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
@@ -175,6 +176,40 @@ def _pairs_of(nbr):
     return p if p is not None else (nbr >= 0).sum()
 
 
+_PAIR_COUNTERS = []  # (weakref to a device pair counter, raw stream it was written on): counters nobody has read yet
+
+
+def _register_pairs(p):
+    if len(_PAIR_COUNTERS) >= 512:  # (inference never reads them: drop the dead ones now and then)
+        _PAIR_COUNTERS[:] = [(r, st) for r, st in _PAIR_COUNTERS if r() is not None][-256:]
+    _PAIR_COUNTERS.append((weakref.ref(p), _stream().value))
+    return p
+
+
+def _pairs_host(p):
+    """int value of a device pair counter.  The first request reads ALL counters written on the calling stream that are still
+    unread in one transfer: the training step asked for them one map at a time from inside the backward pass (19 synchronisations
+    per step, each with the GPU running dry behind it)."""
+    v = getattr(p, "pp_host", None)
+    if v is not None:
+        return v
+    cur = _stream().value
+    batch, keep = [p], []
+    for ref, st in _PAIR_COUNTERS:
+        t = ref()
+        if t is None or t is p or getattr(t, "pp_host", None) is not None:
+            continue
+        if st == cur and t.device == p.device:
+            batch.append(t)
+        else:
+            keep.append((ref, st))
+    vals = torch.stack([t.reshape(()).to(torch.int64) for t in batch]).tolist()
+    for t, val in zip(batch, vals):
+        t.pp_host = int(val)
+    _PAIR_COUNTERS[:] = keep
+    return p.pp_host
+
+
 def _stream():
     # raw handle of torch's current HIP stream; the C-level getters skip ~25 us of Python per call
     # (torch.cuda.current_stream() re-runs lazy-init checks and builds a Stream object every time)
@@ -283,7 +318,7 @@ def kernel_map(out_coords, table, ksize, step, sign):
     pairs = _zeros(1, torch.int64, out_coords.device)
     _lib.check(lib.pp_kernel_map(_ptr(out_coords), n_out, _ptr(table.keys), _ptr(table.vals), table.cap, ksize, int(step),
                                  int(sign), _ptr(nbr), _ptr(pairs), _stream()), "pp_kernel_map")
-    nbr.pp_pairs = pairs  # device scalar: number of (in, out) pairs (flops / density bookkeeping, no sync here)
+    nbr.pp_pairs = _register_pairs(pairs)  # device scalar: number of (in, out) pairs (flops / density bookkeeping, no sync here)
     return nbr
 
 
@@ -366,7 +401,7 @@ def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, transla
                                     _ptr(index.rec), index.unit, index.block_bits, int(step), int(sign),
                                     _ptr(nbr), _ptr(pairs), _ptr(mask), _ptr(_need(translate, torch.int32, "translate")),
                                     _stream()), "pp_kernel_map_bi")
-    nbr.pp_pairs = pairs
+    nbr.pp_pairs = _register_pairs(pairs)
     if want_mask:
         nbr.pp_mask = mask  # int32 [n_out]: bit k set <=> offset k occupied
     return nbr
@@ -814,7 +849,7 @@ def wgrad_pairs(nbr, K, row_order=None):
     rows = nbr.shape[1]
     dev = nbr.device
     tiles = K * ((rows + 1023) // 1024)
-    n_pairs = int(_pairs_of(nbr).item())
+    n_pairs = _pairs_host(_pairs_of(nbr))
     pairs = torch.empty((max(n_pairs, 1), 2), dtype=torch.int32, device=dev)
     tile_start = torch.empty(tiles + 1, dtype=torch.int32, device=dev)
     nbytes = lib.pp_wgrad_pairs_workspace(K, rows)

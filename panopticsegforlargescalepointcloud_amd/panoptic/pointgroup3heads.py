@@ -453,12 +453,13 @@ class PointGroup3heads(nn.Module):
         self.semantic_loss = semantic_nll(out.semantic_logits, self.labels.y.to(torch.int64), IGNORE_LABEL)
         self.loss = self.opt.loss_weights.semantic * self.semantic_loss
         mask = inp.instance_mask
+        rows = torch.nonzero(mask).view(-1)  # ONE compaction (a host read each) for the five row selections below
         if out.offset_logits is not None:
-            for name, loss in offset_loss(gather(out.offset_logits, mask), inp.vote_label[mask], torch.sum(mask)).items():
+            for name, loss in offset_loss(gather(out.offset_logits, rows), inp.vote_label[rows], torch.sum(mask)).items():
                 setattr(self, name, loss)
                 self.loss = self.loss + self.opt.loss_weights[name] * loss
         if out.embed_logits is not None:
-            for name, loss in discriminative_loss(gather(out.embed_logits, mask), inp.instance_labels[mask], inp.batch[mask],
+            for name, loss in discriminative_loss(gather(out.embed_logits, rows), inp.instance_labels[rows], inp.batch[rows],
                                                   self.opt.embed_dim).items():
                 setattr(self, name, loss)
                 if name == "ins_loss":

@@ -16,7 +16,7 @@ class _ScatterFn(torch.autograd.Function):
             out, arg = ops.segment_reduce(src2, index, n_seg, "max", want_arg=True)
             ctx.save_for_backward(arg)
         else:
-            out = ops.segment_reduce(src2, index, n_seg, reduce)
+            out = ops.segment_reduce(src2, index, n_seg, reduce, check=check)
             cnt = None
             if reduce == "mean":
                 cnt = torch.zeros(n_seg, device=src.device).index_add_(0, index, torch.ones(index.numel(), device=src.device))
@@ -44,7 +44,7 @@ class _ScatterFn(torch.autograd.Function):
 
 def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum", check=True):
     """check=False (not in torch_scatter's signature): the caller built the ids itself, so the range validation -- a stream
-    synchronisation and a host read -- is skipped (inference maxima only)."""
+    synchronisation and a host read -- is skipped."""
     if dim != 0 or out is not None:
         raise NotImplementedError("only scatter(src, index, dim=0) is used by the reference path")
     if reduce == "add":
