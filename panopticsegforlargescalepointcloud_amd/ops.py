@@ -1307,6 +1307,9 @@ def not_ignored(labels, ignore_labels, num_classes):
     return lut[(labels + 1).clamp_(0, int(num_classes) + 1)]
 
 
+_IGNORE_ON_DEVICE = {}
+
+
 def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_cluster_size, num_classes):
     lib = _lib.load()
     pos = _need(pos, torch.float32, "pos")
@@ -1314,7 +1317,15 @@ def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_clus
     batch = _need(batch, torch.int64, "batch")
     dev = pos.device
     n = pos.shape[0]
-    ign = _need(ignore_labels.to(device=dev, dtype=torch.int64), torch.int64, "ignore_labels")
+    # (the ignore list on the device, kept per list: a host tensor's .to(device) is a synchronising copy on every call)
+    ikey = (tuple(int(v) for v in ignore_labels.tolist()), str(dev)) if not ignore_labels.is_cuda else None
+    ign = _IGNORE_ON_DEVICE.get(ikey) if ikey is not None else None
+    if ign is None:
+        ign = _need(ignore_labels.to(device=dev, dtype=torch.int64), torch.int64, "ignore_labels")
+        if ikey is not None:
+            if len(_IGNORE_ON_DEVICE) > 64:
+                _IGNORE_ON_DEVICE.clear()
+            _IGNORE_ON_DEVICE[ikey] = ign
     pc = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     offs = torch.empty(n + 2, dtype=torch.int32, device=dev)
     pts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
@@ -1327,7 +1338,7 @@ def region_grow_csr(pos, labels, batch, ignore_labels, nsample, radius, min_clus
     # The neighbour lists dominate the workspace and scale with the number of non-ignored points, which the library
     # counts itself before it carves them: try the kept workspace first (steady state: no extra pass, no extra host read)
     # and size it exactly -- one counting pass -- only when the library says it is too small.
-    kept = _WS_CACHE.get(("region_grow", str(dev)))
+    kept = _WS_CACHE.get(("region_grow", str(dev), _stream().value))  # (the key of _ws: tag, device, stream)
     rc = _lib.PP_ERR_WORKSPACE
     if kept is not None and kept.numel() >= lib.pp_region_grow_workspace_for(n, 0, int(nsample)):
         rc = run(kept, kept.numel())
