@@ -52,16 +52,19 @@ def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_po
     base = csum - ncl
     sample_of_point = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), counts, output_size=m)
     key = torch.where(labels >= 0, labels + base[sample_of_point].to(torch.int32), labels)
-    n_groups = int(csum[-1].item())
-    goffs, out, total = ops.group_by_key(key.contiguous(), n_groups, ids=local_ind.contiguous())
+    # The number of clusters is on the device.  Group with an upper bound instead of reading it first (a sample of p points has
+    # at most p clusters), and read it together with the counts the grouping returns: one host read where there were two
+    bound = m
+    goffs, out, total = ops.group_by_key(key.contiguous(), bound, ids=local_ind.contiguous())
     # sklearn can leave a centre without points; torch.unique in the reference wrapper skips such labels
     sizes = goffs[1:] - goffs[:-1]
     keep = sizes > 0
-    n_keep, kept, bad = torch.cat([keep.sum().view(1).to(torch.int32), total]).tolist()  # one read for all three
+    n_groups, n_keep, kept, bad = torch.cat([csum[-1:].to(torch.int32), keep.sum().view(1).to(torch.int32), total]).tolist()
     if bad:
         raise ops._lib.PanopticHipError("group_by_key: %d keys outside [0, n_groups)" % bad)
     if n_keep == n_groups:
-        return ops.ClusterCSR(goffs, out[:kept], n_groups)
+        return ops.ClusterCSR(goffs[: n_groups + 1], out[:kept], n_groups)
+    sizes, keep = sizes[:n_groups], keep[:n_groups]
     new_offs = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), torch.cumsum(sizes[keep], 0).to(torch.int32)])
     return ops.ClusterCSR(new_offs, out[:kept], n_keep)
 
