@@ -182,7 +182,7 @@ _PAIR_COUNTERS = []  # (weakref to a device pair counter, raw stream it was writ
 def _register_pairs(p):
     if len(_PAIR_COUNTERS) >= 512:  # (inference never reads them: drop the dead ones now and then)
         _PAIR_COUNTERS[:] = [(r, st) for r, st in _PAIR_COUNTERS if r() is not None][-256:]
-    _PAIR_COUNTERS.append((weakref.ref(p), _stream().value))
+    _PAIR_COUNTERS.append((weakref.ref(p), _stream().value or 0))
     return p
 
 
@@ -193,13 +193,14 @@ def _pairs_host(p):
     v = getattr(p, "pp_host", None)
     if v is not None:
         return v
-    cur = _stream().value
+    cur = _stream().value or 0
     batch, keep = [p], []
     for ref, st in _PAIR_COUNTERS:
         t = ref()
         if t is None or t is p or getattr(t, "pp_host", None) is not None:
             continue
-        if st == cur and t.device == p.device:
+        # (written on this stream, or on another one whose map this stream has already taken over -- and waited for)
+        if (st == cur or getattr(t, "pp_seen_stream", None) == cur) and t.device == p.device:
             batch.append(t)
         else:
             keep.append((ref, st))
