@@ -458,18 +458,15 @@ def main():
     ops.PROFILER = None
     sync()
     t_prime = time.perf_counter() - t_prime
-    # per-launch HIP events for the roofline object: created here (~20 ms of host time), only recorded inside the timed region
-    timed_profiler = ops.LaunchProfiler(reserve=launches_per_step * args.steps + 16)
+    for _ in range(args.warmup):
+        step()
+    # per-launch HIP events for the roofline object: created here, only recorded inside the timed region
+    ops.PROFILER = ops.LaunchProfiler(reserve=launches_per_step * args.steps + 16)
     # a serving process freezes the objects of its set-up and keeps the cyclic collector out of the request path: a
     # generation-2 pass over the model / scene object graph is a 20 - 40 ms stall at an arbitrary point of a step
     gc.collect()
     gc.freeze()
     gc.disable()
-    # (both before the warm-up steps, so that the GPU is not left idle for ~100 ms between the warm-up and the timed region: the
-    # first timed step used to run 2 ms slower than the others)
-    for _ in range(args.warmup):
-        step()
-    ops.PROFILER = timed_profiler
     sync()
     host0 = host_cpu_state()
     stats["local_ms"], stats["exchange_events"] = [], []
