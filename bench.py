@@ -458,15 +458,20 @@ def main():
     ops.PROFILER = None
     sync()
     t_prime = time.perf_counter() - t_prime
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     # per-launch HIP events for the roofline object: created here, only recorded inside the timed region
-    ops.PROFILER = ops.LaunchProfiler(reserve=launches_per_step * args.steps + 16)
+    timed_profiler = ops.LaunchProfiler(reserve=launches_per_step * args.steps + 16)
     # a serving process freezes the objects of its set-up and keeps the cyclic collector out of the request path: a
     # generation-2 pass over the model / scene object graph is a 20 - 40 ms stall at an arbitrary point of a step
     gc.collect()
     gc.freeze()
     gc.disable()
+    # the LAST warm-up step runs after that pause (~100 ms with an idle GPU, after which the first step ran 2 ms slower than the
+    # others): W warm-up steps in all, the timed region starts behind a working GPU
+    if args.warmup >= 1:
+        step()
+    ops.PROFILER = timed_profiler
     sync()
     host0 = host_cpu_state()
     stats["local_ms"], stats["exchange_events"] = [], []
