@@ -356,6 +356,21 @@ def self_check(runner, batches, device, oracle_case):
     return checks
 
 
+def self_launch(n):
+    """re-run this command line as n ranks under torch.distributed.run (same interpreter, a free port on 127.0.0.1)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,7 +390,12 @@ def main():
     ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on
+        # 127.0.0.1) and pass rank 0's JSON line through; under torch.distributed.run the environment is already set
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert args.gpus in (1, world), "--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -416,7 +436,7 @@ def main():
     stats = {"proposals": 0, "instances": 0, "local_ms": [], "exchange_events": []}
     input_prefetch = not args.no_input_prefetch
 
-    def step(profile=False):
+    def step(profile=False, input_prefetch=input_prefetch):
         local = {}
         stats["proposals"] = stats["instances"] = 0
         t_local = time.perf_counter()
@@ -521,6 +541,18 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # the same step WITHOUT the next batch's coordinate manager being built during the current batch: what one cold scene
+    # costs (reported beside the pipelined figure, never as `value`)
+    single_scene_ms = None
+    if input_prefetch:
+        step(input_prefetch=False)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(input_prefetch=False)
+        sync()
+        single_scene_ms = round(1e3 * (time.perf_counter() - t1) / 3, 2)
+
     stage_ms = None
     if args.stage_timing:
         runner.stage_timing = True
@@ -588,6 +620,7 @@ def main():
                                    "+ ScorerUnet + NMS" % (len(tiles), radius, total_points, len(scene.pos)),
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "input_prefetch": input_prefetch,  # next batch's coordinate manager built during the current batch
+                       "single_scene_ms": single_scene_ms,  # a step that builds its own coordinate manager first (3 steps, untimed region)
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],
                        "setup_s": round(t_gen, 1), "priming_s": round(t_prime, 2), "stage_ms": stage_ms, "multi_gpu": multi,

@@ -145,14 +145,15 @@ class _CounterPool(threading.local):
     """Small zero-initialised device counters (pair counts, overflow flags, sizes ...) handed out as slices of one zeroed block
     per thread -- every `torch.zeros(2)` was a fill launch of its own (~80 per bench step on the two builder threads and the
     main thread; the small configurations are paced by their dispatches).  A block is never reused: when it is exhausted a
-    fresh one is allocated, so a counter stays valid for as long as its tensor lives.  Per thread = per stream: the fill of a
-    block is ordered on the stream the thread launches on."""
+    fresh one is allocated, so a counter stays valid for as long as its tensor lives.  One block per thread AND stream (the
+    main thread also launches on a side stream, e.g. the overlap-pair pass): the fill of a block is ordered on the stream whose
+    kernels use its counters, and the block comes from that stream's allocator pool."""
 
     def __init__(self):
         self.blocks = {}
 
     def take(self, n, dtype, device):
-        key = (dtype, device)
+        key = (dtype, device, _stream().value or 0)
         blk = self.blocks.get(key)
         if blk is None or blk[1] + n > blk[0].numel():
             blk = self.blocks[key] = [torch.zeros(2048, dtype=dtype, device=device), 0]
@@ -177,12 +178,14 @@ def _pairs_of(nbr):
 
 
 _PAIR_COUNTERS = []  # (weakref to a device pair counter, raw stream it was written on): counters nobody has read yet
+_PAIR_LOCK = threading.Lock()  # (builder threads register counters while the main thread reads them)
 
 
 def _register_pairs(p):
-    if len(_PAIR_COUNTERS) >= 512:  # (inference never reads them: drop the dead ones now and then)
-        _PAIR_COUNTERS[:] = [(r, st) for r, st in _PAIR_COUNTERS if r() is not None][-256:]
-    _PAIR_COUNTERS.append((weakref.ref(p), _stream().value or 0))
+    with _PAIR_LOCK:
+        if len(_PAIR_COUNTERS) >= 512:  # (inference never reads them: drop the dead ones now and then)
+            _PAIR_COUNTERS[:] = [(r, st) for r, st in _PAIR_COUNTERS if r() is not None][-256:]
+        _PAIR_COUNTERS.append((weakref.ref(p), _stream().value or 0))
     return p
 
 
@@ -195,19 +198,20 @@ def _pairs_host(p):
         return v
     cur = _stream().value or 0
     batch, keep = [p], []
-    for ref, st in _PAIR_COUNTERS:
-        t = ref()
-        if t is None or t is p or getattr(t, "pp_host", None) is not None:
-            continue
-        # (written on this stream, or on another one whose map this stream has already taken over -- and waited for)
-        if (st == cur or getattr(t, "pp_seen_stream", None) == cur) and t.device == p.device:
-            batch.append(t)
-        else:
-            keep.append((ref, st))
+    with _PAIR_LOCK:
+        for ref, st in _PAIR_COUNTERS:
+            t = ref()
+            if t is None or t is p or getattr(t, "pp_host", None) is not None:
+                continue
+            # (only counters written on the calling stream: nothing orders this read behind another stream's kernels)
+            if st == cur and t.device == p.device:
+                batch.append(t)
+            else:
+                keep.append((ref, st))
+        _PAIR_COUNTERS[:] = keep
     vals = torch.stack([t.reshape(()).to(torch.int64) for t in batch]).tolist()
     for t, val in zip(batch, vals):
         t.pp_host = int(val)
-    _PAIR_COUNTERS[:] = keep
     return p.pp_host
 
 
@@ -1536,9 +1540,16 @@ class _GroupingCache(threading.local):
 _GROUPINGS = _GroupingCache()
 
 
+def clear_groupings():
+    """drop the calling thread's cached groupings (training.train_step calls this at every step boundary: the entries pin
+    multi-million-row id tensors, and an id buffer rewritten through a raw pointer keeps its version counter)"""
+    _GROUPINGS.items.clear()
+
+
 def _grouping_of(index, n_seg):
     for it in _GROUPINGS.items:
-        if it[0].data_ptr() == index.data_ptr() and it[0].shape == index.shape and it[1] == index._version and it[2] == n_seg:
+        if it[0].data_ptr() == index.data_ptr() and it[0].shape == index.shape and it[0].stride() == index.stride() \
+                and it[0].dtype == index.dtype and it[1] == index._version and it[2] == n_seg:
             return it[3]
     g = group_by_key(index.to(torch.int32), n_seg, ids=None)
     _GROUPINGS.items.append((index, index._version, n_seg, g))

@@ -19,6 +19,8 @@ that were absent everywhere move to trailing buckets and stop blocking the overl
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 BUCKET_BYTES = 32 << 20
 
 
@@ -169,4 +171,5 @@ def train_step(model, data, optimizer, epoch, device, world_size=1, group=None, 
         else:
             allreduce_gradients(list(model.parameters()), world_size, group=group)
     optimizer.step()
+    ops.clear_groupings()  # (the cached segment groupings of this step's id tensors)
     return float(model.loss.detach())
