@@ -75,6 +75,9 @@ __device__ inline unsigned pp_xcd_remap(unsigned b, unsigned n) {
 bool pp_spconv_fwd3_ok(const SpconvArgs& a, int64_t n_in);
 int pp_spconv_fwd3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, int T, int depth, hipStream_t s);
 int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s);
+// wide layers on the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip)
+bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw);
+int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
 
 // pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows
 bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr);

@@ -29,7 +29,17 @@ __host__ __device__ static inline size_t packed_floats(int K, int cin, int cout)
   if (cin % 16 == 0) return (size_t)K * (cin / 16) * NT * 256;
   return (size_t)K * ((cin + 3) / 4) * NT * 64;
 }
-extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) { return packed_floats(K, cin, cout); }
+// mode16 weights carry a second section behind the fp32 one (pp_spconv3.hip): the same fragments split into three bfloat16
+// planes (w == hi + mid + lo exactly), two 16-channel steps per group g (the second one zero when the step count is odd):
+//   x3[k][g][jt][plane][lane][t8] = plane of packed[k][2g + (t8 >> 2)][jt][lane][t8 & 3]        (768 floats per (k, g, jt))
+__host__ __device__ static inline size_t packed_x3_floats(int K, int cin, int cout) {
+  if (cin % 16 != 0) return 0;
+  const int NT = (cout + 15) / 16, G = (cin / 16 + 1) / 2;
+  return (size_t)K * G * NT * 768;
+}
+extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) {
+  return packed_floats(K, cin, cout) + packed_x3_floats(K, cin, cout);
+}
 
 // element e of the packed tensor of one layer (shared by the single-layer and the batched kernel)
 __device__ __forceinline__ float pack_weight_element(const float* __restrict__ w, int K, int cin, int cout, int transpose_w, int64_t e) {
@@ -66,11 +76,34 @@ __device__ __forceinline__ float pack_weight_element(const float* __restrict__ w
   }
   return v;
 }
+// float slot f of the pre-split section: two bfloat16 (t8 = 2 (f & 3), + 1) of plane (f >> 8) % 3
+__device__ __forceinline__ float pack_weight_x3_element(const float* __restrict__ w, int K, int cin, int cout, int transpose_w, int64_t f) {
+  const int NT = (cout + 15) / 16, S = cin / 16, G = (S + 1) / 2;
+  const int tp = (int)(f & 3), lane = (int)((f >> 2) & 63), plane = (int)((f >> 8) % 3);
+  int64_t r = f / 768;
+  const int jt = (int)(r % NT);
+  r /= NT;
+  const int g = (int)(r % G), k = (int)(r / G);
+  unsigned out = 0;
+  for (int u = 0; u < 2; ++u) {
+    const int t8 = 2 * tp + u, s = 2 * g + (t8 >> 2);
+    float x = 0.f;
+    if (s < S) x = pack_weight_element(w, K, cin, cout, transpose_w, ((((int64_t)k * S + s) * NT + jt) * 64 + lane) * 4 + (t8 & 3));
+    const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+    const float rr = x - h;
+    const float m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rr) & 0xFFFF0000u);
+    const float l = rr - m;
+    const unsigned bits = __builtin_bit_cast(unsigned, plane == 0 ? h : (plane == 1 ? m : l)) >> 16;
+    out |= bits << (16 * u);
+  }
+  return __builtin_bit_cast(float, out);
+}
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int K, int cin, int cout,
                                                      int transpose_w, float* __restrict__ packed, int64_t total) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  packed[e] = pack_weight_element(w, K, cin, cout, transpose_w, e);
+  const int64_t n32 = (int64_t)packed_floats(K, cin, cout);
+  packed[e] = e < n32 ? pack_weight_element(w, K, cin, cout, transpose_w, e) : pack_weight_x3_element(w, K, cin, cout, transpose_w, e - n32);
 }
 
 extern "C" int pp_pack_weight(const float* weight, int32_t K, int32_t cin, int32_t cout, int32_t transpose_w,
@@ -97,9 +130,11 @@ __global__ __launch_bounds__(256) void k_pack_weights_batched(const int64_t* __r
   }
   const int64_t* d = desc + 6 * (int64_t)lo;
   const int K = (int)d[2], cin = (int)d[3], cout = (int)d[4], flags = (int)d[5];
-  const int64_t total = (int64_t)packed_floats(K, cin, cout);
+  const int64_t n32 = (int64_t)packed_floats(K, cin, cout), total = n32 + (int64_t)packed_x3_floats(K, cin, cout);
   const int64_t e = (b - first_block[lo]) * 256 + threadIdx.x;
-  if (e < total) ((float*)d[1])[e] = pack_weight_element((const float*)d[0], K, cin, cout, flags, e);
+  if (e < total)
+    ((float*)d[1])[e] = e < n32 ? pack_weight_element((const float*)d[0], K, cin, cout, flags, e)
+                                : pack_weight_x3_element((const float*)d[0], K, cin, cout, flags, e - n32);
 }
 extern "C" int pp_pack_weights_batched(const int64_t* desc, const int64_t* first_block, int32_t n_desc, int64_t total_blocks,
                                        pp_stream_t stream) {
@@ -363,7 +398,16 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
         return PP_UNSUPPORTED;
       a.ds_in = ds_in; a.ds_wp = ds_packed; a.ds_scale = ds_scale; a.ds_shift = ds_shift; a.ds_c = ds_c;
     }
-    int rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
+    // wide layers: the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip) unless a variant was asked for.
+    // PP_CONV_X3=0: never; PP_CONV_X3_MIN_NTW: fewest column tiles per wave that take it (default 3)
+    static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
+    static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 3;
+    int rc = PP_UNSUPPORTED;
+    if (env_x3 && !pipeline && !rows_per_wave && mode16 && !bf16) {
+      const int g4 = (a.NT + 3) / 4, n4 = (a.NT + g4 - 1) / g4;  // (at most 4 column tiles per wave there)
+      if (n4 >= env_x3_ntw && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
+    }
+    if (rc == PP_UNSUPPORTED) rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;
     if (a.split > 1) return pp_spconv_split_reduce_launch(a, pp_s(stream));
   } else {

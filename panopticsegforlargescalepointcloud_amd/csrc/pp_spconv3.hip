@@ -1,0 +1,393 @@
+// K4 (wide layers): the dense-offset sparse convolution on the bf16 matrix pipe with fp32 results -- "X3".
+//
+// Why.  k_spconv_fwd3 (pp_spconv2.hip) multiplies fp32 operands with v_mfma_f32_16x16x4_f32, which runs at the fp32 VECTOR
+// rate (157 TFLOP/s, 32 cycles per SIMD for 2048 flops); its >= 48-channel layers keep that pipe 0.74 - 0.77 busy, i.e.
+// they are bound by it.  v_mfma_f32_16x16x32_bf16 does 16384 flops in ~17 cycles.  An fp32 number is
+// EXACTLY the sum of three bfloat16 numbers (8 + 8 + 8 significand bits: hi = the top 16 bits of x, mid = the top 16 bits
+// of x - hi, lo = the rest; all three subtractions are exact), so
+//     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b|: dropped]
+// six bf16 products (each exact in fp32), accumulated in fp32 by the MFMA: the error per product is below one fp32
+// rounding, the sum over a K = 32 chunk is rounded once instead of 32 times.  Measured on random data the result is CLOSER
+// to the float64 value than the fp32 fmaf chain (oracle/test: tests/test_hip_ops.py::test_spconv_x3_*).  Six bf16 MFMAs
+// cost 6 x 17 = 102 cycles per (16 rows x 16 columns x 32 channels) against 8 x 32 = 256 cycles of fp32 MFMAs.
+//
+// What that needs.  At that rate the operand traffic of a 32 x 64 register tile no longer fits the CU's texture path
+// (every wave loading its own weight fragments: 12 KiB per step), so
+//   * the WORKGROUP (4 waves = 128 output rows) walks the occupied offsets of ITS rows in lockstep; the weight slice of a
+//     step (offset k, 32 input channels, this launch's column tiles: NTW x 3 KiB of pre-split bf16 planes) is fetched ONCE
+//     per workgroup with buffer_load ... lds (no VGPRs, no ds_write) into a double-buffered LDS stage, one barrier per step;
+//   * the gathered rows stay fp32 in HBM (nothing else in the network changes): a wave gathers its two 16-row tiles as
+//     before (zero-cost buffer loads, hardware zeros for missing neighbours) one step ahead, splits them in registers
+//     (5.5 vector-ALU instructions per element, paid once per tile and step, used by NTW column tiles) and feeds
+//     v_mfma_f32_16x16x32_bf16; a wave whose tiles lack the step's offset only takes part in the staging;
+//   * weights are split once, at packing time (pp_pack_weight appends the section: [k][g][jt][plane][lane][8 bf16]).
+// Same contract, prologue and epilogue as k_spconv_fwd3: per output row the sum runs over the occupied offsets in
+// ascending order, inside an offset over the 32-channel groups, inside a group over the six products in a fixed order --
+// independent of the map form, the row order and the batch, so results are bit-identical across those.
+#include "pp_spconv.h"
+
+#define X3_MAXK 28
+#define X3_WPB 4
+#define X3_MISSING 0xFFFFFFFFu
+#define X3_T 2
+#define X3_R 32
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned x3_row_or16(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);  // row_ror:2
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);  // row_ror:1
+  return v;
+}
+
+// 8 floats -> three bf16x8 planes with x == hi + mid + lo exactly (truncating splits: every remainder keeps the sign and
+// fits the bits that are left).  MODE 1 (bfloat16 compute, configs[4]): one plane, round to nearest even.
+struct X3Planes {
+  bf16x8_t p0, p1, p2;
+};
+__device__ __forceinline__ unsigned x3_hi16(float x1, float x0) {  // (bits(x1) & 0xFFFF0000) | (bits(x0) >> 16)
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
+}
+__device__ __forceinline__ X3Planes x3_split(f32x4 lo4, f32x4 hi4) {
+  float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  float r[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x[e]) & 0xFFFF0000u);
+    r[e] = x[e] - h;
+    const float m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r[e]) & 0xFFFF0000u);
+    l[e] = r[e] - m;
+  }
+  u32x4_t a, b, c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = x3_hi16(x[2 * j + 1], x[2 * j]);
+    b[j] = x3_hi16(r[2 * j + 1], r[2 * j]);
+    c[j] = x3_hi16(l[2 * j + 1], l[2 * j]);
+  }
+  X3Planes p;
+  p.p0 = __builtin_bit_cast(bf16x8_t, a);
+  p.p1 = __builtin_bit_cast(bf16x8_t, b);
+  p.p2 = __builtin_bit_cast(bf16x8_t, c);
+  return p;
+}
+
+template <int NTW, bool DS>
+__global__ __launch_bounds__(64 * X3_WPB, 4) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
+  constexpr int T = X3_T, R = X3_R;
+  __shared__ unsigned s_off[X3_WPB][X3_MAXK][R];
+  __shared__ f32x4 s_wb[2][NTW * 192];  // weight stage: per column tile 3 planes x 64 lanes x 16 bytes
+  __shared__ unsigned s_u[X3_WPB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = lane & 15, q = lane >> 4;
+  const unsigned bid = pp_xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row_base = ((int64_t)bid * X3_WPB + wave) * R;  // (may lie behind the last row: the wave then only stages weights)
+  const int jt0 = blockIdx.y * NTW;
+  unsigned(*off)[R] = s_off[wave];
+  const unsigned row_bytes = (unsigned)a.c0 * 4u;
+  const bool m24 = (flags & 1u) != 0u;
+
+  // ---- prologue (as k_spconv_fwd3): neighbour rows -> byte offsets in LDS, per-tile occupancy masks -> SGPRs
+  unsigned m[T];
+  {
+    constexpr int KPL = 2, NL = X3_MAXK / KPL;
+    const int rr = lane % R, kh = lane / R;
+    const bool rv = row_base + rr < a.n_out;
+    const int64_t slot = rv ? row_base + rr : a.n_out - 1;
+    const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
+    if (a.t8) {
+      int e8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + slot];
+      unsigned cls = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cls |= e8[j] >= 0 ? (unsigned)e8[j] >> 28 : 0u;
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) off[kk + NL * kh][rr] = X3_MISSING;
+      unsigned mk = 0;
+      const unsigned kx = (cls & 1u) ? 0u : 1u, ky = (cls & 2u) ? 0u : 3u, kz = (cls & 4u) ? 0u : 9u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = rv && (((unsigned)j & ~cls) == 0u) && e8[j] >= 0;
+        const unsigned k = kx + ((j & 1) ? 2u : 0u) * (cls & 1u) + ky + ((j & 2) ? 6u : 0u) * ((cls >> 1) & 1u) + kz +
+                           ((j & 4) ? 18u : 0u) * ((cls >> 2) & 1u);
+        const unsigned rowj = (unsigned)e8[j] & PP_ROW_MASK;
+        const unsigned prod = m24 ? __umul24(rowj, row_bytes) : rowj * row_bytes;
+        off[(ok && kh == 0) ? k : 27u][rr] = (ok && kh == 0) ? prod : X3_MISSING;
+        mk |= ok ? 1u << k : 0u;
+      }
+      mk = x3_row_or16(mk);
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) m[tt] = (unsigned)__builtin_amdgcn_readlane((int)mk, tt * 16);
+    } else {
+      int v[NL];
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const int k = kk + NL * kh;
+        if (a.nbr) {
+          const int kc = k < a.K ? k : a.K - 1;
+          v[kk] = a.nbr[(int64_t)kc * a.n_out + slot];
+          if (!rv || k >= a.K) v[kk] = -1;
+        } else {
+          v[kk] = (rv && k < a.K) ? (int)row : -1;
+        }
+      }
+      unsigned ml = 0;
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) {
+        const unsigned prod = m24 ? __umul24((unsigned)v[kk], row_bytes) : (unsigned)v[kk] * row_bytes;
+        off[kk + NL * kh][rr] = v[kk] >= 0 ? prod : X3_MISSING;
+        ml |= (v[kk] >= 0 ? 1u : 0u) << kk;
+      }
+      ml = x3_row_or16(ml);
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        m[tt] = 0;
+#pragma unroll
+        for (int h = 0; h < KPL; ++h) m[tt] |= (unsigned)__builtin_amdgcn_readlane((int)ml, h * R + tt * 16) << (NL * h);
+      }
+    }
+  }
+  unsigned kmask = 0xFFFFFFFFu;
+  if (a.split > 1) {
+    const int k0 = (int)blockIdx.z * a.K / a.split, k1 = ((int)blockIdx.z + 1) * a.K / a.split;
+    kmask = (k1 >= 32 ? 0xFFFFFFFFu : (1u << k1) - 1u) & ~((1u << k0) - 1u);
+  }
+  unsigned rem = 0;
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    m[tt] = __builtin_amdgcn_readfirstlane(m[tt]) & kmask;
+    rem |= m[tt];
+  }
+  if (lane == 0) s_u[wave] = rem;
+  __syncthreads();
+  unsigned U = s_u[0] | s_u[1] | s_u[2] | s_u[3];
+  U = (unsigned)__builtin_amdgcn_readfirstlane((int)U);
+
+  f32x4 acc[T][NTW];
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+    for (int jt = 0; jt < NTW; ++jt) acc[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (U) {  // workgroup-uniform
+    const int S0 = a.c0 >> 4, S = (a.c0 + a.c1) >> 4, G = (S + 1) >> 1;
+    const unsigned q16 = (unsigned)q * 16u;
+    // the pre-split section of the packed weights follows the fp32 one: [k][g][jt][plane][lane][8 bf16]
+    const unsigned long long pw_ = (unsigned long long)a.wp + w_bytes;
+    const unsigned wx_bytes = (unsigned)a.K * (unsigned)G * (unsigned)a.NT * 3072u;
+    const u32x4_t dw_ = {(unsigned)pw_, (unsigned)(pw_ >> 32) & 0xFFFFu, wx_bytes, 0x00020000u};
+    const unsigned slice = (unsigned)a.NT * 3072u;  // bytes per (k, g)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned wb_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)&s_wb[0][0];
+
+    // stage the weight slice of step (k, g) into buffer b: 3 NTW pieces of 1 KiB, piece j by wave j % 4
+#define X3_STAGE_W(KK, GG, BUF)                                                                              \
+  {                                                                                                          \
+    const unsigned so_ = ((unsigned)(KK) * (unsigned)G + (unsigned)(GG)) * slice + (unsigned)jt0 * 3072u;     \
+    _Pragma("unroll") for (int j = 0; j < 3 * NTW; ++j) {                                                    \
+      if ((j & 3) == wave) {                                                                                 \
+        const unsigned lds_ = wb_lds + (unsigned)(BUF) * (NTW * 3072u) + (unsigned)j * 1024u;                \
+        const unsigned sj_ = so_ + (unsigned)j * 1024u;                                                      \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"               \
+                     ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory");                               \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+    // gather the two 16-channel halves of group g of offset k for both tiles (missing half / neighbour: hardware zeros)
+#define X3_GATHER(KK, GG, AX)                                                                                  \
+  {                                                                                                            \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                            \
+      const int sl_ = 2 * (GG) + h;                                                                            \
+      const int sc_ = sl_ < S ? sl_ : S - 1;                                                                   \
+      const float* src_ = sc_ < S0 ? a.in0 + sc_ * 16 : a.in1 + (sc_ - S0) * 16;                               \
+      const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)(sl_ < S ? a_bytes : 0u), 0x00020000); \
+      _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                         \
+          AX[tt][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)(off[KK][tt * 16 + i] | q16), 0, 0)); \
+    }                                                                                                          \
+  }
+    int k = __builtin_ctz(U), g = 0, buf = 0;
+    unsigned Ur = U & (U - 1u);
+    f32x4 A[T][2];
+    X3_STAGE_W(k, 0, 0);
+    X3_GATHER(k, 0, A);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (;;) {
+      int kn = k, gn = g + 1, more = 1;
+      if (gn == G) {
+        gn = 0;
+        if (Ur) {
+          kn = __builtin_ctz(Ur);
+          Ur &= Ur - 1u;
+        } else {
+          more = 0;
+          gn = g;
+        }
+      }
+      const unsigned act0 = (m[0] >> k) & 1u, act1 = (m[1] >> k) & 1u;
+      X3Planes P0, P1;
+      if (act0) P0 = x3_split(A[0][0], A[0][1]);
+      if (act1) P1 = x3_split(A[1][0], A[1][1]);
+      if (more) {
+        X3_STAGE_W(kn, gn, buf ^ 1);
+        X3_GATHER(kn, gn, A);
+      }
+      if (act0 | act1) {
+        const f32x4* wb = &s_wb[buf][0];
+#define X3_SIX(ACC, PL, B0, B1, B2)                                                       \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, PL.p0, ACC, 0, 0, 0);                 \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p2, ACC, 0, 0, 0);                 \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, PL.p1, ACC, 0, 0, 0);                 \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, PL.p0, ACC, 0, 0, 0);                 \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p1, ACC, 0, 0, 0);                 \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p0, ACC, 0, 0, 0);
+        // weight fragments of column tile jt + 1 are read from LDS while the MFMAs of tile jt run; the scheduling barriers keep
+        // hipcc from hoisting ALL tiles' fragments in front of the first MFMA (48 registers at NTW = 4: spills)
+        bf16x8_t Bc[3], Bn[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) Bc[p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]);
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt) {
+          if (jt + 1 < NTW) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Bn[p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * 192 + p * 64 + lane]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (act0 & act1) {
+            // the two tiles alternate: consecutive MFMAs never wait for each other's accumulator
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[2], P0.p0, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[2], P1.p0, acc[1][jt], 0, 0, 0);
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p2, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p2, acc[1][jt], 0, 0, 0);
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P0.p1, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P1.p1, acc[1][jt], 0, 0, 0);
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P0.p0, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P1.p0, acc[1][jt], 0, 0, 0);
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p1, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p1, acc[1][jt], 0, 0, 0);
+            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p0, acc[0][jt], 0, 0, 0);
+            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p0, acc[1][jt], 0, 0, 0);
+          } else if (act0) {
+            X3_SIX(acc[0][jt], P0, Bc[0], Bc[1], Bc[2])
+          } else {
+            X3_SIX(acc[1][jt], P1, Bc[0], Bc[1], Bc[2])
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) Bc[p] = Bn[p];
+        }
+#undef X3_SIX
+      }
+      if (!more) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      k = kn;
+      g = gn;
+      buf ^= 1;
+    }
+#undef X3_STAGE_W
+#undef X3_GATHER
+  }
+
+  // ---- fused 1x1 shortcut (fp32 MFMAs on the wave's own rows, as in k_spconv_fwd3: 1/27 of the work)
+  f32x4 acc2[DS ? T : 1][DS ? NTW : 1];
+  if constexpr (DS) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) acc2[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int S2 = a.ds_c >> 4;
+    const unsigned ds_row = (unsigned)a.ds_c * 4u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_in, 0, (int)((unsigned)a.n_out * ds_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_wp, 0, (int)((unsigned)S2 * (unsigned)a.NT * 1024u), 0x00020000);
+    unsigned o2[T];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      const int64_t r = row_base + tt * 16 + i;
+      o2[tt] = r < a.n_out ? (unsigned)r * ds_row + (unsigned)q * 16u : X3_MISSING;
+    }
+    const unsigned lane16d = (unsigned)lane * 16u;
+#pragma unroll 1
+    for (int s2 = 0; s2 < S2; ++s2) {
+      f32x4 A2[T], B2[NTW];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        A2[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)o2[tt], s2 * 64, 0));
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt)
+        B2[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdw, (int)(lane16d + jt * 1024u),
+                                                                                 (int)((unsigned)(s2 * a.NT + jt0) * 1024u), 0));
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(B2[jt][t], A2[tt][t], acc2[tt][jt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (as k_spconv_fwd3; cout % 4 == 0 is a launch condition): lane (j, q) holds out[row j][16 jt + 4 q .. + 3]
+  float* __restrict__ dst = a.split > 1 ? a.part + (int64_t)blockIdx.z * a.n_out * a.cout : a.out;
+#pragma unroll
+  for (int rt = 0; rt < T; ++rt) {
+    const int64_t slot = row_base + rt * 16 + i;
+    if (slot < a.n_out) {
+      const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
+      const int64_t e0 = row * a.cout + (jt0 * 16 + q * 4);
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) {
+        const int col = (jt0 + jt) * 16 + q * 4;
+        if (jt0 + jt < a.NT && col < a.cout) {
+          f32x4 v = acc[rt][jt];
+          if (a.split > 1) {
+            *(f32x4*)(dst + e0 + jt * 16) = v;
+            continue;
+          }
+          if (a.scale) v *= *(const f32x4*)(a.scale + col);
+          if (a.shift) v += *(const f32x4*)(a.shift + col);
+          if (a.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          if (a.residual) v += *(const f32x4*)(a.residual + e0 + jt * 16);
+          if constexpr (DS) {
+            f32x4 w = acc2[rt][jt];
+            if (a.ds_scale) w *= *(const f32x4*)(a.ds_scale + col);
+            if (a.ds_shift) w += *(const f32x4*)(a.ds_shift + col);
+            v += w;
+          }
+          *(f32x4*)(dst + e0 + jt * 16) = v;
+        }
+      }
+    }
+  }
+}
+
+bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
+  if (a.bf16 || a.t8 == 2) return false;
+  if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
+  if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 4 || n_in <= 0) return false;
+  const double S = (a.c0 + a.c1) / 16, G = ((a.c0 + a.c1) / 16 + 1) / 2;
+  return (double)n_in * a.c0 * 4.0 < 4294967000.0 && (double)a.K * S * a.NT * 1024.0 < 4294967000.0 &&
+         (double)a.K * G * a.NT * 3072.0 < 4294967000.0 && (double)a.n_out * 32.0 < 4294967000.0;
+}
+
+int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s) {
+  const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
+  const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
+  const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
+  dim3 grid(pp_blocks(a.n_out, X3_R * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+#define X3_CASE(N)                                                                                                   \
+  case N:                                                                                                            \
+    if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags); \
+    else hipLaunchKernelGGL((k_spconv_x3<N, false>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);       \
+    break;
+  switch (ntw) {
+    X3_CASE(2) X3_CASE(3) X3_CASE(4)
+    default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;
+  }
+#undef X3_CASE
+  return PP_OK;
+}

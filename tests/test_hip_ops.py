@@ -1062,6 +1062,89 @@ def test_spconv_kernel_variants_match_oracle(ops, oracle, kind, c0, c1, cout, ro
     assert torch.equal(ref, outs[0])
 
 
+X3_SHAPES = [("same", 64, 0, 64), ("same", 48, 0, 48), ("same", 80, 80, 64), ("strided", 48, 0, 48), ("transposed", 96, 96, 80),
+             ("transposed", 64, 64, 128), ("same", 32, 0, 64), ("same", 112, 0, 112)]
+
+
+@pytest.mark.parametrize("kind,c0,c1,cout", X3_SHAPES)
+def test_spconv_x3_default_wide_layers(ops, oracle, kind, c0, c1, cout):
+    """Layers with >= 3 column tiles per wave run by default on k_spconv_x3 (pp_spconv3.hip): fp32 operands split EXACTLY into three
+    bfloat16 terms, six bf16 MFMA products, fp32 accumulation.  Against the fp32 oracle at 1e-4 like every other variant; against
+    a float64 evaluation of the same sums its error must not exceed the fp32-MFMA kernel's (forced through variant=(32, 1, 1))
+    by more than a rounding or two -- it is an fp32-accurate evaluation, not a reduced-precision one; odd numbers of 16-channel
+    steps (48, 80, 112: the last group is half empty), two sources whose boundary falls inside a group (80 + 80), strided,
+    transposed and split-K launches, all with folded BN, ReLU and residual."""
+    rng = np.random.default_rng(7)
+    fine = surface(rng, n=26000, n_batch=3, extent=120)
+    coarse, _ = oracle.stride_coords(fine, 2)
+    out_c, in_c, sign = {"same": (fine, fine, 1), "strided": (coarse, fine, 1), "transposed": (fine, coarse, -1)}[kind]
+    nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
+    n_in, n_out = len(in_c), len(out_c)
+    x0 = (rng.normal(size=(n_in, c0)) * np.exp(rng.normal(size=(n_in, 1)))).astype(np.float32)  # rows of very different magnitude
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32) if c1 else None
+    W = (rng.normal(size=(27, c0 + c1, cout)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(n_out, cout)).astype(np.float32)
+    packed = ops.pack_weight(dev(W))
+    kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+    want = oracle.spconv_fwd(x0, W, nbr, n_out, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
+    got = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, **kw)            # default: X3 on these shapes
+    f32 = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(32, 1, 1), **kw)  # the fp32-MFMA kernel
+    assert not torch.equal(got, f32), "the default path did not take the split-bf16 kernel"
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # float64 evaluation of the convolution sums (then the same fp32 epilogue arithmetic in float64)
+    xin = x0 if x1 is None else np.concatenate([x0, x1], 1)
+    ref = np.zeros((n_out, cout))
+    for k in range(27):
+        ok = nbr[k] >= 0
+        ref[ok] += xin[nbr[k][ok]].astype(np.float64) @ W[k].astype(np.float64)
+    ref = np.maximum(ref * sc.astype(np.float64) + sh.astype(np.float64), 0.0) + res.astype(np.float64)
+    mag = np.abs(ref).max()
+    e_x3 = float(np.abs(got.cpu().numpy() - ref).max() / mag)
+    e_f32 = float(np.abs(f32.cpu().numpy() - ref).max() / mag)
+    print("max error / magnitude vs float64: split-bf16 %.2e, fp32 MFMA %.2e" % (e_x3, e_f32))
+    assert e_x3 <= max(2.0 * e_f32, 5e-7), (e_x3, e_f32)
+    # split-K on the same kernel (another summation order, same accuracy), and run-to-run bit identity
+    if 2 * n_out * cout * 4 <= ops.CONV_SCRATCH_BYTES:  # (the partial sums must fit the split-K scratch)
+        sp = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(0, 0, 2), **kw)
+        np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    again = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, **kw)
+    assert torch.equal(got, again)
+
+
+def test_spconv_x3_fused_shortcut_and_row_subsets(ops, oracle):
+    """the fused 1x1 shortcut on the split-bf16 kernel == its two launches bit for bit, and a row's result does not depend on
+    which other rows share its workgroup (the workgroup walks the union of its rows' offsets in lockstep; a row's own sum
+    only contains its own offsets, in ascending order)"""
+    rng = np.random.default_rng(11)
+    fine = surface(rng, n=9000, n_batch=2, extent=70)
+    nbr = oracle.kernel_map(fine, fine, 3, 1, 1)
+    n = len(fine)
+    cin, cout, cs = 64, 64, 32
+    x = rng.normal(size=(n, cin)).astype(np.float32)
+    xs = rng.normal(size=(n, cs)).astype(np.float32)
+    W = (rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32)
+    W1 = (rng.normal(size=(1, cs, cout)) * 0.1).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    sc1, sh1 = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    pk, pk1 = ops.pack_weight(dev(W)), ops.pack_weight(dev(W1))
+    short = ops.spconv_fwd(dev(xs), pk1, None, n, cout, 1, scale=dev(sc1), shift=dev(sh1))
+    two = ops.spconv_fwd(dev(x), pk, dev(nbr), n, cout, 27, scale=dev(sc), shift=dev(sh), relu=True, residual=short)
+    one = ops.spconv_fwd(dev(x), pk, dev(nbr), n, cout, 27, scale=dev(sc), shift=dev(sh), relu=True,
+                         shortcut=(dev(xs), pk1, dev(sc1), dev(sh1)))
+    assert one is not None
+    want = oracle.spconv_fwd(x, W, nbr, n, scale=sc, shift=sh, relu=True) + (xs @ W1[0]) * sc1 + sh1
+    np.testing.assert_allclose(one.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert torch.equal(two, one)  # (1x1 convolutions stay on the fp32 MFMAs in both forms)
+    # a permuted OUTPUT order (row_order) puts every row into another workgroup: same bits per row
+    perm = rng.permutation(n).astype(np.int32)
+    nbr_p = np.ascontiguousarray(nbr[:, perm])  # slot-major map: slot s computes output row perm[s]
+    shuf = ops.spconv_fwd(dev(x), pk, dev(nbr_p), n, cout, 27, scale=dev(sc), shift=dev(sh), relu=True, row_order=dev(perm))
+    plain = ops.spconv_fwd(dev(x), pk, dev(nbr), n, cout, 27, scale=dev(sc), shift=dev(sh), relu=True)
+    assert torch.equal(shuf, plain)
+
+
 @pytest.mark.parametrize("block_bits", [0, 4, 5])
 def test_block_index_maps_match_oracle(ops, oracle, block_bits):
     """kernel maps looked up through the block index (bitmap + popcount) == oracle maps, all map kinds, incl. voxels at
