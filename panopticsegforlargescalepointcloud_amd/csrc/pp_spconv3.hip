@@ -31,6 +31,9 @@
 #define X3_MISSING 0xFFFFFFFFu
 #define X3_T 2
 #define X3_R 32
+#ifndef X3_WAVES
+#define X3_WAVES 4  // waves per SIMD the register budget is set for (A/B builds: 3)
+#endif
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -51,6 +54,15 @@ __device__ __forceinline__ unsigned x3_hi16(float x1, float x0) {  // (bits(x1) 
   return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, x0), 0x07060302u);
 }
 __device__ __forceinline__ X3Planes x3_split(f32x4 lo4, f32x4 hi4) {
+#if defined(X3_ABLATE) && X3_ABLATE == 2
+  {
+    X3Planes p;
+    p.p0 = __builtin_bit_cast(bf16x8_t, lo4);
+    p.p1 = __builtin_bit_cast(bf16x8_t, hi4);
+    p.p2 = __builtin_bit_cast(bf16x8_t, lo4);
+    return p;
+  }
+#endif
   float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
   float r[8], l[8];
 #pragma unroll
@@ -74,8 +86,17 @@ __device__ __forceinline__ X3Planes x3_split(f32x4 lo4, f32x4 hi4) {
   return p;
 }
 
+#if X3_ABLATE == 3
+__device__ __forceinline__ f32x4 x3_mfma(bf16x8_t b, bf16x8_t a, f32x4 c) {
+  asm volatile("" ::"v"(b), "v"(a));
+  return c;
+}
+#else
+#define x3_mfma(B, A, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(B, A, C, 0, 0, 0)
+#endif
+
 template <int NTW, bool DS>
-__global__ __launch_bounds__(64 * X3_WPB, 4) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
+__global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
   constexpr int T = X3_T, R = X3_R;
   __shared__ unsigned s_off[X3_WPB][X3_MAXK][R];
   __shared__ f32x4 s_wb[2][NTW * 192];  // weight stage: per column tile 3 planes x 64 lanes x 16 bytes
@@ -98,7 +119,38 @@ __global__ __launch_bounds__(64 * X3_WPB, 4) void k_spconv_x3(SpconvArgs a, unsi
     const bool rv = row_base + rr < a.n_out;
     const int64_t slot = rv ? row_base + rr : a.n_out - 1;
     const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
-    if (a.t8) {
+    if (a.t8 == 2) {
+      // compact same-level map (pp_map_compact): table filled with MISSING, then the wave's present entries -- one contiguous run
+      // of the entry array -- dropped into their (offset, row) slots; LDS operations of a wave execute in program order
+#pragma unroll
+      for (int kk = 0; kk < NL; ++kk) off[kk + NL * kh][rr] = X3_MISSING;
+      const unsigned mrow = (rv && kh == 0) ? a.cm_mask[slot] : 0u;
+      if (row_base < a.n_out) {
+        const int64_t chunks = (a.n_out + 31) >> 5;
+        const int64_t c0 = row_base >> 5, c1 = c0 + 1 < chunks ? c0 + 1 : chunks;
+        const int e0 = a.cm_start[c0], e1 = a.cm_start[c1];
+        for (int eb = e0; eb < e1; eb += 256) {
+          int v4[4];
+          unsigned t4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = eb + u * 64 + lane;
+            const int ec = e < e1 ? e : e1 - 1;
+            v4[u] = a.nbr[ec];
+            t4[u] = a.cm_tag[ec];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = eb + u * 64 + lane;
+            const unsigned prod = m24 ? __umul24((unsigned)v4[u], row_bytes) : (unsigned)v4[u] * row_bytes;
+            if (e < e1) off[t4[u] >> 6][t4[u] & 31u] = prod;  // (tag = offset << 6 | output row & 63; a wave owns 32 rows)
+          }
+        }
+      }
+      const unsigned mk = x3_row_or16(mrow);
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) m[tt] = (unsigned)__builtin_amdgcn_readlane((int)mk, tt * 16);
+    } else if (a.t8) {
       int e8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + slot];
@@ -206,89 +258,131 @@ __global__ __launch_bounds__(64 * X3_WPB, 4) void k_spconv_x3(SpconvArgs a, unsi
       const float* src_ = sc_ < S0 ? a.in0 + sc_ * 16 : a.in1 + (sc_ - S0) * 16;                               \
       const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)(sl_ < S ? a_bytes : 0u), 0x00020000); \
       _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                         \
-          AX[tt][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)(off[KK][tt * 16 + i] | q16), 0, 0)); \
+          AX[tt][h] = X3_ABLATE == 1 ? (f32x4){1.f, 2.f, 3.f, (float)off[KK][tt * 16 + i]}                      \
+                                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)(off[KK][tt * 16 + i] | q16), 0, 0)); \
     }                                                                                                          \
   }
-    int k = __builtin_ctz(U), g = 0, buf = 0;
+    // ---- the workgroup's step sequence: (offset k of U ascending) x (group g); three positions are live: the step being
+    // computed (k0, g0), the next one (weights being staged, rows in flight since the previous step) and the one after
+    // (rows gathered now).  X3_AHEAD = 1 (A/B builds): rows only one step ahead.
+#ifndef X3_AHEAD
+#define X3_AHEAD 1
+#endif
+// X3_ABLATE (profiling builds only, profiles/build_x3_variants.sh; results are wrong by construction): 1 = no row gathers,
+// 2 = no operand split, 3 = no MFMAs, 4 = no weight staging, 5 = no per-step barrier
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
+#endif
+#ifndef X3_BDEPTH
+#define X3_BDEPTH 2  // weight fragments of one column tile (1) or two (2: the next tile's LDS reads run beside the MFMAs) in registers
+#endif
+#define X3_ADV(KI, GI, UR, OK)            \
+  {                                       \
+    if (GI + 1 < G) {                     \
+      ++GI;                               \
+    } else if (UR) {                      \
+      KI = __builtin_ctz(UR);             \
+      UR &= UR - 1u;                      \
+      GI = 0;                             \
+    } else {                              \
+      OK = 0;                             \
+    }                                     \
+  }
+    int k0 = __builtin_ctz(U), g0 = 0, buf = 0;
     unsigned Ur = U & (U - 1u);
-    f32x4 A[T][2];
-    X3_STAGE_W(k, 0, 0);
-    X3_GATHER(k, 0, A);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (;;) {
-      int kn = k, gn = g + 1, more = 1;
-      if (gn == G) {
-        gn = 0;
-        if (Ur) {
-          kn = __builtin_ctz(Ur);
-          Ur &= Ur - 1u;
-        } else {
-          more = 0;
-          gn = g;
-        }
-      }
-      const unsigned act0 = (m[0] >> k) & 1u, act1 = (m[1] >> k) & 1u;
-      X3Planes P0, P1;
-      if (act0) P0 = x3_split(A[0][0], A[0][1]);
-      if (act1) P1 = x3_split(A[1][0], A[1][1]);
-      if (more) {
-        X3_STAGE_W(kn, gn, buf ^ 1);
-        X3_GATHER(kn, gn, A);
-      }
-      if (act0 | act1) {
-        const f32x4* wb = &s_wb[buf][0];
-#define X3_SIX(ACC, PL, B0, B1, B2)                                                       \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, PL.p0, ACC, 0, 0, 0);                 \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p2, ACC, 0, 0, 0);                 \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, PL.p1, ACC, 0, 0, 0);                 \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, PL.p0, ACC, 0, 0, 0);                 \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p1, ACC, 0, 0, 0);                 \
-  ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, PL.p0, ACC, 0, 0, 0);
-        // weight fragments of column tile jt + 1 are read from LDS while the MFMAs of tile jt run; the scheduling barriers keep
-        // hipcc from hoisting ALL tiles' fragments in front of the first MFMA (48 registers at NTW = 4: spills)
-        bf16x8_t Bc[3], Bn[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) Bc[p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]);
-#pragma unroll
-        for (int jt = 0; jt < NTW; ++jt) {
-          if (jt + 1 < NTW) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) Bn[p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * 192 + p * 64 + lane]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (act0 & act1) {
-            // the two tiles alternate: consecutive MFMAs never wait for each other's accumulator
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[2], P0.p0, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[2], P1.p0, acc[1][jt], 0, 0, 0);
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p2, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p2, acc[1][jt], 0, 0, 0);
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P0.p1, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P1.p1, acc[1][jt], 0, 0, 0);
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P0.p0, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[1], P1.p0, acc[1][jt], 0, 0, 0);
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p1, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p1, acc[1][jt], 0, 0, 0);
-            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P0.p0, acc[0][jt], 0, 0, 0);
-            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bc[0], P1.p0, acc[1][jt], 0, 0, 0);
-          } else if (act0) {
-            X3_SIX(acc[0][jt], P0, Bc[0], Bc[1], Bc[2])
-          } else {
-            X3_SIX(acc[1][jt], P1, Bc[0], Bc[1], Bc[2])
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) Bc[p] = Bn[p];
-        }
-#undef X3_SIX
-      }
-      if (!more) break;
+    int k1 = k0, g1 = g0, ok1 = 1;
+    X3_ADV(k1, g1, Ur, ok1);
+    int k2 = k1, g2 = g1, ok2 = ok1;
+    if (ok2) X3_ADV(k2, g2, Ur, ok2);
+    f32x4 AA[T][2], AB[T][2];
+    X3_STAGE_W(k0, g0, 0);
+    X3_GATHER(k0, g0, AA);
+    if (X3_AHEAD == 2 && ok1) {
+      X3_GATHER(k1, g1, AB);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (the weights and the first step's rows; the second step's rows stay in flight)
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      k = kn;
-      g = gn;
-      buf ^= 1;
     }
+    __syncthreads();
+    // one step: split the rows of (k0, g0) out of ACUR, refill ACUR with the rows of the step after next, stage the next
+    // step's weights, multiply; then advance.  ACUR alternates between AA and AB (loop unrolled by two: no register copies)
+#define X3_STEP(ACUR)                                                                                             \
+  {                                                                                                               \
+    const unsigned act0 = (m[0] >> k0) & 1u, act1 = (m[1] >> k0) & 1u;                                            \
+    X3Planes P0, P1;                                                                                              \
+    if (act0) P0 = x3_split(ACUR[0][0], ACUR[0][1]);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (act1) P1 = x3_split(ACUR[1][0], ACUR[1][1]);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (ok1 && X3_ABLATE != 4) X3_STAGE_W(k1, g1, buf ^ 1);                                                       \
+    if (X3_AHEAD == 2 ? ok2 : ok1) {                                                                              \
+      if (X3_AHEAD == 2) { X3_GATHER(k2, g2, ACUR); } else { X3_GATHER(k1, g1, ACUR); }                           \
+    }                                                                                                             \
+    if (act0 | act1) {                                                                                            \
+      const f32x4* wb = &s_wb[buf][0];                                                                            \
+      bf16x8_t Bf[2][3];                                                                                          \
+      if (X3_BDEPTH == 2) {                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]); \
+      }                                                                                                           \
+      _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) {                                                        \
+        if (X3_BDEPTH == 2) {                                                                                     \
+          if (jt + 1 < NTW) {                                                                                     \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                         \
+                Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * 192 + p * 64 + lane]);           \
+          }                                                                                                       \
+        } else {                                                                                                  \
+          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                           \
+              Bf[jt & 1][p] = __builtin_bit_cast(bf16x8_t, wb[jt * 192 + p * 64 + lane]);                         \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][1], B2 = Bf[jt & 1][2];                                \
+        if (act0 & act1) {                                                                                        \
+          acc[0][jt] = x3_mfma(B2, P0.p0, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B2, P1.p0, acc[1][jt]);                   \
+          acc[0][jt] = x3_mfma(B0, P0.p2, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B0, P1.p2, acc[1][jt]);                   \
+          acc[0][jt] = x3_mfma(B1, P0.p1, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B1, P1.p1, acc[1][jt]);                   \
+          acc[0][jt] = x3_mfma(B1, P0.p0, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B1, P1.p0, acc[1][jt]);                   \
+          acc[0][jt] = x3_mfma(B0, P0.p1, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B0, P1.p1, acc[1][jt]);                   \
+          acc[0][jt] = x3_mfma(B0, P0.p0, acc[0][jt]);                   \
+          acc[1][jt] = x3_mfma(B0, P1.p0, acc[1][jt]);                   \
+        } else if (act0) {                                                                                        \
+          X3_SIX(acc[0][jt], P0, B0, B1, B2)                                                                      \
+        } else {                                                                                                  \
+          X3_SIX(acc[1][jt], P1, B0, B1, B2)                                                                      \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (!ok1) break;                                                                                              \
+    /* before the barrier: this wave's share of the next step's weights has landed (and, in issue order before it, the rows of */ \
+    /* the next step); only the rows gathered in THIS step may still be in flight */                              \
+    if (X3_AHEAD == 2 && ok2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+    if (X3_ABLATE != 5) __syncthreads();                                                                          \
+    k0 = k1; g0 = g1; k1 = k2; g1 = g2; ok1 = ok2;                                                                \
+    if (ok2) X3_ADV(k2, g2, Ur, ok2);                                                                             \
+    buf ^= 1;                                                                                                     \
+  }
+#define X3_SIX(ACC, PL, B0, B1, B2)                                                       \
+  ACC = x3_mfma(B2, PL.p0, ACC);                 \
+  ACC = x3_mfma(B0, PL.p2, ACC);                 \
+  ACC = x3_mfma(B1, PL.p1, ACC);                 \
+  ACC = x3_mfma(B1, PL.p0, ACC);                 \
+  ACC = x3_mfma(B0, PL.p1, ACC);                 \
+  ACC = x3_mfma(B0, PL.p0, ACC);
+    for (;;) {
+      X3_STEP(AA);
+#if X3_AHEAD == 2
+      X3_STEP(AB);
+#endif
+    }
+#undef X3_SIX
+#undef X3_STEP
+#undef X3_ADV
 #undef X3_STAGE_W
 #undef X3_GATHER
   }
@@ -366,7 +460,7 @@ __global__ __launch_bounds__(64 * X3_WPB, 4) void k_spconv_x3(SpconvArgs a, unsi
 }
 
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
-  if (a.bf16 || a.t8 == 2) return false;
+  if (a.bf16) return false;
   if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
   if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 4 || n_in <= 0) return false;
   const double S = (a.c0 + a.c1) / 16, G = ((a.c0 + a.c1) / 16 + 1) / 2;

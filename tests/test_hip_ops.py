@@ -1118,7 +1118,7 @@ def test_spconv_x3_fused_shortcut_and_row_subsets(ops, oracle):
     which other rows share its workgroup (the workgroup walks the union of its rows' offsets in lockstep; a row's own sum
     only contains its own offsets, in ascending order)"""
     rng = np.random.default_rng(11)
-    fine = surface(rng, n=9000, n_batch=2, extent=70)
+    fine = surface(rng, n=70000, n_batch=2, extent=200)  # (large enough that the launch is not split over the offsets)
     nbr = oracle.kernel_map(fine, fine, 3, 1, 1)
     n = len(fine)
     cin, cout, cs = 64, 64, 32
