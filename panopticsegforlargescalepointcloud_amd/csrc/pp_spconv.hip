@@ -37,9 +37,13 @@ __host__ __device__ static inline size_t packed_x3_floats(int K, int cin, int co
   const int NT = (cout + 15) / 16, G = (cin / 16 + 1) / 2;
   return (size_t)K * G * NT * 768;
 }
-extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) {
-  return packed_floats(K, cin, cout) + packed_x3_floats(K, cin, cout);
+// ... and a third one: the same fragments rounded to nearest-even bfloat16 (bfloat16 compute of the same kernel):
+//   b16[k][g][jt][lane][t8] = bf16(packed[k][2g + (t8 >> 2)][jt][lane][t8 & 3])                 (256 floats per (k, g, jt))
+__host__ __device__ static inline size_t packed_total_floats(int K, int cin, int cout) {
+  const size_t x3 = packed_x3_floats(K, cin, cout);
+  return packed_floats(K, cin, cout) + x3 + x3 / 3;
 }
+extern "C" size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout) { return packed_total_floats(K, cin, cout); }
 
 // element e of the packed tensor of one layer (shared by the single-layer and the batched kernel)
 __device__ __forceinline__ float pack_weight_element(const float* __restrict__ w, int K, int cin, int cout, int transpose_w, int64_t e) {
@@ -79,8 +83,11 @@ __device__ __forceinline__ float pack_weight_element(const float* __restrict__ w
 // float slot f of the pre-split section: two bfloat16 (t8 = 2 (f & 3), + 1) of plane (f >> 8) % 3
 __device__ __forceinline__ float pack_weight_x3_element(const float* __restrict__ w, int K, int cin, int cout, int transpose_w, int64_t f) {
   const int NT = (cout + 15) / 16, S = cin / 16, G = (S + 1) / 2;
-  const int tp = (int)(f & 3), lane = (int)((f >> 2) & 63), plane = (int)((f >> 8) % 3);
-  int64_t r = f / 768;
+  const int64_t nx3 = (int64_t)packed_x3_floats(K, cin, cout);
+  const bool rne = f >= nx3;  // the bfloat16 section: one plane per (k, g, jt)
+  if (rne) f -= nx3;
+  const int tp = (int)(f & 3), lane = (int)((f >> 2) & 63), plane = rne ? 3 : (int)((f >> 8) % 3);
+  int64_t r = rne ? f / 256 : f / 768;
   const int jt = (int)(r % NT);
   r /= NT;
   const int g = (int)(r % G), k = (int)(r / G);
@@ -93,7 +100,11 @@ __device__ __forceinline__ float pack_weight_x3_element(const float* __restrict_
     const float rr = x - h;
     const float m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rr) & 0xFFFF0000u);
     const float l = rr - m;
-    const unsigned bits = __builtin_bit_cast(unsigned, plane == 0 ? h : (plane == 1 ? m : l)) >> 16;
+    unsigned bits = __builtin_bit_cast(unsigned, plane == 0 ? h : (plane == 1 ? m : l)) >> 16;
+    if (plane == 3) {  // round to nearest even (finite inputs), as v_cvt_pk_bf16_f32 rounds the gathered rows
+      const unsigned u32 = __builtin_bit_cast(unsigned, x);
+      bits = (u32 + 0x7FFFu + ((u32 >> 16) & 1u)) >> 16;
+    }
     out |= bits << (16 * u);
   }
   return __builtin_bit_cast(float, out);
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_batched(const int64_t* __r
   }
   const int64_t* d = desc + 6 * (int64_t)lo;
   const int K = (int)d[2], cin = (int)d[3], cout = (int)d[4], flags = (int)d[5];
-  const int64_t n32 = (int64_t)packed_floats(K, cin, cout), total = n32 + (int64_t)packed_x3_floats(K, cin, cout);
+  const int64_t n32 = (int64_t)packed_floats(K, cin, cout), total = (int64_t)packed_total_floats(K, cin, cout);
   const int64_t e = (b - first_block[lo]) * 256 + threadIdx.x;
   if (e < total)
     ((float*)d[1])[e] = e < n32 ? pack_weight_element((const float*)d[0], K, cin, cout, flags, e)
@@ -403,7 +414,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
     static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 3;
     int rc = PP_UNSUPPORTED;
-    if (env_x3 && !pipeline && !rows_per_wave && mode16 && !bf16) {
+    if (env_x3 && !pipeline && !rows_per_wave && mode16) {
       const int g4 = (a.NT + 3) / 4, n4 = (a.NT + g4 - 1) / g4;  // (at most 4 column tiles per wave there)
       if (n4 >= env_x3_ntw && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
     }

@@ -27,7 +27,9 @@
 #include "pp_spconv.h"
 
 #define X3_MAXK 28
-#define X3_WPB 4
+#ifndef X3_WPB
+#define X3_WPB 4  // waves per workgroup (A/B builds: 8 = 256 rows share a staged weight slice)
+#endif
 #define X3_MISSING 0xFFFFFFFFu
 #define X3_T 2
 #define X3_R 32
@@ -86,6 +88,14 @@ __device__ __forceinline__ X3Planes x3_split(f32x4 lo4, f32x4 hi4) {
   return p;
 }
 
+__device__ __forceinline__ X3Planes x3_round(f32x4 lo4, f32x4 hi4) {  // MODE 1: one plane, round to nearest even
+  X3Planes p;
+  p.p0 = pp_bf16x8(lo4, hi4);
+  p.p1 = p.p0;
+  p.p2 = p.p0;
+  return p;
+}
+
 #if X3_ABLATE == 3
 __device__ __forceinline__ f32x4 x3_mfma(bf16x8_t b, bf16x8_t a, f32x4 c) {
   asm volatile("" ::"v"(b), "v"(a));
@@ -95,11 +105,16 @@ __device__ __forceinline__ f32x4 x3_mfma(bf16x8_t b, bf16x8_t a, f32x4 c) {
 #define x3_mfma(B, A, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(B, A, C, 0, 0, 0)
 #endif
 
-template <int NTW, bool DS>
+// MODE 0: fp32 results from exactly split operands (three planes, six products).  MODE 1: bfloat16 compute (configs[4],
+// pp_spconv_fwd_bf16): both operands rounded to nearest-even bfloat16 -- the weights at packing time (third section of the
+// packed buffer), the gathered rows in registers (v_cvt_pk_bf16_f32) -- ONE v_mfma_f32_16x16x32_bf16 per tile, column tile
+// and 32 channels, fp32 accumulation; same workgroup-synchronous walk, one 1 KiB weight plane per column tile staged.
+template <int NTW, bool DS, int MODE>
 __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
   constexpr int T = X3_T, R = X3_R;
   __shared__ unsigned s_off[X3_WPB][X3_MAXK][R];
-  __shared__ f32x4 s_wb[2][NTW * 192];  // weight stage: per column tile 3 planes x 64 lanes x 16 bytes
+  constexpr int PL = MODE == 1 ? 1 : 3;      // weight planes per column tile
+  __shared__ f32x4 s_wb[2][NTW * PL * 64];  // weight stage: per column tile PL planes x 64 lanes x 16 bytes
   __shared__ unsigned s_u[X3_WPB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -216,7 +231,9 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   }
   if (lane == 0) s_u[wave] = rem;
   __syncthreads();
-  unsigned U = s_u[0] | s_u[1] | s_u[2] | s_u[3];
+  unsigned U = 0;
+#pragma unroll
+  for (int w = 0; w < X3_WPB; ++w) U |= s_u[w];
   U = (unsigned)__builtin_amdgcn_readfirstlane((int)U);
 
   f32x4 acc[T][NTW];
@@ -229,25 +246,46 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     const int S0 = a.c0 >> 4, S = (a.c0 + a.c1) >> 4, G = (S + 1) >> 1;
     const unsigned q16 = (unsigned)q * 16u;
     // the pre-split section of the packed weights follows the fp32 one: [k][g][jt][plane][lane][8 bf16]
-    const unsigned long long pw_ = (unsigned long long)a.wp + w_bytes;
-    const unsigned wx_bytes = (unsigned)a.K * (unsigned)G * (unsigned)a.NT * 3072u;
+    // (MODE 1: the bfloat16 section behind that one: [k][g][jt][lane][8 bf16])
+    const unsigned x3_bytes = (unsigned)a.K * (unsigned)G * (unsigned)a.NT * 3072u;
+    const unsigned long long pw_ = (unsigned long long)a.wp + w_bytes + (MODE == 1 ? x3_bytes : 0u);
+    const unsigned wx_bytes = MODE == 1 ? x3_bytes / 3u : x3_bytes;
     const u32x4_t dw_ = {(unsigned)pw_, (unsigned)(pw_ >> 32) & 0xFFFFu, wx_bytes, 0x00020000u};
-    const unsigned slice = (unsigned)a.NT * 3072u;  // bytes per (k, g)
+    const unsigned slice = (unsigned)a.NT * (PL * 1024u);  // bytes per (k, g)
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned wb_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)&s_wb[0][0];
 
     // stage the weight slice of step (k, g) into buffer b: 3 NTW pieces of 1 KiB, piece j by wave j % 4
+#ifndef X3_STAGE_MODE
+#define X3_STAGE_MODE 0  // 0: buffer_load ... lds; 1 (A/B builds): loads into registers at the start of a step, ds_write at its end
+#endif
+    constexpr int NPW = (PL * NTW + X3_WPB - 1) / X3_WPB;  // pieces per wave
+    f32x4 wreg[X3_STAGE_MODE == 1 ? NPW : 1];
+    (void)wreg;
 #define X3_STAGE_W(KK, GG, BUF)                                                                              \
   {                                                                                                          \
-    const unsigned so_ = ((unsigned)(KK) * (unsigned)G + (unsigned)(GG)) * slice + (unsigned)jt0 * 3072u;     \
-    _Pragma("unroll") for (int j = 0; j < 3 * NTW; ++j) {                                                    \
-      if ((j & 3) == wave) {                                                                                 \
-        const unsigned lds_ = wb_lds + (unsigned)(BUF) * (NTW * 3072u) + (unsigned)j * 1024u;                \
-        const unsigned sj_ = so_ + (unsigned)j * 1024u;                                                      \
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"               \
-                     ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory");                               \
+    const unsigned so_ = ((unsigned)(KK) * (unsigned)G + (unsigned)(GG)) * slice + (unsigned)jt0 * (PL * 1024u); \
+    if (X3_STAGE_MODE == 1) {                                                                                \
+      const __amdgpu_buffer_rsrc_t rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)pw_, 0, (int)wx_bytes, 0x00020000); \
+      _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj)                                                     \
+          wreg[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                        \
+              rw_, (int)lane16, (int)(so_ + (unsigned)(jj * X3_WPB + wave) * 1024u), 0));                    \
+    } else {                                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < PL * NTW; ++j) {                                                 \
+        if ((j % X3_WPB) == wave) {                                                                          \
+          const unsigned lds_ = wb_lds + (unsigned)(BUF) * (NTW * PL * 1024u) + (unsigned)j * 1024u;              \
+          const unsigned sj_ = so_ + (unsigned)j * 1024u;                                                    \
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"           \
+                       ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory");                             \
+        }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
+  }
+    // (register staging: the pieces loaded at the start of the step go to LDS right before its barrier)
+#define X3_STAGE_FLUSH(BUF)                                                                                  \
+  if (X3_STAGE_MODE == 1) {                                                                                  \
+    _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj)                                                       \
+        if (jj * X3_WPB + wave < PL * NTW) s_wb[BUF][(jj * X3_WPB + wave) * 64 + lane] = wreg[jj];            \
   }
     // gather the two 16-channel halves of group g of offset k for both tiles (missing half / neighbour: hardware zeros)
 #define X3_GATHER(KK, GG, AX)                                                                                  \
@@ -296,6 +334,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     if (ok2) X3_ADV(k2, g2, Ur, ok2);
     f32x4 AA[T][2], AB[T][2];
     X3_STAGE_W(k0, g0, 0);
+    X3_STAGE_FLUSH(0);
     X3_GATHER(k0, g0, AA);
     if (X3_AHEAD == 2 && ok1) {
       X3_GATHER(k1, g1, AB);
@@ -310,9 +349,9 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   {                                                                                                               \
     const unsigned act0 = (m[0] >> k0) & 1u, act1 = (m[1] >> k0) & 1u;                                            \
     X3Planes P0, P1;                                                                                              \
-    if (act0) P0 = x3_split(ACUR[0][0], ACUR[0][1]);                                                              \
+    if (act0) P0 = MODE == 1 ? x3_round(ACUR[0][0], ACUR[0][1]) : x3_split(ACUR[0][0], ACUR[0][1]);               \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (act1) P1 = x3_split(ACUR[1][0], ACUR[1][1]);                                                              \
+    if (act1) P1 = MODE == 1 ? x3_round(ACUR[1][0], ACUR[1][1]) : x3_split(ACUR[1][0], ACUR[1][1]);               \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if (ok1 && X3_ABLATE != 4) X3_STAGE_W(k1, g1, buf ^ 1);                                                       \
     if (X3_AHEAD == 2 ? ok2 : ok1) {                                                                              \
@@ -320,22 +359,27 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     }                                                                                                             \
     if (act0 | act1) {                                                                                            \
       const f32x4* wb = &s_wb[buf][0];                                                                            \
-      bf16x8_t Bf[2][3];                                                                                          \
+      bf16x8_t Bf[2][PL];                                                                                         \
       if (X3_BDEPTH == 2) {                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]); \
+        _Pragma("unroll") for (int p = 0; p < PL; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]); \
       }                                                                                                           \
       _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) {                                                        \
         if (X3_BDEPTH == 2) {                                                                                     \
           if (jt + 1 < NTW) {                                                                                     \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                         \
-                Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * 192 + p * 64 + lane]);           \
+            _Pragma("unroll") for (int p = 0; p < PL; ++p)                                                        \
+                Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * (PL * 64) + p * 64 + lane]);     \
           }                                                                                                       \
         } else {                                                                                                  \
-          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                           \
-              Bf[jt & 1][p] = __builtin_bit_cast(bf16x8_t, wb[jt * 192 + p * 64 + lane]);                         \
+          _Pragma("unroll") for (int p = 0; p < PL; ++p)                                                          \
+              Bf[jt & 1][p] = __builtin_bit_cast(bf16x8_t, wb[jt * (PL * 64) + p * 64 + lane]);                   \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][1], B2 = Bf[jt & 1][2];                                \
+        if constexpr (MODE == 1) {                                                                                \
+          const bf16x8_t B0 = Bf[jt & 1][0];                                                                      \
+          if (act0) acc[0][jt] = x3_mfma(B0, P0.p0, acc[0][jt]);                                                  \
+          if (act1) acc[1][jt] = x3_mfma(B0, P1.p0, acc[1][jt]);                                                  \
+        } else {                                                                                                  \
+        const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][PL > 1 ? 1 : 0], B2 = Bf[jt & 1][PL > 2 ? 2 : 0];      \
         if (act0 & act1) {                                                                                        \
           acc[0][jt] = x3_mfma(B2, P0.p0, acc[0][jt]);                   \
           acc[1][jt] = x3_mfma(B2, P1.p0, acc[1][jt]);                   \
@@ -354,12 +398,14 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
         } else {                                                                                                  \
           X3_SIX(acc[1][jt], P1, B0, B1, B2)                                                                      \
         }                                                                                                         \
+        }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
       }                                                                                                           \
     }                                                                                                             \
     if (!ok1) break;                                                                                              \
     /* before the barrier: this wave's share of the next step's weights has landed (and, in issue order before it, the rows of */ \
     /* the next step); only the rows gathered in THIS step may still be in flight */                              \
+    X3_STAGE_FLUSH(buf ^ 1);                                                                                      \
     if (X3_AHEAD == 2 && ok2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
     if (X3_ABLATE != 5) __syncthreads();                                                                          \
@@ -384,6 +430,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 #undef X3_STEP
 #undef X3_ADV
 #undef X3_STAGE_W
+#undef X3_STAGE_FLUSH
 #undef X3_GATHER
   }
 
@@ -415,13 +462,23 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
       for (int jt = 0; jt < NTW; ++jt)
         B2[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdw, (int)(lane16d + jt * 1024u),
                                                                                  (int)((unsigned)(s2 * a.NT + jt0) * 1024u), 0));
+      if constexpr (MODE == 1) {
 #pragma unroll
-      for (int tt = 0; tt < T; ++tt)
+        for (int tt = 0; tt < T; ++tt) {
+          const s16x4 ah = pp_bf16x4(A2[tt]);
 #pragma unroll
-        for (int jt = 0; jt < NTW; ++jt)
+          for (int jt = 0; jt < NTW; ++jt)
+            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pp_bf16x4(B2[jt]), ah, acc2[tt][jt], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(B2[jt][t], A2[tt][t], acc2[tt][jt], 0, 0, 0);
+        for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(B2[jt][t], A2[tt][t], acc2[tt][jt], 0, 0, 0);
+      }
     }
   }
 
@@ -460,7 +517,6 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 }
 
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
-  if (a.bf16) return false;
   if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
   if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 4 || n_in <= 0) return false;
   const double S = (a.c0 + a.c1) / 16, G = ((a.c0 + a.c1) / 16 + 1) / 2;
@@ -473,10 +529,15 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
   dim3 grid(pp_blocks(a.n_out, X3_R * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
-#define X3_CASE(N)                                                                                                   \
-  case N:                                                                                                            \
-    if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags); \
-    else hipLaunchKernelGGL((k_spconv_x3<N, false>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);       \
+#define X3_CASE(N)                                                                                                          \
+  case N:                                                                                                                   \
+    if (a.bf16) {                                                                                                           \
+      if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true, 1>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);  \
+      else hipLaunchKernelGGL((k_spconv_x3<N, false, 1>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);         \
+    } else {                                                                                                                \
+      if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true, 0>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);  \
+      else hipLaunchKernelGGL((k_spconv_x3<N, false, 0>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);         \
+    }                                                                                                                       \
     break;
   switch (ntw) {
     X3_CASE(2) X3_CASE(3) X3_CASE(4)

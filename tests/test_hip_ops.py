@@ -1111,6 +1111,15 @@ def test_spconv_x3_default_wide_layers(ops, oracle, kind, c0, c1, cout):
         np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
     again = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, **kw)
     assert torch.equal(got, again)
+    # bfloat16 compute on the same kernel (one v_mfma_f32_16x16x32_bf16 per tile and 32 channels; weights rounded at packing
+    # time, rows in registers): the fp32 oracle on operands rounded to nearest-even bfloat16 (their products are exact in fp32)
+    rb = oracle.round_bf16
+    want_bf = oracle.spconv_fwd(rb(x0), rb(W), nbr, n_out, in1=None if x1 is None else rb(x1), scale=sc, shift=sh, relu=True,
+                                residual=res)
+    got_bf = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, bf16=True, **kw)
+    old_bf = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, bf16=True, variant=(32, 1, 1), **kw)  # k_spconv_fwd3
+    assert not torch.equal(got_bf, old_bf)
+    np.testing.assert_allclose(got_bf.cpu().numpy(), want_bf, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want_bf).max())))
 
 
 def test_spconv_x3_fused_shortcut_and_row_subsets(ops, oracle):
