@@ -40,6 +40,11 @@ class FastBatchNorm1d(nn.Module):
 
     def forward(self, x):
         if x.dim() == 2:
+            bn = self.batch_norm
+            if self.training and x.is_cuda and bn.momentum is not None and ops._sync_bn_group() is not None:
+                # SyncBN (training.enable_sync_bn): the heads' BatchNorm joins the all-reduced statistics of the sparse layers
+                running = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
+                return ME._BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn.eps, False, bn.momentum, running)
             return self.batch_norm(x)
         if x.dim() == 3:
             return self.batch_norm(x.permute(0, 2, 1)).permute(0, 2, 1)

@@ -918,11 +918,88 @@ def bn_bwd_reduce(x, dy):
     return a, b
 
 
+# SyncBN for data-parallel training: the reference normalises over ALL cylinders of its batch of 4 on one GPU; with
+# the batch sharded over ranks the per-channel sum / sum of squares / row count are all-reduced so that every rank uses the
+# statistics of the whole batch.  None = per-replica statistics (the fused three-launch kernels).  training.enable_sync_bn sets it.
+SYNC_BN_GROUP = None   # a torch.distributed process group, or True for the default group
+SYNC_BN_STATS = {"all_reduces": 0}
+
+
+def _sync_bn_group():
+    g = SYNC_BN_GROUP
+    if g is None:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if g is True else g
+    return (dist, group) if dist.get_world_size(group) > 1 else None
+
+
+def _all_reduce_f64(dist, group, t):
+    """sum over the ranks of a small float64 device vector (RCCL all-reduce on device tensors; the gloo backend of the
+    single-GPU test box reduces on the host)"""
+    SYNC_BN_STATS["all_reduces"] += 1
+    if dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+def _bn_train_fwd_sync(sync, x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked):
+    dist, group = sync
+    n, c = x.shape
+    s, ss = channel_stats(x)
+    tot = _all_reduce_f64(dist, group, torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=x.device)]))
+    N = tot[2 * c]
+    mean = tot[:c] / N
+    var = (tot[c:2 * c] / N - mean * mean).clamp_min_(0.0)   # biased variance of the whole batch
+    rstd = torch.rsqrt(var + eps)
+    if running_mean is not None:
+        with torch.no_grad():
+            running_mean.mul_(1.0 - momentum).add_((momentum * mean).float())
+            running_var.mul_(1.0 - momentum).add_((momentum * var * (N / (N - 1.0).clamp_min(1.0))).float())
+            if num_batches_tracked is not None:
+                num_batches_tracked.add_(1)
+    w = torch.ones(c, dtype=torch.float64, device=x.device) if weight is None else weight.double()
+    b = torch.zeros(c, dtype=torch.float64, device=x.device) if bias is None else bias.double()
+    scale = w * rstd
+    y = affine_act(x, scale.float(), (b - mean * scale).float(), act=1 if relu else 0)
+    return y, mean, rstd
+
+
+def _bn_train_bwd_sync(sync, x, dy, y_relu, weight, save_mean, save_rstd):
+    dist, group = sync
+    n, c = x.shape
+    if y_relu is not None:
+        dy = dy * (y_relu > 0).to(dy.dtype)
+    a, b = bn_bwd_reduce(x, dy)              # local sum(dy), sum(dy * x), float64
+    tot = _all_reduce_f64(dist, group, torch.cat([a, b, torch.tensor([float(n)], dtype=torch.float64, device=x.device)]))
+    N = tot[2 * c]
+    A = tot[:c]
+    B = (tot[c:2 * c] - save_mean * A) * save_rstd      # sum over the whole batch of dy * xhat
+    w = torch.ones(c, dtype=torch.float64, device=x.device) if weight is None else weight.double()
+    # dx = w rstd (dy - mean(dy) - xhat mean(dy xhat)) with the means over the WHOLE batch; as one affine map of (dy, x):
+    #   dx = s dy + t x + u,  s = w rstd, t = -s rstd B / N, u = -s A / N - t mean
+    sc = w * save_rstd
+    t = -sc * save_rstd * B / N
+    u = -sc * A / N - t * save_mean
+    dx = torch.addcmul(torch.addcmul(u.float().expand_as(x), dy, sc.float()), x, t.float())
+    dweight = ((b - save_mean * a) * save_rstd).float()  # the local part: the gradient all-reduce adds the ranks'
+    return dx, dweight, a.float()
+
+
 def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked=None):
     """Training-mode BatchNorm1d (+ fused ReLU); running statistics (nullable) updated in place, num_batches_tracked (nullable
     int64 scalar on the device) incremented by the same launches.
     Returns (y, save_mean, save_rstd); the saved statistics are float64."""
     lib = _lib.load()
+    sync = _sync_bn_group()
+    if sync is not None:
+        return _bn_train_fwd_sync(sync, _need(x, torch.float32, "x"), weight, bias, eps, momentum, running_mean, running_var,
+                                  relu, num_batches_tracked)
     x = _need(x, torch.float32, "x")
     n, c = x.shape
     y = torch.empty_like(x)
@@ -945,6 +1022,9 @@ def bn_train_bwd(x, dy, y_relu, weight, save_mean, save_rstd):
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     dy = _need(dy, torch.float32, "dy")
+    sync = _sync_bn_group()
+    if sync is not None:
+        return _bn_train_bwd_sync(sync, x, dy, y_relu, weight, save_mean, save_rstd)
     n, c = x.shape
     dx = torch.empty_like(x)
     dwb = torch.empty(2, c, dtype=torch.float32, device=x.device)

@@ -3,7 +3,8 @@ averaged with bucketed all-reduces over RCCL (backend "nccl" on ROCm) / gloo, la
 
 The reference trains single-GPU (`train.py` -> `Trainer._train_epoch`, torch_points3d/trainer.py:150-200: set_input ->
 optimize_parameters = forward + backward + optimizer.step); its DDP switch is unused by the panoptic configs.  BatchNorm
-statistics stay per replica, as they would with DDP there (no SyncBN in the reference).
+statistics stay per replica by default, as they would with DDP there; `enable_sync_bn` (PP_SYNC_BN=1) all-reduces them so that
+N ranks x B/N cylinders normalise like the reference's one GPU x B cylinders (tests/test_syncbn_gpu.py).
 
 Buckets: xGMI is point-to-point (ring all-reduce is per-link bound), so few large messages beat many small ones; the
 whole model is 11.3 M fp32 parameters = 45 MB, i.e. two 32 MB buckets.  Parameters are bucketed in REVERSE registration
@@ -16,6 +17,8 @@ collectives in the same order whatever its local batch did.  A parameter that re
 `.grad = None` (one small MAX all-reduce of a has-gradient mask): the optimizer skips it exactly as on one GPU -- no
 weight decay, no Adam state for never-used parameters.  The same mask re-sorts the buckets after a step: parameters
 that were absent everywhere move to trailing buckets and stop blocking the overlap of the others."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -155,12 +158,23 @@ def allreduce_gradients(params, world_size=None, bucket_bytes=BUCKET_BYTES, grou
     return reducer.finish()
 
 
+def enable_sync_bn(group=True):
+    """Batch statistics over the cylinders of ALL ranks (SyncBN): every training-mode BatchNorm all-reduces its per-channel
+    sum, sum of squares and row count (forward) and sum(dy), sum(dy x) (backward), so 2 ranks x 2 cylinders normalise exactly
+    like the reference's one GPU x 4 cylinders (conf/training/7_area1.yaml:5 batch_size 4; the reference itself is single-GPU,
+    trainer.py:61-66).  group: a process group, True for the default one, None / False to go back to per-replica statistics.
+    PP_SYNC_BN=1 in the environment turns it on when train_step first runs with world_size > 1."""
+    ops.SYNC_BN_GROUP = group if group else None
+
+
 def train_step(model, data, optimizer, epoch, device, world_size=1, group=None, reducer=None):
     """set_input -> forward -> loss -> backward (gradient all-reduces overlapped) -> optimizer step.  Returns the local
     loss.  Pass a GradientReducer built once over model.parameters() to overlap; without one the reduction runs after
     backward."""
     if not model.training:  # nn.Module.train() walks every submodule (1.5 ms of host time for this model)
         model.train()
+    if world_size > 1 and ops.SYNC_BN_GROUP is None and os.environ.get("PP_SYNC_BN", "0") == "1":
+        enable_sync_bn(group if group is not None else True)
     model.set_input(data, device)
     optimizer.zero_grad(set_to_none=True)
     model.forward(epoch=epoch)
