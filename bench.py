@@ -587,25 +587,46 @@ def main():
             roof = {"bound": "mfma", "achieved": prof["flops"] / secs / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json; a
-        # PMC pass cannot run inside the timed bench).  FETCH_SIZE counts the 128-byte requests of wide streaming loads at
-        # 64 bytes and 64-byte row gathers in full (calibrated: profiles/r02_fetch_calibration.md), so half of the bytes the
-        # kernel streams with wide loads -- its kernel map, known exactly -- is added to the raw counter.
+        # PMC pass cannot run inside the timed bench).  FETCH_SIZE tallies 64 bytes per request and a request is <= 128 bytes
+        # (profiles/r05_fetch_calibration.md: known / raw = 1.06 for random 64-byte rows, 2.0 for 128 / 256 / 384-byte rows and all
+        # streaming loads): the convolutions gather every row in 64-byte pieces whatever its width (a lane quad reads one piece),
+        # so their gathers are counted in full; their wide streaming loads -- the kernel map, known exactly -- are counted half
+        # and added back.  Bounds: the gathers at 1.0 x and at 1.059 x the raw counter.
         roof["traffic"] = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 map_b = prof["map_bytes"] / max(prof["launches"], 1)
-                roof["traffic"] = tj["write_bytes_per_launch"] + tj["fetch_raw_bytes_per_launch"] + 0.5 * map_b
-                roof["traffic_bounds"] = [tj["write_bytes_per_launch"] + tj["fetch_raw_bytes_per_launch"],
-                                          tj["write_bytes_per_launch"] + 2.0 * tj["fetch_raw_bytes_per_launch"]]
+                w_, f_ = tj["write_bytes_per_launch"], tj["fetch_raw_bytes_per_launch"]
+                roof["traffic"] = w_ + f_ + 0.5 * map_b
+                roof["traffic_bounds"] = [w_ + f_ + 0.5 * map_b, w_ + 1.059 * f_ + 0.5 * map_b]
                 roof["map_bytes_per_launch"] = map_b
+                roof["traffic_over_algorithmic"] = roof["traffic"] / (prof["bytes"] / max(prof["launches"], 1))
+                fams = {}
+                for fam, pf in prof.get("by_family", {}).items():
+                    cj = tj.get("classes", {}).get(fam)
+                    if cj and pf["launches"]:
+                        n_ = pf["launches"]
+                        tr = cj["write_bytes_per_launch"] + cj["fetch_raw_bytes_per_launch"] + 0.5 * pf["map_bytes"] / n_
+                        fams[fam] = {"launches_per_step": n_ // max(event_steps, 1), "ms_per_step": pf["ms"] / event_steps,
+                                     "alg_bytes_per_launch": pf["bytes"] / n_, "traffic_per_launch": tr,
+                                     "traffic_over_algorithmic": tr / (pf["bytes"] / n_),
+                                     "frac_mfma_fp32": pf["flops"] / (pf["ms"] * 1e-3) / FP32_MFMA_PEAK,
+                                     "frac_hbm": pf["bytes"] / (pf["ms"] * 1e-3) / HBM_PEAK}
+                roof["by_kernel_family"] = fams  # fwd3 = fp32-MFMA kernel (<= 32-channel layers), x3 = split-operand kernel (wide layers)
                 roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE + FETCH_SIZE raw + 0.5 x kernel-map "
-                                          "bytes; calibration profiles/r02_fetch_calibration.md)")
+                                          "bytes; calibration profiles/r05_fetch_calibration.md)")
             except Exception:
                 pass
         roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)
-        roof.update({"kernel": "k_spconv_fwd3 (pp_spconv_fwd)", "launches_per_step": prof["launches"] // max(event_steps, 1), "event_steps": event_steps,
+        x3_on = os.environ.get("PP_CONV_X3", "1") != "0"
+        roof.update({"kernel": "k_spconv_fwd3 + k_spconv_x3 (pp_spconv_fwd)" if x3_on else "k_spconv_fwd3 (pp_spconv_fwd)",
+                     # fp32 operands and fp32-accurate results everywhere; which matrix pipe multiplies them
+                     "mfma_path": ("layers with >= 3 column tiles per wave: v_mfma_f32_16x16x32_bf16 on operands split exactly into "
+                                   "three bfloat16 terms, six products, fp32 accumulation (k_spconv_x3); the others: "
+                                   "v_mfma_f32_16x16x4_f32.  peak = the fp32 MFMA peak either way") if x3_on else
+                                  "v_mfma_f32_16x16x4_f32 on every layer (PP_CONV_X3=0)", "launches_per_step": prof["launches"] // max(event_steps, 1), "event_steps": event_steps,
                      "avg_launch_us": 1e3 * prof["ms"] / max(prof["launches"], 1),
                      "alg_GB_per_step": prof["bytes"] / event_steps / 1e9, "alg_TFLOP_per_step": prof["flops"] / event_steps / 1e12,
                      "hbm_GBps": prof["bytes"] / secs / 1e9, "mfma_TFLOPs": prof["flops"] / secs / 1e12,

@@ -212,6 +212,12 @@ int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t bloc
  * the input gradients of stride-1 convolutions reuse the forward map instead of a flipped copy of it.
  * n_in bounds the gathers: the fast kernel reads rows through a buffer descriptor of n_in * c0 * 4 bytes (missing
  * neighbours come back as hardware-checked zeros); inputs of 4 GiB or more per source take the slower kernel.
+ * The packed buffer (pp_packed_weight_floats floats; opaque to the caller) holds three sections when cin % 16 == 0: the fp32 MFMA
+ * fragments, the same fragments split EXACTLY into three bfloat16 planes (w == hi + mid + lo) and rounded to nearest-even
+ * bfloat16.  Launches with >= 3 sixteen-column tiles per wave (cout >= 48) evaluate their fp32 products from the split planes on
+ * v_mfma_f32_16x16x32_bf16 -- six bf16 products per fp32 product, fp32 accumulation, error below one fp32 rounding per
+ * product (csrc/pp_spconv3.hip; environment PP_CONV_X3=0: v_mfma_f32_16x16x4_f32 everywhere); pp_spconv_fwd_bf16 uses
+ * the rounded plane there.  Results are fp32 tensors in every case.
  * ---------------------------------------------------------------------------------------------- */
 size_t pp_packed_weight_floats(int32_t K, int32_t cin, int32_t cout);
 int pp_pack_weight(const float* weight /*[K,cin,cout]*/, int32_t K, int32_t cin, int32_t cout,

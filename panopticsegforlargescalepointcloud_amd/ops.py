@@ -89,30 +89,51 @@ class LaunchProfiler:
             fl += 2.0 * P * cin * cout
         return {"launches": len(self.records_w), "ms": ms, "bytes": b, "flops": fl}
 
+    @staticmethod
+    def kernel_family(cin, cout, K):
+        """which kernel the library runs a convolution of this shape on (mirrors spconv_fwd_impl, csrc/pp_spconv.hip): "x3" = the
+        split-operand kernel (>= PP_CONV_X3_MIN_NTW sixteen-column tiles per wave at <= 4 per wave), "fwd3" = the fp32-MFMA kernel"""
+        if os.environ.get("PP_CONV_X3", "1") == "0" or cin % 16 or cout % 4 or K < 2 or K > 27:
+            return "fwd3"
+        nt = (cout + 15) // 16
+        g4 = (nt + 3) // 4
+        return "x3" if (nt + g4 - 1) // g4 >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "3")) else "fwd3"
+
     def summarize(self, tag=None):
         torch.cuda.synchronize()
         tot_ms = tot_bytes = tot_flops = map_bytes = 0.0
         counts = self._pair_counts()
         n_used = 0
+        by_family = {}
         tags = self.tags if len(self.tags) == len(self.records) else [None] * len(self.records)
         map_k = self.map_k if len(self.map_k) == len(self.records) else [None] * len(self.records)
         for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg, mk in zip(self.records, counts, tags, map_k):
             if tag is not None and tg != tag:
                 continue
             n_used += 1
+            mb = 0.0
             if mk == -1:
-                map_bytes += 4.125 * n_out + 6.0 * P - 4.0 * K * n_out  # compact map: masks, chunk offsets, 6 bytes per present entry
+                mb += 4.125 * n_out + 6.0 * P - 4.0 * K * n_out  # compact map: masks, chunk offsets, 6 bytes per present entry
             elif mk is not None and K > 1:
-                map_bytes += 4.0 * (mk - K) * n_out  # (corrects the dense estimate below for 8-wide maps)
-            map_bytes += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
+                mb += 4.0 * (mk - K) * n_out  # (corrects the dense estimate below for 8-wide maps)
+            mb += 4.0 * K * n_out if K > 1 else 0.0  # what the kernel actually streams: the dense [K, n_out] map
+            map_bytes += mb
             # SURVEY.md 8(d): features read once + written once, weights once, one (in,out) int32 pair per map entry;
             # a fused 1x1 shortcut (ds_c input channels) adds its input rows, its weights and its flops
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
             b += 4.0 * n_out * ds_c + 4.0 * ds_c * cout
             tot_bytes += b
-            tot_flops += 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
-            tot_ms += e0.elapsed_time(e1)
-        return {"launches": n_used, "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes}
+            fl = 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
+            tot_flops += fl
+            ms = e0.elapsed_time(e1)
+            tot_ms += ms
+            f = by_family.setdefault(self.kernel_family(cin, cout, K), {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "map_bytes": 0.0})
+            f["launches"] += 1
+            f["ms"] += ms
+            f["bytes"] += b
+            f["flops"] += fl
+            f["map_bytes"] += mb
+        return {"launches": n_used, "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes, "by_family": by_family}
 
     def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12):
         """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""

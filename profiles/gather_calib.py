@@ -5,7 +5,9 @@ launches with KNOWN HBM traffic for rocprofv3 --pmc passes (profiles/calibrate_f
     gather64   out[i] = src[perm[i]], 64-byte rows, perm = random permutation of 32 M rows (2 GiB table, far beyond the
                256 MiB infinity cache): every row is fetched exactly once  reads 2.15 GB (rows) + 0.27 GB (index), writes 2.15 GB
     gather64s  the same kernel with the identity permutation                (streaming 64-byte rows)
-usage (GPU box): python profiles/gather_calib.py random|ident   (one gather pattern per process: the PMC summary averages per kernel)"""
+Round 5: the same for the row widths the convolutions actually gather -- 128, 192, 256 and 384 bytes (32 / 48 / 64 / 96 fp32 channels):
+    python profiles/gather_calib.py random|ident [row_bytes]    (2 GiB table whatever the width)
+usage (GPU box): python profiles/gather_calib.py random|ident [row_bytes]  (one gather pattern per process: the PMC summary averages per kernel)"""
 import os
 import sys
 
@@ -18,8 +20,9 @@ from panopticsegforlargescalepointcloud_amd import ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda")
-    n = 1 << 25
-    src = torch.randn(n, 16, device=dev)
+    row_bytes = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    n = (1 << 31) // row_bytes
+    src = torch.randn(n, row_bytes // 4, device=dev)
     g = torch.Generator(device="cpu").manual_seed(1)
     perm = torch.randperm(n, generator=g).to(dev)
     ident = torch.arange(n, device=dev)
@@ -38,7 +41,8 @@ def main():
     ops.gather_rows(src, index)
     e1.record()
     torch.cuda.synchronize()
-    print("gather64 %s: %.3f ms (%.0f GB/s of rows+index+out)" % (mode, e0.elapsed_time(e1), (n * (64 + 8 + 64)) / e0.elapsed_time(e1) / 1e6))
+    print("gather%d %s: %.3f ms (%.0f GB/s of rows+index+out)" % (row_bytes, mode, e0.elapsed_time(e1),
+                                                                 (n * (2 * row_bytes + 8)) / e0.elapsed_time(e1) / 1e6))
 
 
 if __name__ == "__main__":

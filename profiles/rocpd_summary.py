@@ -82,20 +82,35 @@ def traffic(db_fetch, db_write, out):
     bytes the kernel streams with wide loads (its kernel map, known exactly per launch):
         traffic = WRITE_SIZE + FETCH_SIZE_raw + 0.5 * map_bytes      (lower bound: raw, upper bound: 2 x raw)."""
     import json
-    res = {}
-    for name, db, counter in (("fetch", db_fetch, "FETCH_SIZE"), ("write", db_write, "WRITE_SIZE")):
-        con = sqlite3.connect(db)
-        n, tot = con.execute("select count(*), sum(value) from counters_collection where kernel_name like '%k_spconv_fwd%' "
-                             "and counter_name = ?", (counter,)).fetchone()
-        res[name + "_launches"] = n
-        res[name + "_KiB_total"] = tot
+    res = {"classes": {}}
+    # round 5: two kernel families -- k_spconv_fwd3 (fp32 MFMAs: the <= 32-channel layers) and k_spconv_x3 (split operands on the
+    # bf16 pipe: the wide layers); totals over both, and per family so that bench.py can set each beside its algorithmic bytes
+    fams = {"fwd3": "%k_spconv_fwd%", "x3": "%k_spconv_x3%"}
+    tot = {"fetch": [0, 0.0], "write": [0, 0.0]}
+    for fam, like in fams.items():
+        ent = {}
+        for name, db, counter in (("fetch", db_fetch, "FETCH_SIZE"), ("write", db_write, "WRITE_SIZE")):
+            con = sqlite3.connect(db)
+            n, kib = con.execute("select count(*), sum(value) from counters_collection where kernel_name like ? "
+                                 "and counter_name = ?", (like, counter)).fetchone()
+            n, kib = int(n or 0), float(kib or 0.0)
+            ent[name + "_launches"] = n
+            ent[name + ("_raw_bytes_per_launch" if name == "fetch" else "_bytes_per_launch")] = 1024.0 * kib / max(n, 1)
+            tot[name][0] += n
+            tot[name][1] += kib
+        res["classes"][fam] = ent
+    res["fetch_launches"], res["fetch_KiB_total"] = tot["fetch"]
+    res["write_launches"], res["write_KiB_total"] = tot["write"]
     fetch_raw = 1024.0 * res["fetch_KiB_total"] / max(res["fetch_launches"], 1)
     write_b = 1024.0 * res["write_KiB_total"] / max(res["write_launches"], 1)
-    res.update({"kernel": "k_spconv_fwd*", "fetch_raw_bytes_per_launch": fetch_raw, "write_bytes_per_launch": write_b,
+    res.update({"kernel": "k_spconv_fwd3 + k_spconv_x3", "fetch_raw_bytes_per_launch": fetch_raw, "write_bytes_per_launch": write_b,
                 "calibration": {"streaming_known_over_raw": 2.0, "gather64_known_over_raw": 1.059, "write_known_over_raw": 1.0,
-                                "source": "profiles/r02_fetch_calibration.md"},
+                                "source": "profiles/r05_fetch_calibration.md (64 .. 384-byte rows) / r02_fetch_calibration.md",
+                                "rule": "FETCH_SIZE tallies 64 bytes per request; a request is <= 128 bytes: full-line (128-byte) "
+                                        "requests count half, 64-byte requests -- every row gather of the convolutions, whatever "
+                                        "the row width: a lane quad reads one 64-byte piece -- count in full"},
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1` (all launches of "
-                        "both steps averaged); raw counters, see bench.py for the correction"})
+                        "all passes averaged); raw counters, see bench.py for the correction"})
     open(out, "w").write(json.dumps(res, indent=1) + "\n")
     print(res)
 
