@@ -415,8 +415,21 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 3;
     int rc = PP_UNSUPPORTED;
     if (env_x3 && !pipeline && !rows_per_wave && mode16) {
-      const int g4 = (a.NT + 3) / 4, n4 = (a.NT + g4 - 1) / g4;  // (at most 4 column tiles per wave there)
-      if (n4 >= env_x3_ntw && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
+      // column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
+      // gathers AND splits the rows again) -- 96->96 transposed onto 5.4 M rows 2942 -> 2348 us, 96->96 at 2.4 M rows 5566 -> 4662,
+      // 192->80 at 0.15 M rows 842 -> 656, 80->80 384 -> 333, 160->160 928 -> 799 (140 - 152 VGPRs and 45 - 51 KiB of LDS: three
+      // workgroups per CU instead of four); launches below 0.4 M rows stop at 5 (96->96 at 32 k rows 118 -> 135 us with 6), the
+      // fused-shortcut form at 4 (its second accumulator set would leave two waves per SIMD).  PP_CONV_X3_MAX_NTW = 4 .. 6 forces
+      // the bound (A/B runs, profiles/r05_ab_x3_ntw.txt).
+      static const int env_x3_max = getenv("PP_CONV_X3_MAX_NTW") ? atoi(getenv("PP_CONV_X3_MAX_NTW")) : 0;
+      const int mx = ds_in ? 4 : (env_x3_max >= 4 && env_x3_max <= 6 ? env_x3_max : (n_out >= 400000 ? 6 : 5));
+      int g4 = (a.NT + 3) / 4;
+      if ((a.NT + mx - 1) / mx < g4) g4 = (a.NT + mx - 1) / mx;
+      const int n4 = (a.NT + g4 - 1) / g4;
+      // two column tiles per wave pay only where a row brings >= 96 input channels (96->32 at 5.4 M rows 4309 -> 3849 us; 64->32
+      // loses 12 %, 32->32 is even: the operand split and the staging are per step, whatever the number of column tiles)
+      const bool wide_in = n4 == 2 && env_x3_ntw == 3 && (c0 + c1) >= 96;
+      if ((n4 >= env_x3_ntw || wide_in) && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
     }
     if (rc == PP_UNSUPPORTED) rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
   if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
-  if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 4 || n_in <= 0) return false;
+  if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 6 || n_in <= 0) return false;
   const double S = (a.c0 + a.c1) / 16, G = ((a.c0 + a.c1) / 16 + 1) / 2;
   return (double)n_in * a.c0 * 4.0 < 4294967000.0 && (double)a.K * S * a.NT * 1024.0 < 4294967000.0 &&
          (double)a.K * G * a.NT * 3072.0 < 4294967000.0 && (double)a.n_out * 32.0 < 4294967000.0;
@@ -540,7 +540,7 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
     }                                                                                                                       \
     break;
   switch (ntw) {
-    X3_CASE(2) X3_CASE(3) X3_CASE(4)
+    X3_CASE(2) X3_CASE(3) X3_CASE(4) X3_CASE(5) X3_CASE(6)
     default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;
   }
 #undef X3_CASE

@@ -97,7 +97,8 @@ class LaunchProfiler:
             return "fwd3"
         nt = (cout + 15) // 16
         g4 = (nt + 3) // 4
-        return "x3" if (nt + g4 - 1) // g4 >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "3")) else "fwd3"
+        ntw, min_ntw = (nt + g4 - 1) // g4, int(os.environ.get("PP_CONV_X3_MIN_NTW", "3"))
+        return "x3" if (ntw >= min_ntw or (ntw == 2 and min_ntw == 3 and cin >= 96)) else "fwd3"
 
     def summarize(self, tag=None):
         torch.cuda.synchronize()
@@ -888,6 +889,10 @@ def wgrad_pairs(nbr, K, row_order=None):
 # weight gradients without float atomics (PP_WGRAD_DETERMINISTIC=0: the atomic form; workspaces above the cap fall back to it)
 WGRAD_DETERMINISTIC = os.environ.get("PP_WGRAD_DETERMINISTIC", "1") != "0"
 WGRAD_DET_MAX_BYTES = int(os.environ.get("PP_WGRAD_DET_MAX_MB", "1024")) << 20
+# PP_WGRAD_DETERMINISTIC=strict: a weight gradient whose partial-sum workspace exceeds the cap raises instead of falling back to the
+# float-atomic kernel (the default warns once: from that size on the training step is no longer bit-reproducible)
+WGRAD_STRICT = os.environ.get("PP_WGRAD_DETERMINISTIC", "1").lower() == "strict"
+_WGRAD_WARNED = [False]
 
 
 def spconv_bwd_weight_pairs(inp, dout, wp, bf16=False):
@@ -909,6 +914,15 @@ def spconv_bwd_weight_pairs(inp, dout, wp, bf16=False):
                                                       _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _ptr(ws), nbytes,
                                                       _stream()), "pp_spconv_bwd_weight_pairs_det")
     else:
+        if WGRAD_DETERMINISTIC:
+            msg = ("weight gradient %d -> %d over %d map rows: the ordered-reduction workspace (%d MiB) exceeds PP_WGRAD_DET_MAX_MB "
+                   "(%d): float-atomic kernel, not bit-reproducible run to run" % (cin, cout, wp.rows, nbytes >> 20, WGRAD_DET_MAX_BYTES >> 20))
+            if WGRAD_STRICT:
+                raise _lib.PanopticHipError(msg)
+            if not _WGRAD_WARNED[0]:
+                _WGRAD_WARNED[0] = True
+                import warnings
+                warnings.warn(msg)
         _lib.check(lib.pp_spconv_bwd_weight_pairs(_ptr(inp), cin, inp.shape[0], _ptr(dout), cout, dout.shape[0], _ptr(wp.pairs),
                                                   _ptr(wp.tile_start), wp.K, wp.rows, _ptr(dw), 1 if bf16 else 0, _stream()),
                    "pp_spconv_bwd_weight_pairs")
