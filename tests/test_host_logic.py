@@ -458,3 +458,47 @@ def test_pointgroupembed_recipes_match_the_trace_of_the_reference_functions():
         got_order = [rec["calls"].index(p.tag[0]) + 1 for p in proposals for _ in range(p.n)]
         assert got_order == [t // 1000 for t in rec["proposal_tags"]], ct
         assert [t for c, t in typed for _ in range(c.n)] == rec["types"], ct
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs itself as N ranks under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1, a free port) and passes the command line through"""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(4)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_conv_kernel_family_rule(monkeypatch):
+    """which kernel a convolution shape runs on, as bench.py's per-family traffic figures assume it (mirrors spconv_fwd_impl):
+    >= 3 sixteen-column tiles per wave, or two with >= 96 input channels -> the split-operand kernel; 1x1 and thin layers,
+    the 4-channel input layer and everything under PP_CONV_X3=0 -> the fp32-MFMA kernel"""
+    from panopticsegforlargescalepointcloud_amd import ops
+    fam = ops.LaunchProfiler.kernel_family
+    monkeypatch.delenv("PP_CONV_X3", raising=False)
+    monkeypatch.delenv("PP_CONV_X3_MIN_NTW", raising=False)
+    want = {(64, 64, 27): "x3", (48, 48, 27): "x3", (128, 48, 27): "x3", (160, 64, 27): "x3", (96, 96, 27): "x3", (192, 80, 27): "x3",
+            (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "fwd3", (32, 32, 27): "fwd3", (16, 16, 27): "fwd3",
+            (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3"}
+    for (cin, cout, K), f in want.items():
+        assert fam(cin, cout, K) == f, (cin, cout, K)
+    monkeypatch.setenv("PP_CONV_X3", "0")
+    assert fam(64, 64, 27) == "fwd3"
