@@ -43,6 +43,12 @@ wrap(scene_mod, "instance_labels_per_tile", "labels_per_tile")
 wrap(ops, "spconv_fwd", "conv")
 wrap(ops, "region_grow_csr", "region_grow")
 wrap(ops, "proposals_unique", "proposals_unique")
+if os.environ.get("PP_TRACE_FRONT", "0") == "1":  # round 5: the scorer's front end, call by call (main thread AND builder threads)
+    from panopticsegforlargescalepointcloud_amd import MinkowskiEngine as ME_
+    for nm in ("morton_order", "block_index_build", "block_index_coarsen", "kernel_map_bi", "map_order", "map_permute", "level_permute",
+               "gather_rows", "kernel_map_transpose8", "proposal_pairs", "meanshift", "compose_perm"):
+        wrap(ops, nm, nm)
+    wrap(ME_, "_order_level", "_order_level")
 for _ in range(3):
     runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
 torch.cuda.synchronize()
@@ -61,6 +67,8 @@ prev = None
 n_conv = 0
 for n, t in ev:
     if t < t_start or t > t_next + 0.02:
+        continue
+    if os.environ.get("PP_TRACE_FRONT", "0") == "1" and not (float(os.environ.get("PP_TRACE_LO", "70")) <= 1e3 * (t - t_start) <= float(os.environ.get("PP_TRACE_HI", "95"))):
         continue
     if n.startswith("conv"):
         n_conv += 1
