@@ -352,8 +352,41 @@ def self_check(runner, batches, device, oracle_case):
                                  "score_spread": "ScorerHead logits rescaled to mean 2.1 / unit variance for the label check"}
         checks["max_err"].update({"oracle_scores": e_score, "oracle_scores_spread_head": e_spread, "oracle_embeddings": e_feat,
                                   "oracle_semantic": e_seml})
+    checks["split_operand_accuracy"] = split_operand_accuracy(device, checks["max_err"])
     checks["all"] = "pass" if all(not str(v).startswith("FAIL") for v in checks.values()) else "FAIL"
     return checks
+
+
+def split_operand_accuracy(device, max_err):
+    """The wide layers multiply fp32 operands on the bf16 matrix pipe from exactly split operands (k_spconv_x3).
+    Measured here on a 64 -> 64 layer over a 60 k-row surface map: the default path and the fp32-MFMA kernel (forced through
+    pp_spconv_fwd_ex) against a float64 evaluation of the same sums on the device; rows of very different magnitude.  Passes
+    when the default path's error does not exceed twice the fp32-MFMA kernel's (or 5e-7 of the output's magnitude)."""
+    from panopticsegforlargescalepointcloud_amd import ops
+    g = torch.Generator().manual_seed(11)
+    xy = torch.randint(-200, 200, (90000, 2), generator=g)
+    z = ((xy[:, 0].float() * 0.05).sin() * 6 + (xy[:, 1].float() * 0.07).cos() * 5).round().int()
+    c = torch.unique(torch.cat([torch.zeros(len(xy), 1, dtype=torch.int32), xy.int(), z[:, None]], 1), dim=0).to(device)
+    n = c.shape[0]
+    table, _ = ops.hash_build(c)
+    nbr = ops.kernel_map(c, table, 3, 1, 1)
+    x = (torch.randn(n, 64, generator=g) * torch.exp(torch.randn(n, 1, generator=g))).to(device)
+    W = (torch.randn(27, 64, 64, generator=g) * 0.1).to(device)
+    pk = ops.pack_weight(W)
+    got = ops.spconv_fwd(x, pk, nbr, n, 64, 27)
+    f32 = ops.spconv_fwd(x, pk, nbr, n, 64, 27, variant=(32, 1, 1))
+    ref = torch.zeros(n, 64, dtype=torch.float64, device=device)
+    xd, Wd = x.double(), W.double()
+    for k in range(27):
+        ok = nbr[k] >= 0
+        ref[ok] += xd[nbr[k][ok].long()] @ Wd[k]
+    mag = float(ref.abs().max())
+    e_def, e_f32 = float((got.double() - ref).abs().max()) / mag, float((f32.double() - ref).abs().max()) / mag
+    max_err["conv64_default_path_vs_float64"] = e_def
+    max_err["conv64_fp32_mfma_vs_float64"] = e_f32
+    split_on = not torch.equal(got, f32)
+    max_err["conv64_default_path_is_split_operand_kernel"] = split_on
+    return "pass" if e_def <= max(2.0 * e_f32, 5e-7) else "FAIL(default path %.2e vs fp32 MFMA %.2e of the magnitude)" % (e_def, e_f32)
 
 
 def self_launch(n):

@@ -7,8 +7,8 @@
 // of x - hi, lo = the rest; all three subtractions are exact), so
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b|: dropped]
 // six bf16 products (each exact in fp32), accumulated in fp32 by the MFMA: the error per product is below one fp32
-// rounding, the sum over a K = 32 chunk is rounded once instead of 32 times.  Measured on random data the result is CLOSER
-// to the float64 value than the fp32 fmaf chain (oracle/test: tests/test_hip_ops.py::test_spconv_x3_*).  Six bf16 MFMAs
+// rounding, the sum over a K = 32 chunk is rounded once instead of 32 times.  Measured against float64 the error is of the
+// size of the fp32-MFMA kernel's (0.6 - 1.4 x; tests/test_hip_ops.py::test_spconv_x3_*, bench.py's self-check).  Six bf16 MFMAs
 // cost 6 x 17 = 102 cycles per (16 rows x 16 columns x 32 channels) against 8 x 32 = 256 cycles of fp32 MFMAs.
 //
 // What that needs.  At that rate the operand traffic of a 32 x 64 register tile no longer fits the CU's texture path
