@@ -91,6 +91,17 @@ int pp_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* keys
 size_t pp_exclusive_scan_workspace(int64_t n);
 int pp_exclusive_scan(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* workspace, size_t workspace_bytes,
                       pp_stream_t stream);
+/* Stream compaction and run lengths on that scan.  replaces: the torch.nonzero / unique_consecutive / cumsum / repeat_interleave
+ * calls around the embedding clustering (torch_points3d/utils/meanshift_cluster.py:72-123 builds its per-sample lists with the
+ * NumPy equivalents; torch_points3d/models/panoptic/PointGroup3heads.py:291-391 selects the "thing" points with a boolean mask).
+ * pp_select_indices: idx[0 .. count) = the positions of the non-zero flags in ascending order (idx holds n entries).
+ * pp_run_lengths: runs of equal consecutive values: run_id[i] (int32 [n], nullable) = 0-based run of element i, heads[r] = the
+ * run's value, starts[r] = its first position, starts[n_runs] = n (heads n, starts n + 1 entries); n_runs int32 [1]. */
+size_t pp_select_workspace(int64_t n);
+int pp_select_indices(const uint8_t* flags, int64_t n, int64_t* idx, int32_t* count, void* workspace, size_t workspace_bytes,
+                      pp_stream_t stream);
+int pp_run_lengths(const int64_t* values, int64_t n, int32_t* run_id, int64_t* heads, int32_t* starts, int32_t* n_runs,
+                   void* workspace, size_t workspace_bytes, pp_stream_t stream);
 size_t pp_sort_pairs_workspace_bytes(int64_t n);
 int pp_sort_pairs(const void* keys_in, void* keys_out, int32_t key_bytes, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                   int32_t end_bit, void* workspace, size_t workspace_bytes, pp_stream_t stream);

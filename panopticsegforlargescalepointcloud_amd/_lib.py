@@ -33,6 +33,9 @@ SIGNATURES = {
     "pp_kernel_map": (C.c_int, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
     "pp_exclusive_scan_workspace": (sz, [i64]),
     "pp_exclusive_scan": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
+    "pp_select_workspace": (sz, [i64]),
+    "pp_select_indices": (C.c_int, [vp, i64, vp, vp, vp, sz, vp]),
+    "pp_run_lengths": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     "pp_sort_pairs_workspace_bytes": (sz, [i64]),
     "pp_sort_pairs": (C.c_int, [vp, vp, i32, vp, vp, i64, i32, vp, sz, vp]),
     "pp_kernel_map_transpose": (C.c_int, [vp, i64, i32, i64, vp, vp, vp]),

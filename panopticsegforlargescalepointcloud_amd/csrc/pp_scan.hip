@@ -324,3 +324,81 @@ extern "C" int pp_sort_pairs(const void* keys_in, void* keys_out, int32_t key_by
   return pp_sort_pairs_u64((const uint64_t*)keys_in, (uint64_t*)keys_out, vals_in, vals_out, n, end_bit, workspace,
                            workspace_bytes, pp_s(stream));
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream compaction and run lengths on the scan above (round 5): what the host layer took from torch.nonzero /
+// unique_consecutive / cumsum / repeat_interleave around the mean shift (rocPRIM-backed kernels of the tensor library).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sel_mark(const uint8_t* __restrict__ flags, int64_t n, int32_t* __restrict__ mark) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mark[i] = flags[i] ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_sel_scatter(const uint8_t* __restrict__ flags, const int32_t* __restrict__ pos, int64_t n,
+                                                     int64_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) idx[pos[i]] = i;
+}
+__global__ __launch_bounds__(256) void k_run_mark(const int64_t* __restrict__ v, int64_t n, int32_t* __restrict__ mark) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mark[i] = (i == 0 || v[i] != v[i - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_run_scatter(const int64_t* __restrict__ v, const int32_t* __restrict__ mark,
+                                                     const int32_t* __restrict__ pos, int64_t n, int32_t* __restrict__ run_id,
+                                                     int64_t* __restrict__ heads, int32_t* __restrict__ starts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = pos[i] + mark[i] - 1;  // 0-based run of element i
+  if (run_id) run_id[i] = r;
+  if (mark[i]) {
+    heads[r] = v[i];
+    starts[r] = (int32_t)i;
+  }
+  if (i == n - 1) starts[r + 1] = (int32_t)n;
+}
+
+extern "C" size_t pp_select_workspace(int64_t n) { return pp_align((size_t)(n > 0 ? n : 1) * 8) + pp_scan_workspace(n) + 256; }
+
+extern "C" int pp_select_indices(const uint8_t* flags, int64_t n, int64_t* idx, int32_t* count, void* workspace, size_t workspace_bytes,
+                                 pp_stream_t stream) {
+  PP_REQUIRE(count && workspace, "pp_select_indices: null pointer");
+  PP_REQUIRE(n < (int64_t(1) << 31), "pp_select_indices: n must be below 2^31");
+  PP_REQUIRE(workspace_bytes >= pp_select_workspace(n), "pp_select_indices: workspace too small");
+  hipStream_t s = pp_s(stream);
+  if (n <= 0) {
+    PP_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    return PP_OK;
+  }
+  PP_REQUIRE(flags && idx, "pp_select_indices: null pointer");
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* mark = ar.take<int32_t>((size_t)n);
+  int32_t* pos = ar.take<int32_t>((size_t)n);
+  hipLaunchKernelGGL(k_sel_mark, dim3(pp_blocks(n, 256)), dim3(256), 0, s, flags, n, mark);
+  int rc = pp_exclusive_scan_i32(mark, pos, n, count, ar.cur(), ar.left(), s);
+  if (rc != PP_OK) return rc;
+  hipLaunchKernelGGL(k_sel_scatter, dim3(pp_blocks(n, 256)), dim3(256), 0, s, flags, pos, n, idx);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_run_lengths(const int64_t* values, int64_t n, int32_t* run_id, int64_t* heads, int32_t* starts, int32_t* n_runs,
+                              void* workspace, size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(n_runs && workspace, "pp_run_lengths: null pointer");
+  PP_REQUIRE(n < (int64_t(1) << 31), "pp_run_lengths: n must be below 2^31");
+  PP_REQUIRE(workspace_bytes >= pp_select_workspace(n), "pp_run_lengths: workspace too small");
+  hipStream_t s = pp_s(stream);
+  if (n <= 0) {
+    PP_HIP(hipMemsetAsync(n_runs, 0, sizeof(int32_t), s));
+    if (starts) PP_HIP(hipMemsetAsync(starts, 0, sizeof(int32_t), s));
+    return PP_OK;
+  }
+  PP_REQUIRE(values && heads && starts, "pp_run_lengths: null pointer");
+  PPArena ar(workspace, workspace_bytes);
+  int32_t* mark = ar.take<int32_t>((size_t)n);
+  int32_t* pos = ar.take<int32_t>((size_t)n);
+  hipLaunchKernelGGL(k_run_mark, dim3(pp_blocks(n, 256)), dim3(256), 0, s, values, n, mark);
+  int rc = pp_exclusive_scan_i32(mark, pos, n, n_runs, ar.cur(), ar.left(), s);
+  if (rc != PP_OK) return rc;
+  hipLaunchKernelGGL(k_run_scatter, dim3(pp_blocks(n, 256)), dim3(256), 0, s, values, mark, pos, n, run_id, heads, starts);
+  PP_LAUNCH_CHECK();
+  return PP_OK;
+}

@@ -447,6 +447,40 @@ def exclusive_scan(x, want_total=False):
     return (out, total) if want_total else out
 
 
+def select_indices(flags):
+    """positions of the non-zero entries of a bool / uint8 vector, ascending (int64) -- torch.nonzero(flags).view(-1) on the
+    library's own scan (one host read: the count)"""
+    lib = _lib.load()
+    if flags.dtype == torch.bool:
+        flags = flags.view(torch.uint8)
+    flags = _need(flags, torch.uint8, "flags")
+    n = flags.shape[0]
+    idx = torch.empty(max(n, 1), dtype=torch.int64, device=flags.device)
+    count = _zeros(1, torch.int32, flags.device)
+    wsb = lib.pp_select_workspace(n)
+    ws = _ws(wsb, flags.device, tag="select")
+    _lib.check(lib.pp_select_indices(_ptr(flags), n, _ptr(idx), _ptr(count), _ptr(ws), wsb, _stream()), "pp_select_indices")
+    return idx[: int(count.item())]
+
+
+def run_lengths(values, want_run_id=True):
+    """runs of equal consecutive values of an int64 vector: (heads int64 [n] , starts int32 [n + 1], run_id int32 [n] or None,
+    n_runs int32 [1] on the device) -- only the first n_runs (+ 1) entries of heads / starts are meaningful; no host read"""
+    lib = _lib.load()
+    values = _need(values, torch.int64, "values")
+    n = values.shape[0]
+    dev = values.device
+    heads = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    starts = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    run_id = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if want_run_id else None
+    n_runs = _zeros(1, torch.int32, dev)
+    wsb = lib.pp_select_workspace(n)
+    ws = _ws(wsb, dev, tag="select")
+    _lib.check(lib.pp_run_lengths(_ptr(values), n, _ptr(run_id), _ptr(heads), _ptr(starts), _ptr(n_runs), _ptr(ws), wsb, _stream()),
+               "pp_run_lengths")
+    return heads, starts, (run_id[:n] if run_id is not None else None), n_runs
+
+
 def sort_pairs(keys, vals, end_bit=None):
     """stable sort of (key, value) pairs by the low end_bit bits of the keys (int32 / int64 tensors read as unsigned; values
     int32): (sorted keys, sorted values)"""

@@ -248,7 +248,7 @@ class PointGroup3heads(nn.Module):
 
     def _embed_clusters(self, pred, emb):
         label_mask = ops.not_ignored(pred, self._stuff_classes, self.num_classes)
-        local_ind = torch.nonzero(label_mask).view(-1)
+        local_ind = ops.select_indices(label_mask)  # (torch.nonzero on the library's own scan: no rocPRIM launch in the step)
         # (rows by index: a boolean mask costs another compaction pass and host synchronisation per use)
         return meanshift_cluster.cluster_single_csr(emb[local_ind], self.input.batch[local_ind], local_ind,
                                                     self.opt.bandwidth)

@@ -34,24 +34,24 @@ def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_po
     if m == 0:
         return ops.ClusterCSR(torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), 0)
     # samples must be contiguous; PyG batches are sorted, but do not rely on it: the run heads of a sorted batch vector
-    # are strictly increasing (checked on the host from the one read that also brings the run lengths)
-    uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
-    heads, runs = torch.stack([uniq, counts]).tolist()
+    # are strictly increasing (checked on the host from the read that also brings the run boundaries).  Runs, run boundaries
+    # and the run of every point come from the library's own scan (ops.run_lengths; round 5: torch.unique_consecutive / cumsum /
+    # repeat_interleave dispatched rocPRIM kernels here)
+    def runs_of(lb):
+        heads_d, starts_d, run_id, n_runs = ops.run_lengths(lb.contiguous())
+        nr = int(n_runs.item())
+        vals = torch.cat([heads_d[:nr], starts_d[: nr + 1].long()]).tolist()
+        return vals[:nr], vals[nr:], run_id
+    heads, offs, sample_of_point = runs_of(label_batch)
     if any(b <= a for a, b in zip(heads, heads[1:])):
         order = torch.sort(label_batch, stable=True)[1]
         embed_logits_u, label_batch, local_ind = embed_logits_u[order], label_batch[order], local_ind[order]
-        uniq, counts = torch.unique_consecutive(label_batch, return_counts=True)
-        runs = counts.tolist()
-    offs = [0]
-    for r in runs:
-        offs.append(offs[-1] + r)
+        heads, offs, sample_of_point = runs_of(label_batch)
     labels, ncl, _ = ops.meanshift(embed_logits_u.detach().float().contiguous(), offs, bandwidth,
                                    min_points_exclusive=min_points_exclusive)
     # global cluster id = (clusters of earlier samples) + label ; samples ascending, labels ascending
-    csum = torch.cumsum(ncl, 0)
-    base = csum - ncl
-    sample_of_point = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), counts, output_size=m)
-    key = torch.where(labels >= 0, labels + base[sample_of_point].to(torch.int32), labels)
+    base, n_total = ops.exclusive_scan(ncl.to(torch.int32).contiguous(), want_total=True)
+    key = torch.where(labels >= 0, labels + base[sample_of_point.long()], labels)
     # The number of clusters is on the device.  Group with an upper bound instead of reading it first (a sample of p points has
     # at most p clusters), and read it together with the counts the grouping returns: one host read where there were two
     bound = m
@@ -59,7 +59,7 @@ def cluster_single_csr(embed_logits_u, label_batch, local_ind, bandwidth, min_po
     # sklearn can leave a centre without points; torch.unique in the reference wrapper skips such labels
     sizes = goffs[1:] - goffs[:-1]
     keep = sizes > 0
-    n_groups, n_keep, kept, bad = torch.cat([csum[-1:].to(torch.int32), keep.sum().view(1).to(torch.int32), total]).tolist()
+    n_groups, n_keep, kept, bad = torch.cat([n_total.view(1), keep.sum().view(1).to(torch.int32), total]).tolist()
     if bad:
         raise ops._lib.PanopticHipError("group_by_key: %d keys outside [0, n_groups)" % bad)
     if n_keep == n_groups:

@@ -1338,3 +1338,24 @@ def test_transposed_map_8_wide_equals_dense(ops, oracle):
     # the oracle's transposed map (fine rows probing the coarse level with mirrored offsets) names the same pairs
     want = oracle.kernel_map(cs.cpu().numpy(), cc.cpu().numpy(), 3, 1, -1)
     assert np.array_equal(ops.map8_to_dense(m8).cpu().numpy(), want)
+
+
+def test_select_indices_and_run_lengths(ops):
+    """pp_select_indices == torch.nonzero, pp_run_lengths == torch.unique_consecutive (+ run boundaries and the run of every
+    element), incl. empty input, one run, a run boundary at a scan-tile edge (4096) and no flag set"""
+    g = torch.Generator().manual_seed(3)
+    for n in (0, 1, 5, 4096, 4097, 300001):
+        flags = (torch.rand(n, generator=g) < 0.37).cuda()
+        got = ops.select_indices(flags)
+        assert torch.equal(got, torch.nonzero(flags).view(-1))
+        assert ops.select_indices(torch.zeros(n, dtype=torch.bool).cuda()).numel() == 0
+        runs = torch.randint(1, 9000 if n > 10000 else 3, (max(n, 1),), generator=g)
+        vals = torch.repeat_interleave(torch.randint(0, 50, (len(runs),), generator=g) * 2 + torch.arange(len(runs)) % 2, runs)[:n].cuda()
+        heads, starts, run_id, n_runs = ops.run_lengths(vals)
+        uniq, counts = torch.unique_consecutive(vals, return_counts=True)
+        nr = int(n_runs.item())
+        assert nr == uniq.numel()
+        assert torch.equal(heads[:nr], uniq)
+        assert torch.equal(starts[: nr + 1].long(), torch.cat([torch.zeros(1, dtype=torch.int64).cuda(), torch.cumsum(counts, 0)]))
+        if n:
+            assert torch.equal(run_id.long(), torch.repeat_interleave(torch.arange(nr).cuda(), counts))
