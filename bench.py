@@ -578,6 +578,7 @@ def main():
     # costs (reported beside the pipelined figure, never as `value`)
     single_scene_ms = None
     if input_prefetch:
+        gc.disable()  # (as in the timed region: a generation-2 pass is a 20 - 40 ms stall in one of the three steps)
         step(input_prefetch=False)
         sync()
         t1 = time.perf_counter()
@@ -585,6 +586,7 @@ def main():
             step(input_prefetch=False)
         sync()
         single_scene_ms = round(1e3 * (time.perf_counter() - t1) / 3, 2)
+        gc.enable()
 
     stage_ms = None
     if args.stage_timing:

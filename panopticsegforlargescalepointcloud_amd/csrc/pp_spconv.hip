@@ -412,7 +412,7 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
     // wide layers: the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip) unless a variant was asked for.
     // PP_CONV_X3=0: never; PP_CONV_X3_MIN_NTW: fewest column tiles per wave that take it (default 3)
     static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
-    static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 3;
+    static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 2;
     int rc = PP_UNSUPPORTED;
     if (env_x3 && !pipeline && !rows_per_wave && mode16) {
       // column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
@@ -426,10 +426,10 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
       int g4 = (a.NT + 3) / 4;
       if ((a.NT + mx - 1) / mx < g4) g4 = (a.NT + mx - 1) / mx;
       const int n4 = (a.NT + g4 - 1) / g4;
-      // two column tiles per wave pay only where a row brings >= 96 input channels (96->32 at 5.4 M rows 4309 -> 3849 us; 64->32
-      // loses 12 %, 32->32 is even: the operand split and the staging are per step, whatever the number of column tiles)
-      const bool wide_in = n4 == 2 && env_x3_ntw == 3 && (c0 + c1) >= 96;
-      if ((n4 >= env_x3_ntw || wide_in) && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
+      // two column tiles per wave (the 32-channel layers): 10 - 12 % faster than the fp32-MFMA kernel layer by layer (32->32 at 5.4 M
+      // rows 1793 -> 1630 us, 64->32 2991 -> 2686, 96->32 4254 -> 3798) and 1.1 ms per step (118.8 -> 117.7, three alternating pairs,
+      // profiles/r05_ab_x3_two_tiles.txt); one column tile (the 16-channel layers) stays on the fp32 MFMAs: texture-path bound
+      if (n4 >= env_x3_ntw && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
     }
     if (rc == PP_UNSUPPORTED) rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;

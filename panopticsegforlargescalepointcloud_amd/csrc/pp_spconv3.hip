@@ -24,6 +24,8 @@
 // Same contract, prologue and epilogue as k_spconv_fwd3: per output row the sum runs over the occupied offsets in
 // ascending order, inside an offset over the 32-channel groups, inside a group over the six products in a fixed order --
 // independent of the map form, the row order and the batch, so results are bit-identical across those.
+#include <stdlib.h>
+
 #include "pp_spconv.h"
 
 #define X3_MAXK 28
@@ -31,10 +33,14 @@
 #define X3_WPB 4  // waves per workgroup (A/B builds: 8 = 256 rows share a staged weight slice)
 #endif
 #define X3_MISSING 0xFFFFFFFFu
-#define X3_T 2
-#define X3_R 32
 #ifndef X3_WAVES
 #define X3_WAVES 4  // waves per SIMD the register budget is set for (A/B builds: 3)
+#endif
+
+// X3_ABLATE (profiling builds only, profiles/build_x3_variants.sh; results are wrong by construction): 1 = no row gathers,
+// 2 = no operand split, 3 = no MFMAs, 4 = no weight staging, 5 = no per-step barrier
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
 #endif
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -109,9 +115,13 @@ __device__ __forceinline__ f32x4 x3_mfma(bf16x8_t b, bf16x8_t a, f32x4 c) {
 // pp_spconv_fwd_bf16): both operands rounded to nearest-even bfloat16 -- the weights at packing time (third section of the
 // packed buffer), the gathered rows in registers (v_cvt_pk_bf16_f32) -- ONE v_mfma_f32_16x16x32_bf16 per tile, column tile
 // and 32 channels, fp32 accumulation; same workgroup-synchronous walk, one 1 KiB weight plane per column tile staged.
-template <int NTW, bool DS, int MODE>
+// T = 16-row tiles per wave: 2, or 4 on the two-column-tile layers (64 rows per wave: the staging, the barrier and the step
+// bookkeeping are paid per 256 instead of per 128 rows; the tiles are split and multiplied two at a time, so the register budget
+// is that of T = 2 plus the second pair's gathered rows and accumulators).
+template <int NTW, bool DS, int MODE, int T>
 __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
-  constexpr int T = X3_T, R = X3_R;
+  constexpr int R = 16 * T;
+  static_assert(T == 2 || T == 4, "32 or 64 rows per wave");
   __shared__ unsigned s_off[X3_WPB][X3_MAXK][R];
   constexpr int PL = MODE == 1 ? 1 : 3;      // weight planes per column tile
   __shared__ f32x4 s_wb[2][NTW * PL * 64];  // weight stage: per column tile PL planes x 64 lanes x 16 bytes
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   // ---- prologue (as k_spconv_fwd3): neighbour rows -> byte offsets in LDS, per-tile occupancy masks -> SGPRs
   unsigned m[T];
   {
-    constexpr int KPL = 2, NL = X3_MAXK / KPL;
+    constexpr int KPL = 64 / R, NL = X3_MAXK / KPL;
     const int rr = lane % R, kh = lane / R;
     const bool rv = row_base + rr < a.n_out;
     const int64_t slot = rv ? row_base + rr : a.n_out - 1;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
       const unsigned mrow = (rv && kh == 0) ? a.cm_mask[slot] : 0u;
       if (row_base < a.n_out) {
         const int64_t chunks = (a.n_out + 31) >> 5;
-        const int64_t c0 = row_base >> 5, c1 = c0 + 1 < chunks ? c0 + 1 : chunks;
+        const int64_t c0 = row_base >> 5, c1 = c0 + R / 32 < chunks ? c0 + R / 32 : chunks;
         const int e0 = a.cm_start[c0], e1 = a.cm_start[c1];
         for (int eb = e0; eb < e1; eb += 256) {
           int v4[4];
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
           for (int u = 0; u < 4; ++u) {
             const int e = eb + u * 64 + lane;
             const unsigned prod = m24 ? __umul24((unsigned)v4[u], row_bytes) : (unsigned)v4[u] * row_bytes;
-            if (e < e1) off[t4[u] >> 6][t4[u] & 31u] = prod;  // (tag = offset << 6 | output row & 63; a wave owns 32 rows)
+            if (e < e1) off[t4[u] >> 6][(t4[u] & 63u) - ((unsigned)row_base & 63u)] = prod;  // (tag = offset << 6 | output row & 63)
           }
         }
       }
@@ -287,33 +297,28 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj)                                                       \
         if (jj * X3_WPB + wave < PL * NTW) s_wb[BUF][(jj * X3_WPB + wave) * 64 + lane] = wreg[jj];            \
   }
-    // gather the two 16-channel halves of group g of offset k for both tiles (missing half / neighbour: hardware zeros)
-#define X3_GATHER(KK, GG, AX)                                                                                  \
+    // gather the two 16-channel halves of group g of offset k for the tile pair PR (tiles 2 PR, 2 PR + 1; missing half /
+    // neighbour: hardware zeros)
+#define X3_GATHER2(KK, GG, AX, PR)                                                                             \
   {                                                                                                            \
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                            \
       const int sl_ = 2 * (GG) + h;                                                                            \
       const int sc_ = sl_ < S ? sl_ : S - 1;                                                                   \
       const float* src_ = sc_ < S0 ? a.in0 + sc_ * 16 : a.in1 + (sc_ - S0) * 16;                               \
       const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)src_, 0, (int)(sl_ < S ? a_bytes : 0u), 0x00020000); \
-      _Pragma("unroll") for (int tt = 0; tt < T; ++tt)                                                         \
+      _Pragma("unroll") for (int tt = 2 * (PR); tt < 2 * (PR) + 2; ++tt)                                       \
           AX[tt][h] = X3_ABLATE == 1 ? (f32x4){1.f, 2.f, 3.f, (float)off[KK][tt * 16 + i]}                      \
                                      : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_, (int)(off[KK][tt * 16 + i] | q16), 0, 0)); \
     }                                                                                                          \
   }
-    // ---- the workgroup's step sequence: (offset k of U ascending) x (group g); three positions are live: the step being
-    // computed (k0, g0), the next one (weights being staged, rows in flight since the previous step) and the one after
-    // (rows gathered now).  X3_AHEAD = 1 (A/B builds): rows only one step ahead.
-#ifndef X3_AHEAD
-#define X3_AHEAD 1
-#endif
-// X3_ABLATE (profiling builds only, profiles/build_x3_variants.sh; results are wrong by construction): 1 = no row gathers,
-// 2 = no operand split, 3 = no MFMAs, 4 = no weight staging, 5 = no per-step barrier
-#ifndef X3_ABLATE
-#define X3_ABLATE 0
-#endif
+    // ---- the workgroup's step sequence: (offset k of U ascending) x (group g); two positions are live: the step being
+    // computed (k0, g0) and the next one (weights being staged, rows in flight).  (Rows two steps ahead were tried: they fit 128
+    // VGPRs only with spills, and at three waves per SIMD the kernel lost 5 %, profiles/r05_x3_ab_variants.txt.)
 #ifndef X3_BDEPTH
 #define X3_BDEPTH 2  // weight fragments of one column tile (1) or two (2: the next tile's LDS reads run beside the MFMAs) in registers
 #endif
+    // X3_ABLATE (profiling builds only, profiles/build_x3_variants.sh; results are wrong by construction): 1 = no row gathers,
+    // 2 = no operand split, 3 = no MFMAs, 4 = no weight staging, 5 = no per-step barrier
 #define X3_ADV(KI, GI, UR, OK)            \
   {                                       \
     if (GI + 1 < G) {                     \
@@ -330,89 +335,13 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     unsigned Ur = U & (U - 1u);
     int k1 = k0, g1 = g0, ok1 = 1;
     X3_ADV(k1, g1, Ur, ok1);
-    int k2 = k1, g2 = g1, ok2 = ok1;
-    if (ok2) X3_ADV(k2, g2, Ur, ok2);
-    f32x4 AA[T][2], AB[T][2];
+    f32x4 AA[T][2];
     X3_STAGE_W(k0, g0, 0);
     X3_STAGE_FLUSH(0);
-    X3_GATHER(k0, g0, AA);
-    if (X3_AHEAD == 2 && ok1) {
-      X3_GATHER(k1, g1, AB);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (the weights and the first step's rows; the second step's rows stay in flight)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+#pragma unroll
+    for (int pr = 0; pr < T / 2; ++pr) X3_GATHER2(k0, g0, AA, pr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // one step: split the rows of (k0, g0) out of ACUR, refill ACUR with the rows of the step after next, stage the next
-    // step's weights, multiply; then advance.  ACUR alternates between AA and AB (loop unrolled by two: no register copies)
-#define X3_STEP(ACUR)                                                                                             \
-  {                                                                                                               \
-    const unsigned act0 = (m[0] >> k0) & 1u, act1 = (m[1] >> k0) & 1u;                                            \
-    X3Planes P0, P1;                                                                                              \
-    if (act0) P0 = MODE == 1 ? x3_round(ACUR[0][0], ACUR[0][1]) : x3_split(ACUR[0][0], ACUR[0][1]);               \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (act1) P1 = MODE == 1 ? x3_round(ACUR[1][0], ACUR[1][1]) : x3_split(ACUR[1][0], ACUR[1][1]);               \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (ok1 && X3_ABLATE != 4) X3_STAGE_W(k1, g1, buf ^ 1);                                                       \
-    if (X3_AHEAD == 2 ? ok2 : ok1) {                                                                              \
-      if (X3_AHEAD == 2) { X3_GATHER(k2, g2, ACUR); } else { X3_GATHER(k1, g1, ACUR); }                           \
-    }                                                                                                             \
-    if (act0 | act1) {                                                                                            \
-      const f32x4* wb = &s_wb[buf][0];                                                                            \
-      bf16x8_t Bf[2][PL];                                                                                         \
-      if (X3_BDEPTH == 2) {                                                                                       \
-        _Pragma("unroll") for (int p = 0; p < PL; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]); \
-      }                                                                                                           \
-      _Pragma("unroll") for (int jt = 0; jt < NTW; ++jt) {                                                        \
-        if (X3_BDEPTH == 2) {                                                                                     \
-          if (jt + 1 < NTW) {                                                                                     \
-            _Pragma("unroll") for (int p = 0; p < PL; ++p)                                                        \
-                Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * (PL * 64) + p * 64 + lane]);     \
-          }                                                                                                       \
-        } else {                                                                                                  \
-          _Pragma("unroll") for (int p = 0; p < PL; ++p)                                                          \
-              Bf[jt & 1][p] = __builtin_bit_cast(bf16x8_t, wb[jt * (PL * 64) + p * 64 + lane]);                   \
-        }                                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if constexpr (MODE == 1) {                                                                                \
-          const bf16x8_t B0 = Bf[jt & 1][0];                                                                      \
-          if (act0) acc[0][jt] = x3_mfma(B0, P0.p0, acc[0][jt]);                                                  \
-          if (act1) acc[1][jt] = x3_mfma(B0, P1.p0, acc[1][jt]);                                                  \
-        } else {                                                                                                  \
-        const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][PL > 1 ? 1 : 0], B2 = Bf[jt & 1][PL > 2 ? 2 : 0];      \
-        if (act0 & act1) {                                                                                        \
-          acc[0][jt] = x3_mfma(B2, P0.p0, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B2, P1.p0, acc[1][jt]);                   \
-          acc[0][jt] = x3_mfma(B0, P0.p2, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B0, P1.p2, acc[1][jt]);                   \
-          acc[0][jt] = x3_mfma(B1, P0.p1, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B1, P1.p1, acc[1][jt]);                   \
-          acc[0][jt] = x3_mfma(B1, P0.p0, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B1, P1.p0, acc[1][jt]);                   \
-          acc[0][jt] = x3_mfma(B0, P0.p1, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B0, P1.p1, acc[1][jt]);                   \
-          acc[0][jt] = x3_mfma(B0, P0.p0, acc[0][jt]);                   \
-          acc[1][jt] = x3_mfma(B0, P1.p0, acc[1][jt]);                   \
-        } else if (act0) {                                                                                        \
-          X3_SIX(acc[0][jt], P0, B0, B1, B2)                                                                      \
-        } else {                                                                                                  \
-          X3_SIX(acc[1][jt], P1, B0, B1, B2)                                                                      \
-        }                                                                                                         \
-        }                                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                        \
-      }                                                                                                           \
-    }                                                                                                             \
-    if (!ok1) break;                                                                                              \
-    /* before the barrier: this wave's share of the next step's weights has landed (and, in issue order before it, the rows of */ \
-    /* the next step); only the rows gathered in THIS step may still be in flight */                              \
-    X3_STAGE_FLUSH(buf ^ 1);                                                                                      \
-    if (X3_AHEAD == 2 && ok2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-    if (X3_ABLATE != 5) __syncthreads();                                                                          \
-    k0 = k1; g0 = g1; k1 = k2; g1 = g2; ok1 = ok2;                                                                \
-    if (ok2) X3_ADV(k2, g2, Ur, ok2);                                                                             \
-    buf ^= 1;                                                                                                     \
-  }
 #define X3_SIX(ACC, PL, B0, B1, B2)                                                       \
   ACC = x3_mfma(B2, PL.p0, ACC);                 \
   ACC = x3_mfma(B0, PL.p2, ACC);                 \
@@ -421,17 +350,84 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   ACC = x3_mfma(B0, PL.p1, ACC);                 \
   ACC = x3_mfma(B0, PL.p0, ACC);
     for (;;) {
-      X3_STEP(AA);
-#if X3_AHEAD == 2
-      X3_STEP(AB);
-#endif
+      // one step: per tile pair -- split its rows of (k0, g0), refill them with the rows of the next step, multiply; the next
+      // step's weights are staged beside the first pair's MFMAs
+#pragma unroll
+      for (int pr = 0; pr < T / 2; ++pr) {
+        const int ta = 2 * pr, tb = 2 * pr + 1;
+        const unsigned act0 = (m[ta] >> k0) & 1u, act1 = (m[tb] >> k0) & 1u;
+        X3Planes P0, P1;
+        if (act0) P0 = MODE == 1 ? x3_round(AA[ta][0], AA[ta][1]) : x3_split(AA[ta][0], AA[ta][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (act1) P1 = MODE == 1 ? x3_round(AA[tb][0], AA[tb][1]) : x3_split(AA[tb][0], AA[tb][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pr == 0 && ok1 && X3_ABLATE != 4) X3_STAGE_W(k1, g1, buf ^ 1);
+        if (ok1) X3_GATHER2(k1, g1, AA, pr);
+        if (act0 | act1) {
+          const f32x4* wb = &s_wb[buf][0];
+          bf16x8_t Bf[2][PL];
+          if (X3_BDEPTH == 2) {
+#pragma unroll
+            for (int p = 0; p < PL; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]);
+          }
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt) {
+            if (X3_BDEPTH == 2) {
+              if (jt + 1 < NTW) {
+#pragma unroll
+                for (int p = 0; p < PL; ++p)
+                  Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * (PL * 64) + p * 64 + lane]);
+              }
+            } else {
+#pragma unroll
+              for (int p = 0; p < PL; ++p) Bf[jt & 1][p] = __builtin_bit_cast(bf16x8_t, wb[jt * (PL * 64) + p * 64 + lane]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MODE == 1) {
+              const bf16x8_t B0 = Bf[jt & 1][0];
+              if (act0) acc[ta][jt] = x3_mfma(B0, P0.p0, acc[ta][jt]);
+              if (act1) acc[tb][jt] = x3_mfma(B0, P1.p0, acc[tb][jt]);
+            } else {
+              const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][PL > 1 ? 1 : 0], B2 = Bf[jt & 1][PL > 2 ? 2 : 0];
+              if (act0 & act1) {
+                // the two tiles alternate: consecutive MFMAs never wait for each other's accumulator
+                acc[ta][jt] = x3_mfma(B2, P0.p0, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B2, P1.p0, acc[tb][jt]);
+                acc[ta][jt] = x3_mfma(B0, P0.p2, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B0, P1.p2, acc[tb][jt]);
+                acc[ta][jt] = x3_mfma(B1, P0.p1, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B1, P1.p1, acc[tb][jt]);
+                acc[ta][jt] = x3_mfma(B1, P0.p0, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B1, P1.p0, acc[tb][jt]);
+                acc[ta][jt] = x3_mfma(B0, P0.p1, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B0, P1.p1, acc[tb][jt]);
+                acc[ta][jt] = x3_mfma(B0, P0.p0, acc[ta][jt]);
+                acc[tb][jt] = x3_mfma(B0, P1.p0, acc[tb][jt]);
+              } else if (act0) {
+                X3_SIX(acc[ta][jt], P0, B0, B1, B2)
+              } else {
+                X3_SIX(acc[tb][jt], P1, B0, B1, B2)
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (!ok1) break;
+      // before the barrier: this wave's share of the next step's weights has landed (and its rows of the next step)
+      X3_STAGE_FLUSH(buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (X3_ABLATE != 5) __syncthreads();
+      k0 = k1;
+      g0 = g1;
+      X3_ADV(k1, g1, Ur, ok1);
+      buf ^= 1;
     }
 #undef X3_SIX
-#undef X3_STEP
 #undef X3_ADV
+#undef X3_GATHER2
 #undef X3_STAGE_W
 #undef X3_STAGE_FLUSH
-#undef X3_GATHER
   }
 
   // ---- fused 1x1 shortcut (fp32 MFMAs on the wave's own rows, as in k_spconv_fwd3: 1/27 of the work)
@@ -528,21 +524,35 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
-  dim3 grid(pp_blocks(a.n_out, X3_R * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
-#define X3_CASE(N)                                                                                                          \
-  case N:                                                                                                                   \
-    if (a.bf16) {                                                                                                           \
-      if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true, 1>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);  \
-      else hipLaunchKernelGGL((k_spconv_x3<N, false, 1>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);         \
-    } else {                                                                                                                \
-      if (a.ds_in) hipLaunchKernelGGL((k_spconv_x3<N, true, 0>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);  \
-      else hipLaunchKernelGGL((k_spconv_x3<N, false, 0>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags);         \
-    }                                                                                                                       \
+  // 64 rows per wave on two-column-tile launches: built and measured (PP_CONV_X3_T4=1), NOT the default -- 32->32 at 5.4 M rows
+  // 1630 us with 32 rows per wave, 1723 with 64 (the fp32-MFMA kernel: 1793); 64->32 2686 / 2953 / 2991; 96->32 3798 / 4268 / 4254
+  // (profiles/r05_ab_x3_two_tiles.txt): half the staging and barriers per row do not pay for the third of the occupancy
+  static const int env_t4 = getenv("PP_CONV_X3_T4") ? atoi(getenv("PP_CONV_X3_T4")) : 0;
+  const bool t4 = ntw == 2 && !a.ds_in && env_t4 == 1;
+  const int R = t4 ? 64 : 32;
+  dim3 grid(pp_blocks(a.n_out, R * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+#define X3_LAUNCH(N, DSV, MD, TT) \
+  hipLaunchKernelGGL((k_spconv_x3<N, DSV, MD, TT>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags)
+#define X3_CASE(N)                                        \
+  case N:                                                 \
+    if (a.bf16) {                                         \
+      if (a.ds_in) X3_LAUNCH(N, true, 1, 2);              \
+      else X3_LAUNCH(N, false, 1, 2);                     \
+    } else {                                              \
+      if (a.ds_in) X3_LAUNCH(N, true, 0, 2);              \
+      else X3_LAUNCH(N, false, 0, 2);                     \
+    }                                                     \
     break;
+  if (t4) {
+    if (a.bf16) X3_LAUNCH(2, false, 1, 4);
+    else X3_LAUNCH(2, false, 0, 4);
+    return PP_OK;
+  }
   switch (ntw) {
     X3_CASE(2) X3_CASE(3) X3_CASE(4) X3_CASE(5) X3_CASE(6)
     default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;
   }
 #undef X3_CASE
+#undef X3_LAUNCH
   return PP_OK;
 }

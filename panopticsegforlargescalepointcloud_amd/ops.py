@@ -92,13 +92,12 @@ class LaunchProfiler:
     @staticmethod
     def kernel_family(cin, cout, K):
         """which kernel the library runs a convolution of this shape on (mirrors spconv_fwd_impl, csrc/pp_spconv.hip): "x3" = the
-        split-operand kernel (>= PP_CONV_X3_MIN_NTW sixteen-column tiles per wave at <= 4 per wave), "fwd3" = the fp32-MFMA kernel"""
+        split-operand kernel (>= PP_CONV_X3_MIN_NTW = 2 sixteen-column tiles per wave), "fwd3" = the fp32-MFMA kernel"""
         if os.environ.get("PP_CONV_X3", "1") == "0" or cin % 16 or cout % 4 or K < 2 or K > 27:
             return "fwd3"
         nt = (cout + 15) // 16
         g4 = (nt + 3) // 4
-        ntw, min_ntw = (nt + g4 - 1) // g4, int(os.environ.get("PP_CONV_X3_MIN_NTW", "3"))
-        return "x3" if (ntw >= min_ntw or (ntw == 2 and min_ntw == 3 and cin >= 96)) else "fwd3"
+        return "x3" if (nt + g4 - 1) // g4 >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "2")) else "fwd3"
 
     def summarize(self, tag=None):
         torch.cuda.synchronize()

@@ -489,14 +489,14 @@ def test_bench_launches_its_own_ranks(monkeypatch):
 
 def test_conv_kernel_family_rule(monkeypatch):
     """which kernel a convolution shape runs on, as bench.py's per-family traffic figures assume it (mirrors spconv_fwd_impl):
-    >= 3 sixteen-column tiles per wave, or two with >= 96 input channels -> the split-operand kernel; 1x1 and thin layers,
+    >= 2 sixteen-column tiles per wave (>= 32 output channels) -> the split-operand kernel; 1x1 and 16-channel layers,
     the 4-channel input layer and everything under PP_CONV_X3=0 -> the fp32-MFMA kernel"""
     from panopticsegforlargescalepointcloud_amd import ops
     fam = ops.LaunchProfiler.kernel_family
     monkeypatch.delenv("PP_CONV_X3", raising=False)
     monkeypatch.delenv("PP_CONV_X3_MIN_NTW", raising=False)
     want = {(64, 64, 27): "x3", (48, 48, 27): "x3", (128, 48, 27): "x3", (160, 64, 27): "x3", (96, 96, 27): "x3", (192, 80, 27): "x3",
-            (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "fwd3", (32, 32, 27): "fwd3", (16, 16, 27): "fwd3",
+            (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "x3", (32, 32, 27): "x3", (16, 16, 27): "fwd3",
             (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3"}
     for (cin, cout, K), f in want.items():
         assert fam(cin, cout, K) == f, (cin, cout, K)
