@@ -429,7 +429,10 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
       // two column tiles per wave (the 32-channel layers): 10 - 12 % faster than the fp32-MFMA kernel layer by layer (32->32 at 5.4 M
       // rows 1793 -> 1630 us, 64->32 2991 -> 2686, 96->32 4254 -> 3798) and 1.1 ms per step (118.8 -> 117.7, three alternating pairs,
       // profiles/r05_ab_x3_two_tiles.txt); one column tile (the 16-channel layers) stays on the fp32 MFMAs: texture-path bound
-      if (n4 >= env_x3_ntw && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
+      // (... with >= 32 input channels: a 16-channel input is ONE half-empty group per offset -- 16->32 at 5.1 M rows 837 us on the
+      // fp32 MFMAs, 1162 on the split kernel; one column tile, the 16-channel outputs: 16->16 1018 / 1601 us, 64->16 and 32->16 even)
+      const bool thin_in = n4 <= 2 && (c0 + c1) < 32;
+      if (n4 >= env_x3_ntw && !thin_in && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
     }
     if (rc == PP_UNSUPPORTED) rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;

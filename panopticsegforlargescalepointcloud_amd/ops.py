@@ -97,7 +97,8 @@ class LaunchProfiler:
             return "fwd3"
         nt = (cout + 15) // 16
         g4 = (nt + 3) // 4
-        return "x3" if (nt + g4 - 1) // g4 >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "2")) else "fwd3"
+        ntw = (nt + g4 - 1) // g4
+        return "x3" if ntw >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "2")) and not (ntw <= 2 and cin < 32) else "fwd3"
 
     def summarize(self, tag=None):
         torch.cuda.synchronize()

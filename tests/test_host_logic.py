@@ -497,7 +497,7 @@ def test_conv_kernel_family_rule(monkeypatch):
     monkeypatch.delenv("PP_CONV_X3_MIN_NTW", raising=False)
     want = {(64, 64, 27): "x3", (48, 48, 27): "x3", (128, 48, 27): "x3", (160, 64, 27): "x3", (96, 96, 27): "x3", (192, 80, 27): "x3",
             (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "x3", (32, 32, 27): "x3", (16, 16, 27): "fwd3",
-            (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3"}
+            (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3", (16, 32, 27): "fwd3", (16, 48, 27): "x3"}
     for (cin, cout, K), f in want.items():
         assert fam(cin, cout, K) == f, (cin, cout, K)
     monkeypatch.setenv("PP_CONV_X3", "0")
