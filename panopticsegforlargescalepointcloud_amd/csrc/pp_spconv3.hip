@@ -1,7 +1,8 @@
-// K4 (wide layers): the dense-offset sparse convolution on the bf16 matrix pipe with fp32 results -- "X3".
+// K4 (layers with >= 32 input and output channels): the dense-offset sparse convolution on the bf16 matrix pipe with fp32
+// results -- "X3".
 //
 // Why.  k_spconv_fwd3 (pp_spconv2.hip) multiplies fp32 operands with v_mfma_f32_16x16x4_f32, which runs at the fp32 VECTOR
-// rate (157 TFLOP/s, 32 cycles per SIMD for 2048 flops); its >= 48-channel layers keep that pipe 0.74 - 0.77 busy, i.e.
+// rate (157 TFLOP/s, 32 cycles per SIMD for 2048 flops); its >= 48-channel layers keep that pipe 0.74 - 0.77 busy (the 32-channel ones 0.65), i.e.
 // they are bound by it.  v_mfma_f32_16x16x32_bf16 does 16384 flops in ~17 cycles.  An fp32 number is
 // EXACTLY the sum of three bfloat16 numbers (8 + 8 + 8 significand bits: hi = the top 16 bits of x, mid = the top 16 bits
 // of x - hi, lo = the rest; all three subtractions are exact), so
