@@ -649,7 +649,7 @@ def main():
                                      "traffic_over_algorithmic": tr / (pf["bytes"] / n_),
                                      "frac_mfma_fp32": pf["flops"] / (pf["ms"] * 1e-3) / FP32_MFMA_PEAK,
                                      "frac_hbm": pf["bytes"] / (pf["ms"] * 1e-3) / HBM_PEAK}
-                roof["by_kernel_family"] = fams  # fwd3 = fp32-MFMA kernel (<= 32-channel layers), x3 = split-operand kernel (wide layers)
+                roof["by_kernel_family"] = fams  # fwd3 = fp32-MFMA kernel (16-channel layers), x3 = split-operand kernel (>= 32 channels)
                 roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE + FETCH_SIZE raw + 0.5 x kernel-map "
                                           "bytes; calibration profiles/r05_fetch_calibration.md)")
             except Exception:
@@ -658,7 +658,7 @@ def main():
         x3_on = os.environ.get("PP_CONV_X3", "1") != "0"
         roof.update({"kernel": "k_spconv_fwd3 + k_spconv_x3 (pp_spconv_fwd)" if x3_on else "k_spconv_fwd3 (pp_spconv_fwd)",
                      # fp32 operands and fp32-accurate results everywhere; which matrix pipe multiplies them
-                     "mfma_path": ("layers with >= 3 column tiles per wave: v_mfma_f32_16x16x32_bf16 on operands split exactly into "
+                     "mfma_path": ("layers with >= 2 column tiles per wave (>= 32 output channels; on two tiles >= 32 input channels): v_mfma_f32_16x16x32_bf16 on operands split exactly into "
                                    "three bfloat16 terms, six products, fp32 accumulation (k_spconv_x3); the others: "
                                    "v_mfma_f32_16x16x4_f32.  peak = the fp32 MFMA peak either way") if x3_on else
                                   "v_mfma_f32_16x16x4_f32 on every layer (PP_CONV_X3=0)", "launches_per_step": prof["launches"] // max(event_steps, 1), "event_steps": event_steps,

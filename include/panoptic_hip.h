@@ -225,7 +225,8 @@ int pp_morton_order(const int32_t* coords, int64_t n, int32_t unit, int32_t bloc
  * neighbours come back as hardware-checked zeros); inputs of 4 GiB or more per source take the slower kernel.
  * The packed buffer (pp_packed_weight_floats floats; opaque to the caller) holds three sections when cin % 16 == 0: the fp32 MFMA
  * fragments, the same fragments split EXACTLY into three bfloat16 planes (w == hi + mid + lo) and rounded to nearest-even
- * bfloat16.  Launches with >= 3 sixteen-column tiles per wave (cout >= 48) evaluate their fp32 products from the split planes on
+ * bfloat16.  Launches with >= 2 sixteen-column tiles per wave (cout >= 32; on two tiles only with >= 32 input channels; the rule itself:
+ * pp_spconv_kernel_family) evaluate their fp32 products from the split planes on
  * v_mfma_f32_16x16x32_bf16 -- six bf16 products per fp32 product, fp32 accumulation, error below one fp32 rounding per
  * product (csrc/pp_spconv3.hip; environment PP_CONV_X3=0: v_mfma_f32_16x16x4_f32 everywhere); pp_spconv_fwd_bf16 uses
  * the rounded plane there.  Results are fp32 tensors in every case.
@@ -287,6 +288,12 @@ int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1,
  * the caller, must outlive the launches and serves ONE stream at a time; NULL un-registers.  Needs
  * split * n_out * cout * 4 bytes, otherwise the launch runs unsplit. */
 int pp_spconv_set_scratch(void* scratch, size_t bytes);
+/* Which kernel the pp_spconv_fwd family runs a launch of this shape on: 1 = k_spconv_x3 (fp32 operands split exactly into three
+ * bfloat16 terms, bf16 matrix pipe; >= 2 sixteen-column tiles per wave and, on <= 2 tiles, >= 32 input channels), 0 = the fp32-MFMA
+ * kernels.  The dispatch's own rule (environment overrides included), exported so that a profiler attributes launch times to a
+ * kernel family without mirroring it.  replaces: nothing in the reference (ME picks its kernels internally, reached from
+ * modules/MinkowskiEngine/api_modules.py:30-51); measurement support for SURVEY.md 8(d). */
+int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int32_t K, int64_t n_out, int32_t cout, int32_t shortcut);
 int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                        const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                        const float* scale, const float* shift, int32_t relu, const float* residual,

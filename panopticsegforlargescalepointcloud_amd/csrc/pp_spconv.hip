@@ -13,6 +13,7 @@
 // D reg r of lane l -> D[row=4*(l>>4)+r][col=l&15].  With a float4 per lane, MFMA #t of a 16-channel
 // step consumes channels {t, 4+t, 8+t, 12+t}: lane (i,q) feeds A[i][4q+t], lane (j,q) feeds W[4q+t][j].
 #include <stdlib.h>
+#include <string.h>
 
 #include "pp_spconv.h"
 
@@ -322,6 +323,47 @@ extern "C" int pp_spconv_set_scratch(void* scratch, size_t bytes) {
   return PP_OK;
 }
 
+// Which launches take the split-operand kernel k_spconv_x3 (pp_spconv3.hip), and with how many column tiles per wave: 0 = none
+// (the fp32-MFMA kernel k_spconv_fwd3 runs the launch).  The rule: cin % 16 == 0, 2 <= K <= 27, >= PP_CONV_X3_MIN_NTW (default 2)
+// sixteen-column tiles per wave and -- on launches with <= 2 column tiles -- >= 32 input channels.  PP_CONV_X3=0: never.
+//   column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
+//   gathers AND splits the rows again) -- 96->96 transposed onto 5.4 M rows 2942 -> 2348 us, 96->96 at 2.4 M rows 5566 -> 4662,
+//   192->80 at 0.15 M rows 842 -> 656, 80->80 384 -> 333, 160->160 928 -> 799 (140 - 152 VGPRs and 45 - 51 KiB of LDS: three
+//   workgroups per CU instead of four); launches below 0.4 M rows stop at 5 (96->96 at 32 k rows 118 -> 135 us with 6), the
+//   fused-shortcut form at 4 (its second accumulator set would leave two waves per SIMD).  PP_CONV_X3_MAX_NTW = 4 .. 6 forces
+//   the bound (A/B runs, profiles/r05_ab_x3_ntw.txt).
+//   two column tiles per wave (the 32-channel layers): 10 - 12 % faster than the fp32-MFMA kernel layer by layer (32->32 at 5.4 M
+//   rows 1793 -> 1630 us, 64->32 2991 -> 2686, 96->32 4254 -> 3798) and 1.1 ms per step (118.8 -> 117.7, three alternating pairs,
+//   profiles/r05_ab_x3_two_tiles.txt); one column tile (the 16-channel layers) stays on the fp32 MFMAs: texture-path bound
+//   (... with >= 32 input channels: a 16-channel input is ONE half-empty group per offset -- 16->32 at 5.1 M rows 837 us on the
+//   fp32 MFMAs, 1162 on the split kernel; one column tile, the 16-channel outputs: 16->16 1018 / 1601 us, 64->16 and 32->16 even)
+static int x3_column_tiles(const SpconvArgs& a, int64_t n_in, bool shortcut) {
+  static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
+  static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 2;
+  static const int env_x3_max = getenv("PP_CONV_X3_MAX_NTW") ? atoi(getenv("PP_CONV_X3_MAX_NTW")) : 0;
+  if (!env_x3 || (a.c0 + a.c1) % 16 != 0) return 0;
+  const int mx = shortcut ? 4 : (env_x3_max >= 4 && env_x3_max <= 6 ? env_x3_max : (a.n_out >= 400000 ? 6 : 5));
+  int g4 = (a.NT + 3) / 4;
+  if ((a.NT + mx - 1) / mx < g4) g4 = (a.NT + mx - 1) / mx;
+  const int n4 = (a.NT + g4 - 1) / g4;
+  const bool thin_in = n4 <= 2 && (a.c0 + a.c1) < 32;
+  return (n4 >= env_x3_ntw && !thin_in && pp_spconv_x3_ok(a, n_in, n4)) ? n4 : 0;
+}
+
+/* Which kernel pp_spconv_fwd / _shortcut / _t8 run a launch of this shape on: 1 = k_spconv_x3 (split-operand, bf16 matrix pipe),
+ * 0 = k_spconv_fwd3 / k_spconv_fwd (fp32 MFMAs).  The same function the dispatch calls -- for profilers that attribute launch times
+ * to a kernel family (ops.LaunchProfiler) without mirroring the rule. */
+extern "C" int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int32_t K, int64_t n_out, int32_t cout,
+                                       int32_t shortcut) {
+  if (c0 <= 0 || c1 < 0 || n_out <= 0) return 0;
+  SpconvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout; a.NT = pp_nt(cout);
+  const bool mode16 = ((c0 + c1) % 16 == 0) && c0 % 16 == 0;
+  if (!mode16 || K > 28 || !pp_spconv_fwd3_ok(a, n_in)) return 0;
+  return x3_column_tiles(a, n_in, shortcut != 0) ? 1 : 0;
+}
+
 // rows_per_wave (0 | 32 | 64), pipeline (0 | 1 | 3) and split_k (0 | 1 | 2 | 4 | 8) select the variant of the pipelined
 // kernel explicitly; 0 = the per-shape choice below.  The parity tests drive every variant through pp_spconv_fwd_ex.
 static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
@@ -409,30 +451,12 @@ static int spconv_fwd_impl(const float* in0, int32_t c0, const float* in1, int32
         return PP_UNSUPPORTED;
       a.ds_in = ds_in; a.ds_wp = ds_packed; a.ds_scale = ds_scale; a.ds_shift = ds_shift; a.ds_c = ds_c;
     }
-    // wide layers: the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip) unless a variant was asked for.
-    // PP_CONV_X3=0: never; PP_CONV_X3_MIN_NTW: fewest column tiles per wave that take it (default 3)
-    static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
-    static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 2;
+    // wide layers: the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip) unless a variant was asked for
+    // (x3_column_tiles above: the rule, also exported as pp_spconv_kernel_family)
     int rc = PP_UNSUPPORTED;
-    if (env_x3 && !pipeline && !rows_per_wave && mode16) {
-      // column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
-      // gathers AND splits the rows again) -- 96->96 transposed onto 5.4 M rows 2942 -> 2348 us, 96->96 at 2.4 M rows 5566 -> 4662,
-      // 192->80 at 0.15 M rows 842 -> 656, 80->80 384 -> 333, 160->160 928 -> 799 (140 - 152 VGPRs and 45 - 51 KiB of LDS: three
-      // workgroups per CU instead of four); launches below 0.4 M rows stop at 5 (96->96 at 32 k rows 118 -> 135 us with 6), the
-      // fused-shortcut form at 4 (its second accumulator set would leave two waves per SIMD).  PP_CONV_X3_MAX_NTW = 4 .. 6 forces
-      // the bound (A/B runs, profiles/r05_ab_x3_ntw.txt).
-      static const int env_x3_max = getenv("PP_CONV_X3_MAX_NTW") ? atoi(getenv("PP_CONV_X3_MAX_NTW")) : 0;
-      const int mx = ds_in ? 4 : (env_x3_max >= 4 && env_x3_max <= 6 ? env_x3_max : (n_out >= 400000 ? 6 : 5));
-      int g4 = (a.NT + 3) / 4;
-      if ((a.NT + mx - 1) / mx < g4) g4 = (a.NT + mx - 1) / mx;
-      const int n4 = (a.NT + g4 - 1) / g4;
-      // two column tiles per wave (the 32-channel layers): 10 - 12 % faster than the fp32-MFMA kernel layer by layer (32->32 at 5.4 M
-      // rows 1793 -> 1630 us, 64->32 2991 -> 2686, 96->32 4254 -> 3798) and 1.1 ms per step (118.8 -> 117.7, three alternating pairs,
-      // profiles/r05_ab_x3_two_tiles.txt); one column tile (the 16-channel layers) stays on the fp32 MFMAs: texture-path bound
-      // (... with >= 32 input channels: a 16-channel input is ONE half-empty group per offset -- 16->32 at 5.1 M rows 837 us on the
-      // fp32 MFMAs, 1162 on the split kernel; one column tile, the 16-channel outputs: 16->16 1018 / 1601 us, 64->16 and 32->16 even)
-      const bool thin_in = n4 <= 2 && (c0 + c1) < 32;
-      if (n4 >= env_x3_ntw && !thin_in && pp_spconv_x3_ok(a, n_in, n4)) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
+    if (!pipeline && !rows_per_wave) {
+      const int n4 = x3_column_tiles(a, n_in, ds_in != nullptr);
+      if (n4) rc = pp_spconv_x3_launch(a, n_in, n4, (unsigned)((a.NT + n4 - 1) / n4), pp_s(stream));
     }
     if (rc == PP_UNSUPPORTED) rc = pp_spconv_fwd3_launch(a, n_in, ntw, (unsigned)groups, T, depth, pp_s(stream));
     if (rc != PP_OK) return rc;

@@ -29,6 +29,11 @@
 
 #include "pp_spconv.h"
 
+// The weight staging writes m0 in inline assembly and lists it as clobbered, so that the compiler never keeps a value of its own
+// live in m0 across the statement (it re-materialises m0 before every instruction of its own that reads it).  clang warns about any
+// reserved register on a clobber list; the clobber is what is wanted here.
+#pragma clang diagnostic ignored "-Winline-asm"
+
 #define X3_MAXK 28
 #ifndef X3_WPB
 #define X3_WPB 4  // waves per workgroup (A/B builds: 8 = 256 rows share a staged weight slice)
@@ -116,9 +121,7 @@ __device__ __forceinline__ f32x4 x3_mfma(bf16x8_t b, bf16x8_t a, f32x4 c) {
 // pp_spconv_fwd_bf16): both operands rounded to nearest-even bfloat16 -- the weights at packing time (third section of the
 // packed buffer), the gathered rows in registers (v_cvt_pk_bf16_f32) -- ONE v_mfma_f32_16x16x32_bf16 per tile, column tile
 // and 32 channels, fp32 accumulation; same workgroup-synchronous walk, one 1 KiB weight plane per column tile staged.
-// T = 16-row tiles per wave: 2, or 4 on the two-column-tile layers (64 rows per wave: the staging, the barrier and the step
-// bookkeeping are paid per 256 instead of per 128 rows; the tiles are split and multiplied two at a time, so the register budget
-// is that of T = 2 plus the second pair's gathered rows and accumulators).
+// T = 16-row tiles per wave: 2 (T = 4, 64 rows per wave, compiles but is not instantiated: it lost on every layer it was tried on).
 template <int NTW, bool DS, int MODE, int T>
 __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags) {
   constexpr int R = 16 * T;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
           const unsigned lds_ = wb_lds + (unsigned)(BUF) * (NTW * PL * 1024u) + (unsigned)j * 1024u;              \
           const unsigned sj_ = so_ + (unsigned)j * 1024u;                                                    \
           asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"           \
-                       ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory");                             \
+                       ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory", "m0");                             \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
@@ -525,12 +528,10 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
-  // 64 rows per wave on two-column-tile launches: built and measured (PP_CONV_X3_T4=1), NOT the default -- 32->32 at 5.4 M rows
-  // 1630 us with 32 rows per wave, 1723 with 64 (the fp32-MFMA kernel: 1793); 64->32 2686 / 2953 / 2991; 96->32 3798 / 4268 / 4254
-  // (profiles/r05_ab_x3_two_tiles.txt): half the staging and barriers per row do not pay for the third of the occupancy
-  static const int env_t4 = getenv("PP_CONV_X3_T4") ? atoi(getenv("PP_CONV_X3_T4")) : 0;
-  const bool t4 = ntw == 2 && !a.ds_in && env_t4 == 1;
-  const int R = t4 ? 64 : 32;
+  // (64 rows per wave -- T = 4 -- on the two-column-tile launches was built and measured in round 5 and lost: 32->32 at 5.4 M rows
+  // 1630 us with 32 rows per wave, 1723 with 64; 64->32 2686 / 2953; 96->32 3798 / 4268, profiles/r05_ab_x3_two_tiles.txt: half the
+  // staging and barriers per row do not pay for the third of the occupancy.  The instantiation was removed in round 6.)
+  const int R = 32;
   dim3 grid(pp_blocks(a.n_out, R * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
 #define X3_LAUNCH(N, DSV, MD, TT) \
   hipLaunchKernelGGL((k_spconv_x3<N, DSV, MD, TT>), grid, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags)
@@ -544,11 +545,6 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
       else X3_LAUNCH(N, false, 0, 2);                     \
     }                                                     \
     break;
-  if (t4) {
-    if (a.bf16) X3_LAUNCH(2, false, 1, 4);
-    else X3_LAUNCH(2, false, 0, 4);
-    return PP_OK;
-  }
   switch (ntw) {
     X3_CASE(2) X3_CASE(3) X3_CASE(4) X3_CASE(5) X3_CASE(6)
     default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;

@@ -57,6 +57,7 @@ class LaunchProfiler:
     def __init__(self, reserve=0):
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
         self.map_k = []    # per record: rows of the kernel map the launch streams (27, or 8 for an 8-wide transposed map)
+        self.fams = []     # per record: kernel family the launch ran on ("x3" / "fwd3"), asked from the library at launch time
         self.tags = []     # per record: TAG at launch time ("fwd" / "dgrad": the input gradient runs on the forward kernel)
         self.records_w = []  # weight-gradient launches (pp_spconv_bwd_weight): (start, end, n_in, n_out, cin, cout, K, pairs)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
@@ -90,15 +91,12 @@ class LaunchProfiler:
         return {"launches": len(self.records_w), "ms": ms, "bytes": b, "flops": fl}
 
     @staticmethod
-    def kernel_family(cin, cout, K):
-        """which kernel the library runs a convolution of this shape on (mirrors spconv_fwd_impl, csrc/pp_spconv.hip): "x3" = the
-        split-operand kernel (>= PP_CONV_X3_MIN_NTW = 2 sixteen-column tiles per wave), "fwd3" = the fp32-MFMA kernel"""
-        if os.environ.get("PP_CONV_X3", "1") == "0" or cin % 16 or cout % 4 or K < 2 or K > 27:
-            return "fwd3"
-        nt = (cout + 15) // 16
-        g4 = (nt + 3) // 4
-        ntw = (nt + g4 - 1) // g4
-        return "x3" if ntw >= int(os.environ.get("PP_CONV_X3_MIN_NTW", "2")) and not (ntw <= 2 and cin < 32) else "fwd3"
+    def kernel_family(cin, cout, K, n_in=1 << 20, n_out=1 << 20, c1=0, shortcut=False):
+        """which kernel the library runs a convolution of this shape on: "x3" = the split-operand kernel, "fwd3" = the fp32-MFMA
+        kernels.  Asks the library (pp_spconv_kernel_family: the dispatch's own rule, its cached environment overrides included)
+        instead of mirroring it.  cin = channels of both sources together, c1 = those of the second (ME.cat fused)."""
+        fam = _lib.load().pp_spconv_kernel_family(int(cin) - int(c1), int(c1), int(n_in), int(K), int(n_out), int(cout), int(bool(shortcut)))
+        return "x3" if fam == 1 else "fwd3"
 
     def summarize(self, tag=None):
         torch.cuda.synchronize()
@@ -108,7 +106,8 @@ class LaunchProfiler:
         by_family = {}
         tags = self.tags if len(self.tags) == len(self.records) else [None] * len(self.records)
         map_k = self.map_k if len(self.map_k) == len(self.records) else [None] * len(self.records)
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg, mk in zip(self.records, counts, tags, map_k):
+        fams = self.fams if len(self.fams) == len(self.records) else [None] * len(self.records)
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, tg, mk, fam in zip(self.records, counts, tags, map_k, fams):
             if tag is not None and tg != tag:
                 continue
             n_used += 1
@@ -128,7 +127,9 @@ class LaunchProfiler:
             tot_flops += fl
             ms = e0.elapsed_time(e1)
             tot_ms += ms
-            f = by_family.setdefault(self.kernel_family(cin, cout, K), {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "map_bytes": 0.0})
+            if fam is None:
+                fam = self.kernel_family(cin, cout, K, n_in, n_out, 0, ds_c > 0)
+            f = by_family.setdefault(fam, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "map_bytes": 0.0})
             f["launches"] += 1
             f["ms"] += ms
             f["bytes"] += b
@@ -869,6 +870,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         prof.records.append((e0, e1, in0.shape[0], n_out, c0 + c1, cout, K, _pairs_of(nbr), residual is not None,
                              shortcut[0].shape[1] if shortcut is not None else 0))
         prof.tags.append(PROFILE_TAG)
+        prof.fams.append("fwd3" if variant is not None else LaunchProfiler.kernel_family(c0 + c1, cout, K, in0.shape[0], n_out, c1, shortcut is not None))
         prof.map_k.append(-1 if cmap is not None else (8 if t8 else K))  # (-1: compact map, bytes from the pair count)
     return out
 

@@ -1063,12 +1063,18 @@ def test_spconv_kernel_variants_match_oracle(ops, oracle, kind, c0, c1, cout, ro
 
 
 X3_SHAPES = [("same", 64, 0, 64), ("same", 48, 0, 48), ("same", 80, 80, 64), ("strided", 48, 0, 48), ("transposed", 96, 96, 80),
-             ("transposed", 64, 64, 128), ("same", 32, 0, 64), ("same", 112, 0, 112)]
+             ("transposed", 64, 64, 128), ("same", 32, 0, 64), ("same", 112, 0, 112),
+             # two column tiles per wave: the 32-output-channel layers (k_spconv_x3<2, ...>, the template with the largest share of the
+             # bench step) incl. a strided launch.  (The test surface has 4.4 pairs per row -- the density of the proposal scorer's levels, 4.6;
+             # "dust" thins it to 2.4: most tiles then walk offsets only one or two of their rows have)
+             ("same", 32, 0, 32), ("same", 64, 0, 32), ("same", 96, 0, 32), ("same", 32, 32, 32), ("strided", 32, 0, 32),
+             ("dust", 32, 0, 32), ("dust", 64, 0, 32)]
 
 
 @pytest.mark.parametrize("kind,c0,c1,cout", X3_SHAPES)
 def test_spconv_x3_default_wide_layers(ops, oracle, kind, c0, c1, cout):
-    """Layers with >= 3 column tiles per wave run by default on k_spconv_x3 (pp_spconv3.hip): fp32 operands split EXACTLY into three
+    """Layers with >= 2 column tiles per wave (>= 32 output channels; on two tiles >= 32 input channels) run by default on
+    k_spconv_x3 (pp_spconv3.hip): fp32 operands split EXACTLY into three
     bfloat16 terms, six bf16 MFMA products, fp32 accumulation.  Against the fp32 oracle at 1e-4 like every other variant; against
     a float64 evaluation of the same sums its error must not exceed the fp32-MFMA kernel's (forced through variant=(32, 1, 1))
     by more than a rounding or two -- it is an fp32-accurate evaluation, not a reduced-precision one; odd numbers of 16-channel
@@ -1076,10 +1082,16 @@ def test_spconv_x3_default_wide_layers(ops, oracle, kind, c0, c1, cout):
     transposed and split-K launches, all with folded BN, ReLU and residual."""
     rng = np.random.default_rng(7)
     fine = surface(rng, n=26000, n_batch=3, extent=120)
+    if kind == "dust":  # a thinned surface: most neighbours are missing, a 16-row tile walks many offsets for few pairs
+        fine = fine[np.sort(rng.choice(len(fine), int(0.42 * len(fine)), replace=False))]
     coarse, _ = oracle.stride_coords(fine, 2)
-    out_c, in_c, sign = {"same": (fine, fine, 1), "strided": (coarse, fine, 1), "transposed": (fine, coarse, -1)}[kind]
+    out_c, in_c, sign = {"same": (fine, fine, 1), "dust": (fine, fine, 1), "strided": (coarse, fine, 1),
+                         "transposed": (fine, coarse, -1)}[kind]
     nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
     n_in, n_out = len(in_c), len(out_c)
+    if kind == "dust":
+        ppr = float((nbr >= 0).sum()) / n_out
+        assert 1.5 < ppr < 4.0, ppr
     x0 = (rng.normal(size=(n_in, c0)) * np.exp(rng.normal(size=(n_in, 1)))).astype(np.float32)  # rows of very different magnitude
     x1 = rng.normal(size=(n_in, c1)).astype(np.float32) if c1 else None
     W = (rng.normal(size=(27, c0 + c1, cout)) * 0.1).astype(np.float32)

@@ -487,18 +487,24 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def test_conv_kernel_family_rule(monkeypatch):
-    """which kernel a convolution shape runs on, as bench.py's per-family traffic figures assume it (mirrors spconv_fwd_impl):
-    >= 2 sixteen-column tiles per wave (>= 32 output channels) -> the split-operand kernel; 1x1 and 16-channel layers,
-    the 4-channel input layer and everything under PP_CONV_X3=0 -> the fp32-MFMA kernel"""
+def test_conv_kernel_family_rule():
+    """which kernel a convolution shape runs on, as bench.py's per-family figures attribute it: the library's own dispatch rule
+    (pp_spconv_kernel_family, a host function -- no GPU needed): >= 2 sixteen-column tiles per wave (>= 32 output channels) and,
+    on <= 2 tiles, >= 32 input channels -> the split-operand kernel; 1x1 and 16-channel layers, the 4-channel input layer and
+    everything under PP_CONV_X3=0 (read once per process: checked in a child) -> the fp32-MFMA kernel"""
+    import subprocess
+    import sys
     from panopticsegforlargescalepointcloud_amd import ops
     fam = ops.LaunchProfiler.kernel_family
-    monkeypatch.delenv("PP_CONV_X3", raising=False)
-    monkeypatch.delenv("PP_CONV_X3_MIN_NTW", raising=False)
     want = {(64, 64, 27): "x3", (48, 48, 27): "x3", (128, 48, 27): "x3", (160, 64, 27): "x3", (96, 96, 27): "x3", (192, 80, 27): "x3",
             (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "x3", (32, 32, 27): "x3", (16, 16, 27): "fwd3",
             (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3", (16, 32, 27): "fwd3", (16, 48, 27): "x3"}
-    for (cin, cout, K), f in want.items():
-        assert fam(cin, cout, K) == f, (cin, cout, K)
-    monkeypatch.setenv("PP_CONV_X3", "0")
-    assert fam(64, 64, 27) == "fwd3"
+    if os.environ.get("PP_CONV_X3", "1") != "0" and not os.environ.get("PP_CONV_X3_MIN_NTW"):
+        for (cin, cout, K), f in want.items():
+            assert fam(cin, cout, K) == f, (cin, cout, K)
+        assert fam(64, 32, 27, c1=32) == "x3" and fam(48, 32, 27, c1=16) == "fwd3"  # two sources (ME.cat fused): equal widths only
+        assert fam(64, 64, 27, n_in=1 << 26) == "fwd3"  # >= 4 GiB of input rows: not addressable by the buffer descriptors
+    code = "from panopticsegforlargescalepointcloud_amd import ops; print(ops.LaunchProfiler.kernel_family(64, 64, 27))"
+    env = dict(os.environ, PP_CONV_X3="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip().endswith("fwd3"), out.stdout + out.stderr
