@@ -758,14 +758,15 @@ class _BatchNormTrainFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps, relu, momentum, running):
         x = x.contiguous()
         rm, rv, nbt = running if running is not None else (None, None, None)
-        y, mean, rstd = ops.bn_train_fwd(x, weight, bias, eps, momentum, rm, rv, relu, nbt)
+        ctx.sync = ops.sync_bn_active()  # (the backward all-reduces exactly when the forward did)
+        y, mean, rstd = ops.bn_train_fwd(x, weight, bias, eps, momentum, rm, rv, relu, nbt, use_sync=ctx.sync)
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, mean, rstd, y = ctx.saved_tensors
-        dx, dweight, dbias = ops.bn_train_bwd(x, dy.contiguous(), y, weight, mean, rstd)
+        dx, dweight, dbias = ops.bn_train_bwd(x, dy.contiguous(), y, weight, mean, rstd, use_sync=ctx.sync)
         return dx, dweight, dbias, None, None, None, None
 
 
@@ -781,7 +782,8 @@ class _ConvBnActTrainFn(torch.autograd.Function):
         h = ops.spconv_fwd(feats, _pack(kernel, kflip=kflip), nbr, n_out, kernel.shape[-1], K,
                            row_order=getattr(nbr, "pp_order", None), bf16=bf16)
         rm, rv, nbt = running if running is not None else (None, None, None)
-        y, mean, rstd = ops.bn_train_fwd(h, bn_w, bn_b, eps, momentum, rm, rv, relu, nbt)
+        ctx.sync = ops.sync_bn_active()
+        y, mean, rstd = ops.bn_train_fwd(h, bn_w, bn_b, eps, momentum, rm, rv, relu, nbt, use_sync=ctx.sync)
         ctx.save_for_backward(feats, kernel, h, bn_w, mean, rstd, y if relu else None)
         ctx.nbr, ctx.inv_fn, ctx.K, ctx.bf16 = nbr, inv_fn, K, bf16
         ctx.same_level, ctx.kflip = same_level, kflip
@@ -790,7 +792,7 @@ class _ConvBnActTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         feats, kernel, h, bn_w, mean, rstd, y = ctx.saved_tensors
-        dh, dbw, dbb = ops.bn_train_bwd(h, dy.contiguous(), y, bn_w, mean, rstd)
+        dh, dbw, dbb = ops.bn_train_bwd(h, dy.contiguous(), y, bn_w, mean, rstd, use_sync=ctx.sync)
         din, dw = _conv_backward(ctx, feats, kernel, dh, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return (din, dw, dbw if bn_w is not None else None, dbb if ctx.needs_input_grad[3] else None,
                 None, None, None, None, None, None, None, None, None, None)
@@ -800,8 +802,10 @@ FUSE_TRAIN = os.environ.get("PP_FUSE_TRAIN", "1") != "0"
 
 
 def _one_row_check(n, c):
-    """batch statistics of a single row: torch's BatchNorm1d (what ME.MinkowskiBatchNorm wraps) refuses them in training"""
-    if n == 1:
+    """batch statistics of a single row: torch's BatchNorm1d (what ME.MinkowskiBatchNorm wraps) refuses them in training.
+    Under SyncBN the statistics are those of all ranks' rows and a rank must never leave the collective schedule on its own (a
+    raise here would leave its peers blocked in the all-reduce): no local check, like torch's SyncBatchNorm with world size > 1."""
+    if n == 1 and not ops.sync_bn_active():
         raise ValueError("Expected more than 1 value per channel when training, got input size torch.Size([1, %d])" % c)
 
 

@@ -994,11 +994,35 @@ def bn_bwd_reduce(x, dy):
 # statistics of the whole batch.  None = per-replica statistics (the fused three-launch kernels).  training.enable_sync_bn sets it.
 SYNC_BN_GROUP = None   # a torch.distributed process group, or True for the default group
 SYNC_BN_STATS = {"all_reduces": 0}
+# The collective schedule must be the same on every rank.  The backbone and the heads run the same layers on every rank whatever
+# their cylinders hold; the proposal scorer does not -- a rank without proposals skips it, a rank with many runs it in several
+# chunks (pointgroup3heads.group_and_score / _score_unique) -- so its BatchNorms keep per-replica statistics (their "batch" is the
+# rank's proposals, not cylinders): `sync_bn_suspended()` around the scorer.  The decision is taken in the forward and kept by the
+# autograd node (`use_sync` below), so that a layer's backward issues a collective exactly when its forward did.
+_SYNC_BN_SUSPENDED = threading.local()
 
 
-def _sync_bn_group():
+class sync_bn_suspended:
+    """with ops.sync_bn_suspended(): training-mode BatchNorms inside use per-replica statistics even when SyncBN is on"""
+
+    def __enter__(self):
+        self.prev = getattr(_SYNC_BN_SUSPENDED, "on", False)
+        _SYNC_BN_SUSPENDED.on = True
+        return self
+
+    def __exit__(self, *exc):
+        _SYNC_BN_SUSPENDED.on = self.prev
+        return False
+
+
+def sync_bn_active():
+    """True when a training-mode BatchNorm launched now would all-reduce its statistics"""
+    return _sync_bn_group() is not None
+
+
+def _sync_bn_group(use_sync=None):
     g = SYNC_BN_GROUP
-    if g is None:
+    if g is None or use_sync is False or (use_sync is None and getattr(_SYNC_BN_SUSPENDED, "on", False)):
         return None
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -1022,7 +1046,10 @@ def _all_reduce_f64(dist, group, t):
 def _bn_train_fwd_sync(sync, x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked):
     dist, group = sync
     n, c = x.shape
-    s, ss = channel_stats(x)
+    if n:
+        s, ss = channel_stats(x)
+    else:  # a rank without rows still joins the collective
+        s = ss = torch.zeros(c, dtype=torch.float64, device=x.device)
     tot = _all_reduce_f64(dist, group, torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=x.device)]))
     N = tot[2 * c]
     mean = tot[:c] / N
@@ -1046,28 +1073,33 @@ def _bn_train_bwd_sync(sync, x, dy, y_relu, weight, save_mean, save_rstd):
     n, c = x.shape
     if y_relu is not None:
         dy = dy * (y_relu > 0).to(dy.dtype)
-    a, b = bn_bwd_reduce(x, dy)              # local sum(dy), sum(dy * x), float64
+    if n:
+        a, b = bn_bwd_reduce(x, dy)          # local sum(dy), sum(dy * x), float64
+    else:
+        a = b = torch.zeros(c, dtype=torch.float64, device=x.device)
     tot = _all_reduce_f64(dist, group, torch.cat([a, b, torch.tensor([float(n)], dtype=torch.float64, device=x.device)]))
     N = tot[2 * c]
     A = tot[:c]
     B = (tot[c:2 * c] - save_mean * A) * save_rstd      # sum over the whole batch of dy * xhat
     w = torch.ones(c, dtype=torch.float64, device=x.device) if weight is None else weight.double()
-    # dx = w rstd (dy - mean(dy) - xhat mean(dy xhat)) with the means over the WHOLE batch; as one affine map of (dy, x):
-    #   dx = s dy + t x + u,  s = w rstd, t = -s rstd B / N, u = -s A / N - t mean
+    # dx = w rstd (dy - mean(dy) - xhat mean(dy xhat)) with the means over the WHOLE batch, evaluated on CENTRED operands:
+    #   dx = s (dy - A / N) + t (x - mean),  s = w rstd, t = -s rstd B / N
+    # (folding the constants into one offset u = -s A / N - t mean makes t x and t mean cancel in fp32: an error of
+    # eps |mean| / std per channel that the fused per-replica kernel does not have)
     sc = w * save_rstd
     t = -sc * save_rstd * B / N
-    u = -sc * A / N - t * save_mean
-    dx = torch.addcmul(torch.addcmul(u.float().expand_as(x), dy, sc.float()), x, t.float())
+    dx = (dy - (A / N).float()) * sc.float() + (x - save_mean.float()) * t.float()
     dweight = ((b - save_mean * a) * save_rstd).float()  # the local part: the gradient all-reduce adds the ranks'
     return dx, dweight, a.float()
 
 
-def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked=None):
+def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu, num_batches_tracked=None, use_sync=None):
     """Training-mode BatchNorm1d (+ fused ReLU); running statistics (nullable) updated in place, num_batches_tracked (nullable
-    int64 scalar on the device) incremented by the same launches.
+    int64 scalar on the device) incremented by the same launches.  use_sync: None = SyncBN when it is on and not suspended
+    (ask `sync_bn_active()` first and pass the answer to the backward), False = per-replica statistics.
     Returns (y, save_mean, save_rstd); the saved statistics are float64."""
     lib = _lib.load()
-    sync = _sync_bn_group()
+    sync = _sync_bn_group(use_sync)
     if sync is not None:
         return _bn_train_fwd_sync(sync, _need(x, torch.float32, "x"), weight, bias, eps, momentum, running_mean, running_var,
                                   relu, num_batches_tracked)
@@ -1088,12 +1120,13 @@ def bn_train_fwd(x, weight, bias, eps, momentum, running_mean, running_var, relu
     return y, stat[0], stat[1]
 
 
-def bn_train_bwd(x, dy, y_relu, weight, save_mean, save_rstd):
-    """Backward of bn_train_fwd: (dx, dweight, dbias); y_relu (the forward output) masks dy when the ReLU was fused."""
+def bn_train_bwd(x, dy, y_relu, weight, save_mean, save_rstd, use_sync=None):
+    """Backward of bn_train_fwd: (dx, dweight, dbias); y_relu (the forward output) masks dy when the ReLU was fused.
+    use_sync: what the forward of this layer did (a layer's backward all-reduces exactly when its forward did)."""
     lib = _lib.load()
     x = _need(x, torch.float32, "x")
     dy = _need(dy, torch.float32, "dy")
-    sync = _sync_bn_group()
+    sync = _sync_bn_group(use_sync)
     if sync is not None:
         return _bn_train_bwd_sync(sync, x, dy, y_relu, weight, save_mean, save_rstd)
     n, c = x.shape

@@ -221,7 +221,10 @@ class PointGroup3heads(nn.Module):
                 csr, cluster_type = fns[ct](pred, None if off is None else off.detach(),
                                             None if emb is None else emb.detach())
             if self.use_score_net and csr.n:
-                cluster_scores, mask_scores = self._compute_score(epoch, csr, feats, sem)
+                # (the scorer's launches depend on this rank's proposals -- none at all, or several chunks -- so its BatchNorms never
+                # take part in SyncBN's collectives: per-replica statistics over the rank's own proposals, ops.sync_bn_suspended)
+                with ops.sync_bn_suspended():
+                    cluster_scores, mask_scores = self._compute_score(epoch, csr, feats, sem)
                 self._lap("scorer")
         return PanopticResults(semantic_logits=sem, offset_logits=off, embed_logits=emb, clusters=None,
                                cluster_scores=cluster_scores, mask_scores=mask_scores, cluster_type=cluster_type,

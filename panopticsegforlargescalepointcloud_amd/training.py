@@ -16,7 +16,13 @@ with scorer_type "unet", the whole scorer before `prepare_epoch`), always in buc
 collectives in the same order whatever its local batch did.  A parameter that received a gradient on NO rank keeps
 `.grad = None` (one small MAX all-reduce of a has-gradient mask): the optimizer skips it exactly as on one GPU -- no
 weight decay, no Adam state for never-used parameters.  The same mask re-sorts the buckets after a step: parameters
-that were absent everywhere move to trailing buckets and stop blocking the overlap of the others."""
+that were absent everywhere move to trailing buckets and stop blocking the overlap of the others.
+
+Collective schedule with SyncBN (`enable_sync_bn`): the BatchNorms of the backbone and the heads all-reduce their statistics from
+inside forward and backward, in layer order -- the same on every rank; the proposal scorer, whose launches depend on the rank's own
+proposals, is excluded (`ops.sync_bn_suspended`, per-replica statistics over the rank's proposals), and the gradient buckets are
+all launched by `finish()`, after backward, so that no bucket interleaves with a BatchNorm all-reduce differently on different
+ranks (tests/test_syncbn_gpu.py: two ranks, one of them without any proposal, past `prepare_epoch`)."""
 import os
 
 import torch
@@ -100,6 +106,13 @@ class GradientReducer:
 
     def _launch_ready(self):
         # strictly in bucket order: ranks whose gradients arrive in a different order still issue identical collectives
+        if ops.SYNC_BN_GROUP is not None:
+            # SyncBN's backward issues blocking all-reduces of its own from inside backward; how many buckets are complete between
+            # two of them differs per rank (a rank without proposals has no scorer gradients), so a bucket launched here would sit
+            # at a different place of the collective sequence on different ranks -- mismatched collectives (gloo aborts, RCCL
+            # hangs).  With SyncBN on every bucket waits for finish(): the sequence is [BatchNorm all-reduces in layer order]
+            # [buckets in bucket order] [mask] on every rank.  (Costs the overlap: 45 MB of gradients after backward.)
+            return
         while self._next < len(self.buckets) and self._missing[self._next] == 0:
             self._launch(self._next)
             self._next += 1

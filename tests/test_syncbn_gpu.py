@@ -141,3 +141,70 @@ def test_two_ranks_normalise_like_one_rank_with_the_whole_batch():
         np.testing.assert_allclose(fw[1], rm0, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(fw[2], rv5, rtol=1e-5, atol=1e-7)
     assert ar0 == ar1 and ar0 >= 80  # one all-reduce per training-mode BatchNorm and direction
+
+
+def _train_worker(rank, world, port, q):
+    """two steps of training.train_step past prepare_epoch with SyncBN and a GradientReducer; rank 1 finds no proposal at all
+    (every class declared "stuff"), so it never runs the scorer -- the ranks' launch sequences differ, their collectives must not"""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from panopticsegforlargescalepointcloud_amd import ops, training
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        training.enable_sync_bn(True)
+        model, data, dev = _model_and_batch(TILES[2 * rank: 2 * rank + 2])
+        if rank == 1:
+            model._stuff_classes = torch.arange(-1, model.num_classes)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+        reducer = training.GradientReducer(model.parameters(), bucket_bytes=8 << 20)
+        epoch = int(model.opt.prepare_epoch) + 1
+        losses, props = [], []
+        for _ in range(2):
+            losses.append(training.train_step(model, data, opt, epoch, dev, world, reducer=reducer))
+            csr = model.output.clusters_csr
+            props.append(0 if csr is None else int(csr.n))
+        named = dict(model.named_parameters())
+        scorer_grad = any(p.grad is not None for n_, p in named.items() if n_.startswith("ScorerUnet."))
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+        q.put((rank, losses, props, scorer_grad, reducer.launched_in_backward, ops.SYNC_BN_STATS["all_reduces"], flat.tobytes()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:
+        q.put((rank, "error: %r" % (e,)))
+        raise
+
+
+def test_syncbn_training_with_a_rank_that_has_no_proposals():
+    """the collective sequence must be the same on every rank.  Rank 0 groups and scores its proposals (ScorerUnet
+    BatchNorms, score loss, scorer gradients), rank 1 has none: the scorer's BatchNorms stay per replica, the gradient buckets wait
+    for finish(), both ranks issue the same number of BatchNorm all-reduces and end with identical parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = sorted((q.get(timeout=400) for _ in range(world)), key=lambda m: m[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # (a mismatched collective blocks its ranks: do not leave them behind)
+            if p.is_alive():
+                p.terminate()
+    assert all(len(m) == 7 for m in got), got
+    (_, l0, p0, sg0, in_bwd0, ar0, w0), (_, l1, p1, sg1, in_bwd1, ar1, w1) = got
+    assert all(np.isfinite(l0 + l1))
+    assert min(p0) > 0 and max(p1) == 0, (p0, p1)         # rank 0 scored proposals, rank 1 had none
+    assert sg0 and sg1                                      # ... yet both hold the (averaged) scorer gradients
+    assert in_bwd0 == 0 and in_bwd1 == 0                    # with SyncBN every bucket is launched by finish()
+    assert ar0 == ar1 and ar0 >= 2 * 2 * 80                 # same BatchNorm all-reduces on both ranks (2 steps x 2 directions)
+    assert w0 == w1, "replicas diverged"
