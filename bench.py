@@ -30,6 +30,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12      # B/s   MI355X_MICROARCH.md chip-level parameters
 FP32_MFMA_PEAK = 157.3e12  # FLOP/s (v_mfma_f32_16x16x4_f32 = fp32 vector rate)
+BF16_MFMA_PEAK = 2.5e15    # FLOP/s dense (v_mfma_f32_16x16x32_bf16; MI355X_MICROARCH.md)
+X3_PRODUCTS = 6            # bf16 products k_spconv_x3 executes per fp32 product (csrc/pp_spconv3.hip)
+
+
+def pipe_seconds(family, flops):
+    """time the matrix pipe a kernel family runs on needs for `flops` algorithmic fp32 flops at its dense peak: the split-operand
+    kernel executes 6 bf16 products per fp32 product on the 2.5 PFLOP/s pipe (ceiling 417 TFLOP/s fp32-equivalent), the fp32-MFMA
+    kernels one product on the 157.3 TFLOP/s pipe"""
+    return X3_PRODUCTS * flops / BF16_MFMA_PEAK if family == "x3" else flops / FP32_MFMA_PEAK
 
 
 def env_int(name, default):
@@ -114,15 +123,16 @@ def host_threads():
         return os.cpu_count(), quota
 
 
-def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=5, warmups=2, n_tiles=16):
+def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=5, warmups=2, n_tiles=16, net_tiles=4):
     """CPU baseline per SURVEY.md 8d on a batch of `n_tiles` tiles around the median size (reported baseline only):
       (1) embedding clustering = the reference's own dependency and fan-out: sklearn MeanShift(bin_seeding) on ONE sample
           per process, min(n_tiles, cores) SPAWNED processes, `pool.map` over the batch's samples exactly as
           torch_points3d/utils/meanshift_cluster.py:9-18,96-101 does (the pool persists across passes: process start-up is
           not charged);
       (2) sparse U-Net + heads + region growing + ScorerUnet = the C/OpenMP restatement (oracle/) on all the threads the
-          container's CPU quota grants, timed on the batch's median tile and scaled by the batch's point count (the
-          restatement is parallel over rows, so a 16-tile batch costs 16 tiles' worth of the same passes).
+          container's CPU quota grants, timed on `net_tiles` tiles of the batch (its smallest ... largest, the median tile among
+          them) and scaled by the batch's point count (the restatement is parallel over rows, so a 16-tile batch costs 16
+          tiles' worth of the same passes); the median-tile-only estimate of earlier rounds is printed beside it.
     Both parts: `warmups` untimed passes, then the median of `repeats`.  value = points of the batch / (network time for
     the batch + mean-shift fan-out time) -- the reference runs the two one after the other inside forward().
     Also returns what the self-check needs to compare the GPU path with the oracle on the median tile."""
@@ -171,30 +181,54 @@ def cpu_baseline(model, cfg, DS, scene, tiles, voxel, repeats=5, warmups=2, n_ti
     j = chosen.index(t_med)
     li = np.nonzero(~np.isin(cls, ignore))[0]
     ms_clusters = [li[ms_labels[j] == l] for l in np.unique(ms_labels[j]) if l != -1] if len(li) > 3 else []
-    # ---- (2) U-Net + heads + region growing + scorer on the median tile
-    runs = []
-    for it in range(warmups + repeats):
+    # ---- (2) U-Net + heads + region growing + scorer: the median tile (2 warm-ups + median of `repeats`, also what the self-check
+    # compares the GPU path with) AND `net_tiles` - 1 more tiles spread over the batch's size range (1 warm-up + median of 3), so
+    # that the batch figure is a sum over tiles of different sizes, not one tile scaled by 16
+    def net_pass(bt, heads, clusters):
         timings = {}
         opipe.CONV_STATS["flops"] = opipe.CONV_STATS["seconds"] = 0.0
         t0 = time.perf_counter()
-        out = opipe.forward(sd, b, opt, DS.num_classes, syn.NPM3D_STUFF, override=(cls, off, emb), use_sklearn_meanshift=use_sk,
-                            timings=timings, ms_clusters=ms_clusters)
-        want_labels = opipe.instance_labels(out, len(b["pos"]), b["batch"])
-        runs.append((time.perf_counter() - t0, timings, dict(opipe.CONV_STATS)))
+        out = opipe.forward(sd, bt, opt, DS.num_classes, syn.NPM3D_STUFF, override=heads, use_sklearn_meanshift=use_sk,
+                            timings=timings, ms_clusters=clusters)
+        want = opipe.instance_labels(out, len(bt["pos"]), bt["batch"])
+        return time.perf_counter() - t0, timings, dict(opipe.CONV_STATS), out, want
+
+    runs = []
+    for it in range(warmups + repeats):
+        runs.append(net_pass(b, (cls, off, emb), ms_clusters))
+    out, want_labels = runs[-1][3], runs[-1][4]
     runs = sorted(runs[warmups:], key=lambda r: r[0])
-    dt, timings, conv = runs[len(runs) // 2]
+    dt, timings, conv = runs[len(runs) // 2][:3]
     n = len(b["pos"])
-    t_net_batch = dt * n_batch / n
+    timed = [(t_med, n, dt)]
+    others = [chosen[i] for i in np.linspace(0, len(chosen) - 1, max(net_tiles, 1)).round().astype(int)] if net_tiles > 1 else []
+    for t in dict.fromkeys(others):  # (distinct, order kept)
+        if t == t_med or len(timed) >= net_tiles:
+            continue
+        bt = syn.tile_batch(scene, tiles, [t])
+        c_t, o_t, e_t = syn.synthetic_head_outputs(scene, bt["origin_id"], 0.0, np.random.default_rng(99))
+        jt = chosen.index(t)
+        li_t = np.nonzero(~np.isin(c_t, ignore))[0]
+        cl_t = [li_t[ms_labels[jt] == l] for l in np.unique(ms_labels[jt]) if l != -1] if len(li_t) > 3 else []
+        tt = sorted(net_pass(bt, (c_t, o_t, e_t), cl_t)[0] for _ in range(1 + 3))  # (the first pass is the slowest or close to it)
+        timed.append((t, len(bt["pos"]), tt[1]))
+    n_timed = sum(v[1] for v in timed)
+    t_net_batch = sum(v[2] for v in timed) * n_batch / n_timed   # the timed tiles' passes, scaled by points to the batch
+    t_net_one = dt * n_batch / n                                  # (round 5's estimate: the median tile alone, scaled)
     timings = dict(timings)
     timings["meanshift"] = t_ms  # the fan-out over the whole batch (the per-tile passes reuse its result)
     res = {"value": n_batch / (t_net_batch + t_ms), "unit": "points/sec", "cores": threads, "host_cpus": os.cpu_count(),
-           "cgroup_cpu_quota": quota, "kind": "port", "tiles_timed_meanshift": len(chosen), "tiles_timed_network": 1,
+           "cgroup_cpu_quota": quota, "kind": "port", "tiles_timed_meanshift": len(chosen), "tiles_timed_network": len(timed),
+           "network_tiles": [{"tile": int(t), "voxels": int(nv), "s_per_pass": round(sec, 3)} for t, nv, sec in timed],
            "network_scaled_to_tiles": len(chosen), "meanshift_processes": procs,
+           "value_from_median_tile_only": n_batch / (t_net_one + t_ms),
            "sample": "batch of %d of %d tiles around the median size (%d voxels): %s MeanShift one sample per spawned process on %d "
                      "processes (pool.map, %.2f s per batch) + C/OpenMP oracle U-Net+heads+region_grow+scorer on %d threads "
-                     "(median tile of %d voxels: %.2f s per pass, scaled by points to the batch: %.1f s); %d warm-ups, median "
-                     "of %d passes each" % (len(chosen), len(tiles), n_batch, "sklearn" if use_sk else "oracle", procs, t_ms,
-                                            threads, n, dt, t_net_batch, warmups, repeats),
+                     "timed on %d tiles of the batch (%d voxels, smallest to largest incl. the median tile: %.2f s per pass in all, "
+                     "scaled by points to the batch: %.1f s; the median tile alone scaled: %.1f s); median tile %d warm-ups + median "
+                     "of %d passes, the other tiles 1 + median of 3" % (
+                         len(chosen), len(tiles), n_batch, "sklearn" if use_sk else "oracle", procs, t_ms, threads, len(timed),
+                         n_timed, sum(v[2] for v in timed), t_net_batch, t_net_one, warmups, repeats),
            "stages_s": {k: round(v, 3) for k, v in timings.items()}}
     res["conv_GFLOPs"] = round(conv["flops"] / max(conv["seconds"], 1e-9) / 1e9, 1)  # sparse convolutions of both U-Nets
     return res, (b, (cls, off, emb), out, want_labels)
@@ -621,6 +655,24 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": prof["flops"] / secs / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # per kernel family: fwd3 = fp32-MFMA kernel (16-channel layers), x3 = split-operand kernel (>= 32 channels).  `frac_mfma_fp32`
+        # = algorithmic flops against the fp32 MFMA peak (the figure of earlier rounds, kept for continuity: the split kernel can
+        # exceed 1 there); `frac_pipe` = against the pipe the family RUNS on (pipe_seconds: 6 bf16 products per fp32 product on the
+        # 2.5 PFLOP/s pipe for x3) -- the honest denominator
+        fams = {}
+        pipe_s = 0.0
+        for fam, pf in prof.get("by_family", {}).items():
+            if pf["launches"]:
+                n_ = pf["launches"]
+                pipe_s += pipe_seconds(fam, pf["flops"])
+                fams[fam] = {"launches_per_step": n_ // max(event_steps, 1), "ms_per_step": pf["ms"] / event_steps,
+                             "alg_bytes_per_launch": pf["bytes"] / n_,
+                             "frac_mfma_fp32": pf["flops"] / (pf["ms"] * 1e-3) / FP32_MFMA_PEAK,
+                             "frac_pipe": pipe_seconds(fam, pf["flops"]) / (pf["ms"] * 1e-3),
+                             "pipe": "bf16 MFMA 2.5 PFLOP/s, 6 products per fp32 product" if fam == "x3" else "fp32 MFMA 157.3 TFLOP/s",
+                             "frac_hbm": pf["bytes"] / (pf["ms"] * 1e-3) / HBM_PEAK}
+        roof["by_kernel_family"] = fams
+        roof["frac_pipe"] = pipe_s / secs  # all launches: matrix-pipe time at the dense peak of the pipe each runs on / measured time
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json; a
         # PMC pass cannot run inside the timed bench).  FETCH_SIZE tallies 64 bytes per request and a request is <= 128 bytes
         # (profiles/r05_fetch_calibration.md: known / raw = 1.06 for random 64-byte rows, 2.0 for 128 / 256 / 384-byte rows and all
@@ -638,18 +690,12 @@ def main():
                 roof["traffic_bounds"] = [w_ + f_ + 0.5 * map_b, w_ + 1.059 * f_ + 0.5 * map_b]
                 roof["map_bytes_per_launch"] = map_b
                 roof["traffic_over_algorithmic"] = roof["traffic"] / (prof["bytes"] / max(prof["launches"], 1))
-                fams = {}
                 for fam, pf in prof.get("by_family", {}).items():
                     cj = tj.get("classes", {}).get(fam)
-                    if cj and pf["launches"]:
+                    if cj and pf["launches"] and fam in fams:
                         n_ = pf["launches"]
                         tr = cj["write_bytes_per_launch"] + cj["fetch_raw_bytes_per_launch"] + 0.5 * pf["map_bytes"] / n_
-                        fams[fam] = {"launches_per_step": n_ // max(event_steps, 1), "ms_per_step": pf["ms"] / event_steps,
-                                     "alg_bytes_per_launch": pf["bytes"] / n_, "traffic_per_launch": tr,
-                                     "traffic_over_algorithmic": tr / (pf["bytes"] / n_),
-                                     "frac_mfma_fp32": pf["flops"] / (pf["ms"] * 1e-3) / FP32_MFMA_PEAK,
-                                     "frac_hbm": pf["bytes"] / (pf["ms"] * 1e-3) / HBM_PEAK}
-                roof["by_kernel_family"] = fams  # fwd3 = fp32-MFMA kernel (16-channel layers), x3 = split-operand kernel (>= 32 channels)
+                        fams[fam].update({"traffic_per_launch": tr, "traffic_over_algorithmic": tr / (pf["bytes"] / n_)})
                 roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE + FETCH_SIZE raw + 0.5 x kernel-map "
                                           "bytes; calibration profiles/r05_fetch_calibration.md)")
             except Exception:

@@ -153,6 +153,19 @@ int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_rec, in
                            int32_t block_bits, uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start,
                            uint64_t* rec, uint64_t* bkey_ord, int32_t* coords, int32_t* counts /*int32[2]*/,
                            void* workspace, size_t workspace_bytes, pp_stream_t stream);
+/* The level chain of an encoder in ONE call: `levels` successive coarsenings (tensor stride unit_fine -> 2 unit_fine -> ...), the
+ * block and row counts of level l - 1 consumed by level l's launches straight from DEVICE memory (no host read between levels).
+ * Every level's outputs have the input level's capacity (nb_fine blocks / n_fine rows, cap = pp_block_index_capacity(nb_fine)) and lie
+ * one after the other: bkeys / bvals [levels][cap], start / bkey_ord [levels][nb_fine], rec [levels][nb_fine * 128],
+ * coords [levels][n_fine * 4], counts [levels][2] = {blocks, rows}: one read of `counts` sizes all levels.  Contents equal `levels`
+ * calls of pp_block_index_coarsen.  workspace: pp_block_index_coarsen_workspace(nb_fine).
+ * replaces: the chain of strided coordinate maps an encoder requests one after the other -- MinkowskiConvolution(stride=2) per
+ * ResNetDown, modules/MinkowskiEngine/api_modules.py:256-271, reached from applications/minkowski.py:160-196 (backbone: 6 levels)
+ * and models/panoptic/PointGroup3heads.py:393-454 (ScorerUnet: 2 levels). */
+int pp_block_index_coarsen_chain(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine, int64_t n_fine,
+                                 int32_t unit_fine, int32_t block_bits, int32_t levels, uint64_t* bkeys, int32_t* bvals,
+                                 int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord, int32_t* coords, int32_t* counts,
+                                 void* workspace, size_t workspace_bytes, pp_stream_t stream);
 int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* bkeys, const int32_t* bvals, int64_t cap,
                      const uint64_t* rec, int32_t unit_src,
                      int32_t block_bits, int32_t step, int32_t sign, int32_t* nbr /*[27][n_out]*/,
@@ -189,6 +202,7 @@ int pp_map_compact_count(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t*
 int pp_map_compact_write(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* start, uint32_t* entries, uint16_t* tags,
                          pp_stream_t stream);
 int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
+                   int64_t translate_rows /*entries of translate = rows of the level the map's values name; 0 without translate*/,
                    int32_t window, int32_t* out, pp_stream_t stream);
 int pp_level_permute(const int32_t* coords, int64_t n, const int32_t* order, int32_t* coords_out, int32_t* inverse,
                      pp_stream_t stream);

@@ -30,6 +30,9 @@ from . import utils  # noqa: F401
 ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
 # build coarser levels from the finer level's block index (PP_COARSEN=0: hash + sort path, for A/B runs)
 COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
+# inference with a prefetch plan: all the coarser levels the plan asks for come from ONE library call (ops.block_index_coarsen_chain:
+# level sizes chained in device memory) and one host read, instead of a call and a read per level (PP_LEVEL_CHAIN=0: A/B runs)
+LEVEL_CHAIN = os.environ.get("PP_LEVEL_CHAIN", "1") != "0"
 # tile scheduling at map-build time (csrc/pp_maporder.hip): every kernel map gets a slot order in which the 16 rows of
 # an MFMA tile want the same offsets; a level's physical row order is the slot order of its same-level map, cross-level
 # maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
@@ -258,6 +261,15 @@ class CoordinateManager:
         self._side_built = False  # anything built on the prefetch stream? (otherwise no cross-stream bookkeeping is needed)
         self._worker_err = None
         self._input_final = threading.Event()  # set when levels[1] and its same-level map are the final ones
+        self._chain = {}        # tensor stride -> (BlockIndex, coords) built ahead by the level chain, not yet made a level
+        self._chain_depth = {}  # tensor stride -> how many successive stride-2 levels the plan asks for from there
+        if prefetch_plan and LEVEL_CHAIN:
+            want = {it[1] for it in prefetch_plan if it[0] == "stride" and it[2] == 2}
+            for ts in want:
+                d = 0
+                while (ts << d) in want:
+                    d += 1
+                self._chain_depth[ts] = d
         try:
             if self.sorted:
                 perm32 = order = None
@@ -380,7 +392,18 @@ class CoordinateManager:
             src = self.levels[ts_in]
             if self.sorted and stride == 2 and ORDER_BLOCK_BITS == 4 and src.index is not None and COARSEN_FROM_INDEX:
                 # the coarse level is a bit permutation of the fine level's occupancy bitmaps: no hash, no sort
-                index, out = ops.block_index_coarsen(src.index, src.n)
+                built = self._chain.pop(ts_out, None)
+                if built is None:
+                    depth = self._chain_depth.get(ts_in, 0)
+                    if depth >= 2 and not torch.is_grad_enabled():
+                        # every level the plan will ask for from here on, in one call and one host read
+                        chain = ops.block_index_coarsen_chain(src.index, src.n, depth)
+                        for l, item in enumerate(chain):
+                            self._chain[ts_in << (l + 1)] = item
+                        built = self._chain.pop(ts_out)
+                    else:
+                        built = ops.block_index_coarsen(src.index, src.n)
+                index, out = built
                 level = _Level(out, index=index)
             else:
                 src_coords = src.coords

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pp_block_index_fill": (C.c_int, [vp, i64, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp]),
     "pp_block_index_coarsen_workspace": (sz, [i64]),
     "pp_block_index_coarsen": (C.c_int, [vp, vp, i64, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "pp_block_index_coarsen_chain": (C.c_int, [vp, vp, i64, i64, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
     "pp_kernel_map_bi": (C.c_int, [vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "pp_proposals_unique_workspace": (sz, [i64]),
     "pp_proposals_unique": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
@@ -69,7 +70,7 @@ SIGNATURES = {
     "pp_map_compact_write": (C.c_int, [vp, i32, i64, vp, vp, vp, vp]),
     "pp_spconv_fwd_cmap": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "pp_map_set_window": (C.c_int, [i32]),
-    "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i32, vp, vp]),
+    "pp_map_permute": (C.c_int, [vp, i32, i64, vp, vp, i64, i32, vp, vp]),
     "pp_level_permute": (C.c_int, [vp, i64, vp, vp, vp, vp]),
     "pp_morton_order_workspace": (sz, [i64]),
     "pp_morton_order": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, sz, vp, vp]),

@@ -177,9 +177,14 @@ __device__ inline uint64_t bi_parent_key(uint64_t fkey) {  // key >> 12 of the f
   const uint64_t outer_mask = (1ull << 36) - 1ull;
   return (fkey & ~outer_mask) | ((fkey & outer_mask) >> 3);
 }
-__global__ __launch_bounds__(256) void k_bic_flags(const uint64_t* __restrict__ fkey, int64_t nb, int32_t* flag) {
+// nb_dev (nullable): the number of fine blocks lives in device memory (a chained coarsening, pp_block_index_coarsen_chain: the
+// previous level's count has not been read by the host); nb is then the launch's upper bound and the flags behind the real count
+// are zero, so that the scans over the upper bound see nothing there
+__global__ __launch_bounds__(256) void k_bic_flags(const uint64_t* __restrict__ fkey, int64_t nb, const int32_t* __restrict__ nb_dev,
+                                                   int32_t* flag) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) flag[b] = (b == 0 || bi_parent_key(fkey[b]) != bi_parent_key(fkey[b - 1])) ? 1 : 0;
+  const int64_t nbr = nb_dev ? (int64_t)nb_dev[0] : nb;
+  if (b < nb) flag[b] = (b < nbr && (b == 0 || bi_parent_key(fkey[b]) != bi_parent_key(fkey[b - 1]))) ? 1 : 0;
 }
 __global__ __launch_bounds__(256) void k_bic_first_child(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank,
                                                          int64_t nb, int32_t* first_child) {
@@ -188,12 +193,14 @@ __global__ __launch_bounds__(256) void k_bic_first_child(const int32_t* __restri
 }
 // one wave per coarse block: its bitmap from the children's bitmaps, its voxel count and key
 __global__ __launch_bounds__(256) void k_bic_bits(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ frec,
-                                                  int64_t nb_f, const int32_t* __restrict__ first_child,
+                                                  int64_t nb_f, const int32_t* __restrict__ nb_dev,
+                                                  const int32_t* __restrict__ first_child,
                                                   const int32_t* __restrict__ n_coarse, uint64_t* crec, int32_t* ccount,
                                                   uint64_t* ckey) {
   __shared__ unsigned long long lds[4][BI_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nbc = n_coarse[0];
+  if (nb_dev) nb_f = nb_dev[0];
   const int64_t c = (int64_t)blockIdx.x * 4 + wave;
   if (c >= nbc) return;
   unsigned long long* w = lds[wave];
@@ -278,17 +285,10 @@ extern "C" size_t pp_block_index_coarsen_workspace(int64_t nb_fine) {
 }
 // All outputs have capacity nb_fine blocks (cap = pp_block_index_capacity(nb_fine)) resp. n_fine rows; counts = {coarse
 // blocks, coarse rows}.  unit_coarse = tensor stride of the NEW level.  block_bits must be 4.
-extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine,
-                                      int32_t unit_coarse, int32_t block_bits, uint64_t* bkeys, int32_t* bvals,
-                                      int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord, int32_t* coords,
-                                      int32_t* counts, void* workspace, size_t workspace_bytes, pp_stream_t stream) {
-  PP_REQUIRE(f_bkey_ord && f_rec && bkeys && bvals && start && rec && bkey_ord && coords && counts,
-             "pp_block_index_coarsen: null pointer");
-  PP_REQUIRE(block_bits == 4, "pp_block_index_coarsen: needs the parity-block row order (block_bits = 4)");
-  PP_REQUIRE(unit_coarse >= 2 && (unit_coarse & (unit_coarse - 1)) == 0, "pp_block_index_coarsen: unit must be a power of two >= 2");
-  PP_REQUIRE(cap >= 2 * nb_fine && (cap & (cap - 1)) == 0, "pp_block_index_coarsen: cap must be a power of two >= 2 nb_fine");
-  if (workspace_bytes < pp_block_index_coarsen_workspace(nb_fine)) return PP_ERR_WORKSPACE;
-  hipStream_t s = pp_s(stream);
+static int bi_coarsen_launch(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine, const int32_t* nb_dev,
+                             int32_t unit_coarse, uint64_t* bkeys, int32_t* bvals, int64_t cap, int32_t* start, uint64_t* rec,
+                             uint64_t* bkey_ord, int32_t* coords, int32_t* counts, void* workspace, size_t workspace_bytes,
+                             hipStream_t s) {
   PP_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s));
   hipLaunchKernelGGL(k_bi_hash_fill, dim3((unsigned)std::min<int64_t>((cap + 255) / 256, 4096)), dim3(256), 0, s, bkeys, cap);
   PP_LAUNCH_CHECK();
@@ -301,13 +301,13 @@ extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t
   int32_t* first_child = ar.take<int32_t>((size_t)nb_fine);
   int32_t* ccount = ar.take<int32_t>((size_t)nb_fine);
   const unsigned gb = pp_blocks(nb_fine, 256), gw = pp_blocks(nb_fine, 4);
-  hipLaunchKernelGGL(k_bic_flags, dim3(gb), dim3(256), 0, s, f_bkey_ord, nb_fine, flag);
+  hipLaunchKernelGGL(k_bic_flags, dim3(gb), dim3(256), 0, s, f_bkey_ord, nb_fine, nb_dev, flag);
   PP_LAUNCH_CHECK();
   int rc = pp_exclusive_scan_i32(flag, rank, nb_fine, counts, ar.cur(), ar.left(), s);  // counts[0] = coarse blocks
   if (rc) return rc;
   hipLaunchKernelGGL(k_bic_first_child, dim3(gb), dim3(256), 0, s, flag, rank, nb_fine, first_child);
   PP_HIP(hipMemsetAsync(ccount, 0, sizeof(int32_t) * (size_t)nb_fine, s));
-  hipLaunchKernelGGL(k_bic_bits, dim3(gw), dim3(256), 0, s, f_bkey_ord, f_rec, nb_fine, first_child, counts, rec, ccount,
+  hipLaunchKernelGGL(k_bic_bits, dim3(gw), dim3(256), 0, s, f_bkey_ord, f_rec, nb_fine, nb_dev, first_child, counts, rec, ccount,
                      bkey_ord);
   PP_LAUNCH_CHECK();
   rc = pp_exclusive_scan_i32(ccount, start, nb_fine, counts + 1, ar.cur(), ar.left(), s);  // counts[1] = coarse rows
@@ -315,6 +315,58 @@ extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t
   hipLaunchKernelGGL(k_bic_finish, dim3(gw), dim3(256), 0, s, bkey_ord, rec, start, counts, unit_shift, bkeys, bvals, cap,
                      (int4*)coords);
   PP_LAUNCH_CHECK();
+  return PP_OK;
+}
+
+extern "C" int pp_block_index_coarsen(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine,
+                                      int32_t unit_coarse, int32_t block_bits, uint64_t* bkeys, int32_t* bvals,
+                                      int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord, int32_t* coords,
+                                      int32_t* counts, void* workspace, size_t workspace_bytes, pp_stream_t stream) {
+  PP_REQUIRE(f_bkey_ord && f_rec && bkeys && bvals && start && rec && bkey_ord && coords && counts,
+             "pp_block_index_coarsen: null pointer");
+  PP_REQUIRE(block_bits == 4, "pp_block_index_coarsen: needs the parity-block row order (block_bits = 4)");
+  PP_REQUIRE(unit_coarse >= 2 && (unit_coarse & (unit_coarse - 1)) == 0, "pp_block_index_coarsen: unit must be a power of two >= 2");
+  PP_REQUIRE(cap >= 2 * nb_fine && (cap & (cap - 1)) == 0, "pp_block_index_coarsen: cap must be a power of two >= 2 nb_fine");
+  if (workspace_bytes < pp_block_index_coarsen_workspace(nb_fine)) return PP_ERR_WORKSPACE;
+  return bi_coarsen_launch(f_bkey_ord, f_rec, nb_fine, nullptr, unit_coarse, bkeys, bvals, cap, start, rec, bkey_ord, coords,
+                           counts, workspace, workspace_bytes, pp_s(stream));
+}
+
+// The level chain of a U-Net encoder in ONE call: `levels` successive coarsenings (tensor stride unit_fine -> 2 unit_fine -> ...),
+// level l built from level l - 1 with the block and row counts chained in DEVICE memory -- no host read between the levels.  The
+// host knows only upper bounds (a coarse level has at most as many blocks and rows as the input level): every level's outputs have
+// the capacity of the input level (nb_fine blocks, n_fine rows), the launches cover nb_fine blocks and read the real count from
+// counts[l - 1].  Per-level outputs are laid out one after the other: bkeys / bvals [levels][cap], start / bkey_ord [levels][nb_fine],
+// rec [levels][nb_fine * 128], coords [levels][n_fine * 4], counts [levels][2] = {blocks, rows} -- ONE read of `counts` after the call
+// sizes every level.  Level l's arrays equal those of `levels` single pp_block_index_coarsen calls (the hash tables aside: their
+// capacity is that of the input level).  workspace: pp_block_index_coarsen_workspace(nb_fine), reused level after level.
+extern "C" int pp_block_index_coarsen_chain(const uint64_t* f_bkey_ord, const uint64_t* f_rec, int64_t nb_fine, int64_t n_fine,
+                                            int32_t unit_fine, int32_t block_bits, int32_t levels, uint64_t* bkeys,
+                                            int32_t* bvals, int64_t cap, int32_t* start, uint64_t* rec, uint64_t* bkey_ord,
+                                            int32_t* coords, int32_t* counts, void* workspace, size_t workspace_bytes,
+                                            pp_stream_t stream) {
+  PP_REQUIRE(f_bkey_ord && f_rec && bkeys && bvals && start && rec && bkey_ord && coords && counts,
+             "pp_block_index_coarsen_chain: null pointer");
+  PP_REQUIRE(block_bits == 4, "pp_block_index_coarsen_chain: needs the parity-block row order (block_bits = 4)");
+  PP_REQUIRE(levels >= 1 && levels <= 14, "pp_block_index_coarsen_chain: 1 .. 14 levels");
+  PP_REQUIRE(unit_fine >= 1 && (unit_fine & (unit_fine - 1)) == 0 && ((int64_t)unit_fine << levels) <= 32768,
+             "pp_block_index_coarsen_chain: unit must be a power of two and the coarsest tensor stride <= 32768");
+  PP_REQUIRE(cap >= 2 * nb_fine && (cap & (cap - 1)) == 0, "pp_block_index_coarsen_chain: cap must be a power of two >= 2 nb_fine");
+  PP_REQUIRE(n_fine >= 0 && nb_fine >= 0, "pp_block_index_coarsen_chain: negative size");
+  if (workspace_bytes < pp_block_index_coarsen_workspace(nb_fine)) return PP_ERR_WORKSPACE;
+  const size_t nbm = (size_t)std::max<int64_t>(nb_fine, 1), nrm = (size_t)std::max<int64_t>(n_fine, 1);
+  const uint64_t* in_key = f_bkey_ord;
+  const uint64_t* in_rec = f_rec;
+  for (int l = 0; l < levels; ++l) {
+    uint64_t* o_key = bkey_ord + (size_t)l * nbm;
+    uint64_t* o_rec = rec + (size_t)l * nbm * 2 * BI_WORDS;
+    int rc = bi_coarsen_launch(in_key, in_rec, nb_fine, l ? counts + 2 * (l - 1) : nullptr, unit_fine << (l + 1),
+                               bkeys + (size_t)l * (size_t)cap, bvals + (size_t)l * (size_t)cap, cap, start + (size_t)l * nbm, o_rec, o_key,
+                               coords + (size_t)l * nrm * 4, counts + 2 * l, workspace, workspace_bytes, pp_s(stream));
+    if (rc) return rc;
+    in_key = o_key;
+    in_rec = o_rec;
+  }
   return PP_OK;
 }
 

@@ -416,7 +416,7 @@ extern "C" int pp_map_compact_write(const int32_t* nbr, int32_t K, int64_t n_out
 template <int W>
 __global__ __launch_bounds__(1024) void k_map_permute_win(const int32_t* __restrict__ nbr, int K, int64_t n,
                                                           const int32_t* __restrict__ order, const int32_t* __restrict__ translate,
-                                                          int32_t* __restrict__ out) {
+                                                          int64_t n_tr, int32_t* __restrict__ out) {
   // one workgroup per window, all K offsets: the window's order (16-bit local) and, with `translate`, the window's own
   // slice of it stay in LDS -- most neighbours of a window's rows live in the window itself (rows are in block order), so
   // the translation is an LDS read for them and a global gather only across window borders; the K slices of the map
@@ -429,7 +429,9 @@ __global__ __launch_bounds__(1024) void k_map_permute_win(const int32_t* __restr
   const int cnt = (int)((n - base) < W ? (n - base) : W);
   for (int j = threadIdx.x; j < cnt; j += NT) {
     ord[j] = (unsigned short)(order[base + j] - (int32_t)base);
-    if (translate) tr[j] = translate[base + j];
+    // (`translate` has n_tr entries -- the rows of the level the map's VALUES name, which a cross-level map's n output rows can
+    // outnumber: the preload stops at its end; values are < n_tr by construction)
+    if (translate) tr[j] = base + j < n_tr ? translate[base + j] : 0;
   }
   int32_t stage[PER];
 #pragma unroll
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_map_permute_win(const int32_t* __restr
         int32_t v = cur[ord[j]];
         if (translate && v >= 0) {
           const int64_t l = (int64_t)v - base;
-          v = (l >= 0 && l < cnt) ? tr[l] : translate[v];
+          v = (l >= 0 && l < cnt && v < n_tr) ? tr[l] : translate[v];
         }
         dst[j] = v;
       }
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(256) void k_map_permute(const int32_t* __restrict__
 }
 // window: the window size `order` was built with (pp_map_window() at that time), or 0 for an arbitrary / NULL order
 extern "C" int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, const int32_t* order, const int32_t* translate,
-                              int32_t window, int32_t* out, pp_stream_t stream) {
+                              int64_t translate_rows, int32_t window, int32_t* out, pp_stream_t stream) {
+  PP_REQUIRE(!translate || translate_rows > 0, "pp_map_permute: translate needs its number of rows");
   PP_REQUIRE((nbr && out) || n_out == 0, "pp_map_permute: null pointer");
   PP_REQUIRE(K >= 1 && K <= 27, "pp_map_permute: K must be in [1,27]");
   PP_REQUIRE(nbr != out, "pp_map_permute: in-place permutation is not supported");
@@ -560,10 +563,10 @@ extern "C" int pp_map_permute(const int32_t* nbr, int32_t K, int64_t n_out, cons
     switch (window) {
       case 16384: hipLaunchKernelGGL(k_map_permute_big<16384>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
       case 32768: hipLaunchKernelGGL(k_map_permute_big<32768>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
-      case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
-      case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
-      case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
-      default: hipLaunchKernelGGL(k_map_permute_win<8192>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, out); break;
+      case 1024: hipLaunchKernelGGL(k_map_permute_win<1024>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, translate_rows, out); break;
+      case 2048: hipLaunchKernelGGL(k_map_permute_win<2048>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, translate_rows, out); break;
+      case 4096: hipLaunchKernelGGL(k_map_permute_win<4096>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, translate_rows, out); break;
+      default: hipLaunchKernelGGL(k_map_permute_win<8192>, grid, dim3(1024), 0, s, nbr, K, n_out, order, translate, translate_rows, out); break;
     }
   } else
     hipLaunchKernelGGL(k_map_permute, dim3(pp_blocks(n_out, 256)), dim3(256), 0, s, nbr, K, n_out, order, translate, out);

@@ -270,6 +270,12 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     const unsigned wb_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)&s_wb[0][0];
 
     // stage the weight slice of step (k, g) into buffer b: 3 NTW pieces of 1 KiB, piece j by wave j % 4
+#ifndef X3_STAGE_ARITH
+#define X3_STAGE_ARITH 1  // LDS-DMA staging: 1 = piece index computed from the wave number, 0 (A/B builds) = one compare + branch per piece
+#endif
+#ifndef X3_TILE_ORDER
+#define X3_TILE_ORDER 1   // MFMAs of a column tile: 1 = tile by tile, accumulating in place, 0 (A/B builds) = the two tiles alternating
+#endif
 #ifndef X3_STAGE_MODE
 #define X3_STAGE_MODE 0  // 0: buffer_load ... lds; 1 (A/B builds): loads into registers at the start of a step, ds_write at its end
 #endif
@@ -284,6 +290,17 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
       _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj)                                                     \
           wreg[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                        \
               rw_, (int)lane16, (int)(so_ + (unsigned)(jj * X3_WPB + wave) * 1024u), 0));                    \
+    } else if (X3_STAGE_ARITH) {                                                                             \
+      /* piece jj * X3_WPB + wave of this wave: scalar arithmetic on the wave number, no branch per piece */ \
+      _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj) {                                                   \
+        const int j_ = jj * X3_WPB + wave;                                                                   \
+        if ((jj + 1) * X3_WPB <= PL * NTW || j_ < PL * NTW) {                                                \
+          const unsigned lds_ = wb_lds + (unsigned)(BUF) * (NTW * PL * 1024u) + (unsigned)j_ * 1024u;        \
+          const unsigned sj_ = so_ + (unsigned)j_ * 1024u;                                                   \
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"           \
+                       ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory", "m0");                       \
+        }                                                                                                    \
+      }                                                                                                      \
     } else {                                                                                                 \
       _Pragma("unroll") for (int j = 0; j < PL * NTW; ++j) {                                                 \
         if ((j % X3_WPB) == wave) {                                                                          \
@@ -393,6 +410,18 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
               if (act1) acc[tb][jt] = x3_mfma(B0, P1.p0, acc[tb][jt]);
             } else {
               const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][PL > 1 ? 1 : 0], B2 = Bf[jt & 1][PL > 2 ? 2 : 0];
+              if (X3_TILE_ORDER == 1) {
+                // tile by tile: every chain accumulates IN PLACE.  The alternating form below merges three code paths per
+                // accumulator; the compiler then writes the products into fresh registers and copies them back -- 4 v_mov_b64
+                // behind an s_nop after EVERY column tile and 12 more at the loop's back edge, each waiting for the matrix pipe
+                // to drain (round 6, read off the ISA)
+                if (act0) {
+                  X3_SIX(acc[ta][jt], P0, B0, B1, B2)
+                }
+                if (act1) {
+                  X3_SIX(acc[tb][jt], P1, B0, B1, B2)
+                }
+              } else
               if (act0 & act1) {
                 // the two tiles alternate: consecutive MFMAs never wait for each other's accumulator
                 acc[ta][jt] = x3_mfma(B2, P0.p0, acc[ta][jt]);

@@ -137,25 +137,31 @@ class LaunchProfiler:
             f["map_bytes"] += mb
         return {"launches": n_used, "ms": tot_ms, "bytes": tot_bytes, "flops": tot_flops, "map_bytes": map_bytes, "by_family": by_family}
 
-    def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12):
-        """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of both roofs."""
+    def table(self, steps=1, hbm_peak=8.0e12, mfma_peak=157.3e12, bf16_peak=2.5e15):
+        """Markdown table: launches grouped by shape, per step -- time, algorithmic GB and GFLOP, fraction of the HBM roof, of the fp32
+        MFMA peak (algorithmic flops; the split-operand kernel can exceed 1 there) and of the pipe the launch RUNS on (x3: six bf16
+        products per fp32 product against the dense bf16 peak)."""
         torch.cuda.synchronize()
         groups = {}
-        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P in zip(self.records, self._pair_counts()):
+        fams = self.fams if len(self.fams) == len(self.records) else [None] * len(self.records)
+        for (e0, e1, n_in, n_out, cin, cout, K, pairs, has_res, ds_c), P, fam in zip(self.records, self._pair_counts(), fams):
             b = 4.0 * (n_in * cin + n_out * cout) + 4.0 * K * cin * cout + 8.0 * P + (4.0 * n_out * cout if has_res else 0.0)
             b += 4.0 * n_out * ds_c + 4.0 * ds_c * cout
-            g = groups.setdefault((n_in, n_out, "%d+%d" % (cin, ds_c) if ds_c else cin, cout, K, P), [0, 0.0, 0.0, 0.0])
+            if fam is None:
+                fam = self.kernel_family(cin, cout, K, n_in, n_out, 0, ds_c > 0)
+            g = groups.setdefault((n_in, n_out, "%d+%d" % (cin, ds_c) if ds_c else cin, cout, K, P, fam), [0, 0.0, 0.0, 0.0])
             g[0] += 1
             g[1] += e0.elapsed_time(e1)
             g[2] += b
             g[3] += 2.0 * P * cin * cout + 2.0 * n_out * ds_c * cout
-        lines = ["| rows in | rows out | Cin | Cout | K | pairs/row | launches/step | ms/step | us/launch | alg GB/s | alg TFLOP/s | "
-                 "frac HBM | frac MFMA |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-        for (n_in, n_out, cin, cout, K, P), (cnt, ms, b, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
+        lines = ["| rows in | rows out | Cin | Cout | K | pairs/row | kernel | launches/step | ms/step | us/launch | alg GB/s | alg TFLOP/s | "
+                 "frac HBM | frac fp32 MFMA | frac pipe |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+        for (n_in, n_out, cin, cout, K, P, fam), (cnt, ms, b, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
             sec = ms / 1e3
-            lines.append("| %d | %d | %s | %d | %d | %.2f | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f |" % (
-                n_in, n_out, cin, cout, K, P / max(n_out, 1), cnt / steps, ms / steps, ms / cnt * 1e3, b / sec / 1e9,
-                fl / sec / 1e12, b / sec / hbm_peak, fl / sec / mfma_peak))
+            pipe = 6.0 * fl / bf16_peak if fam == "x3" else fl / mfma_peak
+            lines.append("| %d | %d | %s | %d | %d | %.2f | %s | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f | %.3f |" % (
+                n_in, n_out, cin, cout, K, P / max(n_out, 1), fam, cnt / steps, ms / steps, ms / cnt * 1e3, b / sec / 1e9,
+                fl / sec / 1e12, b / sec / hbm_peak, fl / sec / mfma_peak, pipe / sec))
         return "\n".join(lines) + "\n"
 
 
@@ -414,6 +420,43 @@ def block_index_coarsen(fine, n_fine_rows):
     return bi, coords[:nc]
 
 
+def block_index_coarsen_chain(fine, n_fine_rows, levels):
+    """`levels` successive coarsenings of a BlockIndex in one library call (csrc/pp_blockindex.hip: the counts of a level feed the
+    next level's launches from device memory) and ONE host read for all the level sizes: [(BlockIndex, coords int32 [n_l, 4]), ...],
+    element l at tensor stride fine.unit << (l + 1).  Every level is a view of arrays with the input level's capacity (the level
+    sizes are not known when they are allocated); levels that turn out much smaller than that get compact copies of their coordinate
+    rows so that the large blocks go back to the allocator."""
+    lib = _lib.load()
+    dev = fine.rec.device
+    nbf, n0, L = int(fine.n_blocks), int(n_fine_rows), int(levels)
+    nbm, nrm = max(nbf, 1), max(n0, 1)
+    cap = int(lib.pp_block_index_capacity(nbf))
+    bkeys = torch.empty((L, cap), dtype=torch.int64, device=dev)
+    bvals = torch.empty((L, cap), dtype=torch.int32, device=dev)
+    start = torch.empty((L, nbm), dtype=torch.int32, device=dev)
+    rec = torch.empty((L, nbm * 128), dtype=torch.int64, device=dev)
+    bkey_ord = torch.empty((L, nbm), dtype=torch.int64, device=dev)
+    coords_all = torch.empty((L, nrm, 4), dtype=torch.int32, device=dev)
+    counts = _zeros(2 * L, torch.int32, dev)
+    wsb = lib.pp_block_index_coarsen_workspace(nbf)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.pp_block_index_coarsen_chain(_ptr(fine.bkey_ord), _ptr(fine.rec), nbf, n0, fine.unit, fine.block_bits, L,
+                                                _ptr(bkeys), _ptr(bvals), cap, _ptr(start), _ptr(rec), _ptr(bkey_ord),
+                                                _ptr(coords_all), _ptr(counts), _ptr(ws), wsb, _stream()),
+               "pp_block_index_coarsen_chain")
+    vals = counts.tolist()  # the chain's one host read
+    out = []
+    for l in range(L):
+        nbc, nc = int(vals[2 * l]), int(vals[2 * l + 1])
+        bi = BlockIndex()
+        bi.unit, bi.block_bits, bi.n_blocks, bi.cap = fine.unit << (l + 1), fine.block_bits, nbc, cap
+        bi.bkeys, bi.bvals, bi.start, bi.rec, bi.bkey_ord = bkeys[l], bvals[l], start[l], rec[l], bkey_ord[l]
+        # the coordinate rows of ALL levels sit in one block of levels x n_fine rows: they are copied out level by level (the sum of
+        # the level sizes, a fraction of the block) and the block goes back to the allocator
+        out.append((bi, coords_all[l, :nc].clone()))
+    return out
+
+
 def kernel_map_bi(out_coords, index, ksize, step, sign, want_mask=False, translate=None):
     """nbr int32 [27, n_out] through a BlockIndex: row in the indexed level of out_coords + sign*offset*step (or -1).
     translate (int32 [rows of the indexed level], optional): found rows r are stored as translate[r]."""
@@ -561,8 +604,8 @@ def map_permute(nbr, order=None, translate=None):
     K, n_out = nbr.shape
     out = torch.empty_like(nbr)
     _lib.check(lib.pp_map_permute(_ptr(nbr), K, n_out, _ptr(_need(order, torch.int32, "order")),
-                                  _ptr(_need(translate, torch.int32, "translate")), int(getattr(order, "pp_window", 0)),
-                                  _ptr(out), _stream()), "pp_map_permute")
+                                  _ptr(_need(translate, torch.int32, "translate")), 0 if translate is None else translate.shape[0],
+                                  int(getattr(order, "pp_window", 0)), _ptr(out), _stream()), "pp_map_permute")
     if hasattr(nbr, "pp_pairs"):
         out.pp_pairs = nbr.pp_pairs
     return out

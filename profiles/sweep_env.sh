@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/sweep_$TAG.txt
 : > $O
 for E in "$@"; do
-  env $E python $R/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-checks ${BENCH_ARGS:-} 2>/dev/null | tail -1 | \
+  env $E python $R/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-checks ${BENCH_ARGS:-} 2>$R/gpurun_out/sweep_${TAG}_err.log | tail -1 | \
     python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j['roofline']; f=r.get('by_kernel_family') or {}

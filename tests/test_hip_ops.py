@@ -857,9 +857,10 @@ def test_map_order_and_slot_ordered_maps(ops, oracle):
             np.testing.assert_allclose(b.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("window", [16384, 32768])
+@pytest.mark.parametrize("window", [1024, 2048, 4096, 8192, 16384, 32768])
 def test_map_order_large_windows(ops, oracle, window):
-    """pp_map_order_window with 16384 / 32768 rows per window (the levels' own order): a window-local permutation sorted by
+    """pp_map_order_window with every window size it takes (1024 .. 32768 rows; 8192 / 16384 are the levels' own orders, the
+    others A/B settings -- 4096 crashed the bench's window sweeps of rounds 4 and 6): a window-local permutation sorted by
     (remapped neighbour mask, row); pp_map_permute with that window restates the same-level map in the new row ids."""
     rng = np.random.default_rng(33)
     for n_pts, n_batch in [(70000, 2), (window // 30, 1)]:
