@@ -1256,6 +1256,41 @@ def test_coarser_levels_from_the_block_index(ops, oracle):
         cur_idx, cur = got_idx, want
 
 
+@pytest.mark.parametrize("levels", [1, 2, 6])
+def test_level_chain_equals_level_by_level_coarsening(ops, oracle, levels):
+    """pp_block_index_coarsen_chain (all levels of an encoder in one call, the counts of a level feeding the next level's launches
+    from device memory, one host read) == `levels` calls of pp_block_index_coarsen: coordinates, records, block starts and keys;
+    kernel maps looked up through a chained index == oracle maps.  Several batch elements, range ends, a level chain that
+    collapses to one voxel per batch element, and an empty input level."""
+    rng = np.random.default_rng(52)
+    fine = surface(rng, n=9000, n_batch=3, extent=120)
+    edge = np.array([[1, 32767, 32767, 32767], [1, 32766, 32766, 32767], [1, -32768, -32768, -32768], [2, -32767, 5, 9]], np.int32)
+    fine = np.unique(np.concatenate([fine, edge]), axis=0).astype(np.int32)
+    fine = fine[ops.morton_order(dev(fine), 1, 4).cpu().numpy()]
+    idx, _ = ops.block_index_build(dev(fine), 1, 4)
+    chain = ops.block_index_coarsen_chain(idx, len(fine), levels)
+    assert len(chain) == levels
+    cur_idx, cur_n, prev = idx, len(fine), fine
+    for l, (got_idx, got) in enumerate(chain):
+        ref_idx, ref = ops.block_index_coarsen(cur_idx, cur_n)
+        ts = 2 << l
+        assert got_idx.unit == ts == ref_idx.unit and got_idx.n_blocks == ref_idx.n_blocks
+        assert torch.equal(got, ref), l
+        nb = ref_idx.n_blocks
+        assert torch.equal(got_idx.rec[: nb * 128], ref_idx.rec[: nb * 128])
+        assert torch.equal(got_idx.start[:nb], ref_idx.start[:nb]) and torch.equal(got_idx.bkey_ord[:nb], ref_idx.bkey_ord[:nb])
+        c = got.cpu().numpy()
+        same = ops.kernel_map_bi(got, got_idx, 3, ts, 1)
+        assert np.array_equal(same.cpu().numpy(), oracle.kernel_map(c, c, 3, ts, 1))
+        down = ops.kernel_map_bi(got, cur_idx, 3, ts // 2, 1)
+        assert np.array_equal(down.cpu().numpy(), oracle.kernel_map(c, prev, 3, ts // 2, 1))
+        cur_idx, cur_n, prev = ref_idx, ref.shape[0], c
+    # an empty level: every coarser level is empty too
+    empty_idx, _ = ops.block_index_build(dev(np.zeros((0, 4), np.int32)), 1, 4)
+    for bi, c in ops.block_index_coarsen_chain(empty_idx, 0, 2):
+        assert bi.n_blocks == 0 and c.shape == (0, 4)
+
+
 def test_linear_wgrad_matches_torch(ops):
     """pp_linear_wgrad (streaming dW / db of a skinny Linear layer) vs the float64 product; through modules.Linear's autograd
     path vs torch.nn.Linear; bit-reproducible from run to run"""
