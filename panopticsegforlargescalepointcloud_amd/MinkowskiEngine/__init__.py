@@ -61,6 +61,7 @@ MAP_T8 = os.environ.get("PP_MAP_T8", "1") != "0"
 # strided maps are slot-ordered when the fine level has fewer than this many rows per coarse row (0 = never; A/B runs)
 STRIDED_ORDER_RATIO = float(os.environ.get("PP_STRIDED_ORDER_RATIO", "1.7"))
 _SIDE_STREAMS = {}
+_NO_READS_MARK = os.environ.get("PP_NO_READS_MARK", "0") == "1"  # evidence runs only: CoordinateManager._reads as in round 5
 
 
 _STREAM_TLS = threading.local()
@@ -176,7 +177,9 @@ def _order_level(coords_m, index, ts):
     order = ops.map_order(nbr_m.pp_mask, window=SAME_WINDOW[0 if ts == 1 else 1])
     del nbr_m.pp_mask
     coords_p, phys_of = ops.level_permute(coords_m, order)
-    return coords_p, order, phys_of, lambda: ops.map_permute(nbr_m, order, translate=phys_of)
+    finish = lambda: ops.map_permute(nbr_m, order, translate=phys_of)  # noqa: E731
+    finish.reads = (nbr_m, order, phys_of)  # (what a caller on ANOTHER stream must mark as in use there: CoordinateManager._reads)
+    return coords_p, order, phys_of, finish
 
 
 _IDENTITY_PAIRS = {}
@@ -363,6 +366,36 @@ class CoordinateManager:
                 t.record_stream(_current_stream())
                 t.pp_seen_by = raw
 
+    def _reads(self, *items):
+        """A build on THIS stream is about to read `items` -- levels, block indices, maps, tensors -- that another stream's build
+        may have allocated (the prefetch worker and the main thread both build whatever is asked of them first; each holds the
+        lock, waits for the producing launch's event, and launches on ITS stream).  The event orders the data; it does not
+        keep the MEMORY: a temporary of the build that the producer stream's allocator pool owns (the Morton-order map a
+        level's pending same-level map is permuted from, a reverse map, an order, a block index) goes back to that pool when
+        its last reference drops, and the producer stream may hand it out again while this stream's kernels still read it --
+        a map full of another kernel's output, row translations gathered at garbage indices (the memory faults of the 4096-row
+        window sweeps in rounds 4 and 6: a timing the default windows rarely reach).  Marks them all for the calling stream."""
+        if not self._side_built or _NO_READS_MARK:
+            return
+        flat = []
+        for it in items:
+            if it is None:
+                continue
+            if torch.is_tensor(it):
+                flat.append(it)
+                flat.extend(t for t in (getattr(it, "pp_order", None), getattr(it, "pp_mask", None), getattr(it, "pp_pairs", None),
+                                        getattr(it, "pp_dense", None)) if t is not None)
+                flat.extend(_cmap_tensors(it))
+            elif isinstance(it, _Level):
+                flat.extend(t for t in (it.coords, it.phys_of, it.same_map) if t is not None)
+                if it.index is not None:
+                    flat.extend(getattr(it.index, a) for a in ops.BlockIndex.__slots__ if torch.is_tensor(getattr(it.index, a, None)))
+                if it.table is not None:
+                    flat.extend((it.table.keys, it.table.vals))
+            elif isinstance(it, (tuple, list)):
+                flat.extend(t for t in it if torch.is_tensor(t))
+        self._consumed_here(*flat)
+
     def level(self, ts):
         self._use(("level", ts))
         lv = self.levels[ts]
@@ -390,9 +423,13 @@ class CoordinateManager:
         if ts_out not in self.levels:
             self._use(("level", ts_in))
             src = self.levels[ts_in]
+            self._reads(src)
             if self.sorted and stride == 2 and ORDER_BLOCK_BITS == 4 and src.index is not None and COARSEN_FROM_INDEX:
                 # the coarse level is a bit permutation of the fine level's occupancy bitmaps: no hash, no sort
                 built = self._chain.pop(ts_out, None)
+                if built is not None:
+                    self._reads(built[1], *[getattr(built[0], a) for a in ops.BlockIndex.__slots__
+                                            if torch.is_tensor(getattr(built[0], a, None))])
                 if built is None:
                     depth = self._chain_depth.get(ts_in, 0)
                     if depth >= 2 and not torch.is_grad_enabled():
@@ -479,6 +516,7 @@ class CoordinateManager:
                 self._use((ts_to, ts_from, ksize, -sign))
             dst = self.levels[ts_to]
             finish = self._pending_same.pop(ts_to, None) if (ts_from == ts_to and sign == 1 and ksize == 3) else None
+            self._reads(dst, self.levels.get(ts_from), rev, getattr(finish, "reads", None))
             if finish is not None:
                 m = dst.same_map = _with_compact(finish())
             elif rev is not None and ts_from == ts_to:
