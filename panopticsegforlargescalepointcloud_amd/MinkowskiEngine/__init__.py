@@ -31,8 +31,14 @@ ORDER_BLOCK_BITS = int(os.environ.get("PP_ORDER_BLOCK", "4"))
 # build coarser levels from the finer level's block index (PP_COARSEN=0: hash + sort path, for A/B runs)
 COARSEN_FROM_INDEX = os.environ.get("PP_COARSEN", "1") != "0"
 # inference with a prefetch plan: all the coarser levels the plan asks for come from ONE library call (ops.block_index_coarsen_chain:
-# level sizes chained in device memory) and one host read, instead of a call and a read per level (PP_LEVEL_CHAIN=0: A/B runs)
+# level sizes chained in device memory) and one host read, instead of a call and a read per level.  Measured (round 6, two
+# alternating pairs each, profiles/r06_ab_level_chain.txt): one rank's share of the 8-GPU scene (1.18 M voxels) 22.25 -> 21.60 ms per
+# step, the full 9.8 M-voxel scene 114.7 -> 116.1 ms -- every level of the chain is allocated at the input level's capacity, and at
+# ~10 M rows that costs more than the five host reads it saves (the builder threads hide those behind the previous batch).  So the
+# chain serves inputs up to PP_LEVEL_CHAIN_MAX_ROWS rows (default 3 M: tile batches of a sharded scene, C2, the scorer's inputs
+# there); PP_LEVEL_CHAIN=0 turns it off, PP_LEVEL_CHAIN_MAX_ROWS=0 lifts the bound (A/B runs).
 LEVEL_CHAIN = os.environ.get("PP_LEVEL_CHAIN", "1") != "0"
+LEVEL_CHAIN_MAX_ROWS = int(os.environ.get("PP_LEVEL_CHAIN_MAX_ROWS", "3000000"))
 # tile scheduling at map-build time (csrc/pp_maporder.hip): every kernel map gets a slot order in which the 16 rows of
 # an MFMA tile want the same offsets; a level's physical row order is the slot order of its same-level map, cross-level
 # maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
@@ -266,7 +272,7 @@ class CoordinateManager:
         self._input_final = threading.Event()  # set when levels[1] and its same-level map are the final ones
         self._chain = {}        # tensor stride -> (BlockIndex, coords) built ahead by the level chain, not yet made a level
         self._chain_depth = {}  # tensor stride -> how many successive stride-2 levels the plan asks for from there
-        if prefetch_plan and LEVEL_CHAIN:
+        if prefetch_plan and LEVEL_CHAIN and (LEVEL_CHAIN_MAX_ROWS <= 0 or coords.shape[0] <= LEVEL_CHAIN_MAX_ROWS):
             want = {it[1] for it in prefetch_plan if it[0] == "stride" and it[2] == 2}
             for ts in want:
                 d = 0

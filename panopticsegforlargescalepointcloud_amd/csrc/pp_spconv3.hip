@@ -273,6 +273,10 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 #ifndef X3_STAGE_ARITH
 #define X3_STAGE_ARITH 1  // LDS-DMA staging: 1 = piece index computed from the wave number, 0 (A/B builds) = one compare + branch per piece
 #endif
+#ifndef X3_AHEAD
+#define X3_AHEAD 1        // gathered rows in flight: 1 = one step ahead; 2 (A/B builds) = two steps ahead, two register sets in ping-pong --
+                          // measured neutral (-0.1 % over 11 layer shapes, profiles/r06_x3_ab_ahead.txt): not bound by the gathers' latency
+#endif
 #ifndef X3_TILE_ORDER
 #define X3_TILE_ORDER 1   // MFMAs of a column tile: 1 = tile by tile, accumulating in place, 0 (A/B builds) = the two tiles alternating
 #endif
@@ -361,8 +365,6 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
     X3_STAGE_FLUSH(0);
 #pragma unroll
     for (int pr = 0; pr < T / 2; ++pr) X3_GATHER2(k0, g0, AA, pr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 #define X3_SIX(ACC, PL, B0, B1, B2)                                                       \
   ACC = x3_mfma(B2, PL.p0, ACC);                 \
   ACC = x3_mfma(B0, PL.p2, ACC);                 \
@@ -370,20 +372,20 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   ACC = x3_mfma(B1, PL.p0, ACC);                 \
   ACC = x3_mfma(B0, PL.p1, ACC);                 \
   ACC = x3_mfma(B0, PL.p0, ACC);
-    for (;;) {
-      // one step: per tile pair -- split its rows of (k0, g0), refill them with the rows of the next step, multiply; the next
-      // step's weights are staged beside the first pair's MFMAs
+    // one step: per tile pair -- split its rows of (k0, g0) held in AX, refill AX with the rows of step (kg, gg) if there is one
+    // (okg), multiply; the next step's weights are staged beside the first pair's MFMAs
+    auto x3_step = [&](f32x4 (&AX)[T][2], const int kg, const int gg, const int okg) __attribute__((always_inline)) {
 #pragma unroll
       for (int pr = 0; pr < T / 2; ++pr) {
         const int ta = 2 * pr, tb = 2 * pr + 1;
         const unsigned act0 = (m[ta] >> k0) & 1u, act1 = (m[tb] >> k0) & 1u;
         X3Planes P0, P1;
-        if (act0) P0 = MODE == 1 ? x3_round(AA[ta][0], AA[ta][1]) : x3_split(AA[ta][0], AA[ta][1]);
+        if (act0) P0 = MODE == 1 ? x3_round(AX[ta][0], AX[ta][1]) : x3_split(AX[ta][0], AX[ta][1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (act1) P1 = MODE == 1 ? x3_round(AA[tb][0], AA[tb][1]) : x3_split(AA[tb][0], AA[tb][1]);
+        if (act1) P1 = MODE == 1 ? x3_round(AX[tb][0], AX[tb][1]) : x3_split(AX[tb][0], AX[tb][1]);
         __builtin_amdgcn_sched_barrier(0);
         if (pr == 0 && ok1 && X3_ABLATE != 4) X3_STAGE_W(k1, g1, buf ^ 1);
-        if (ok1) X3_GATHER2(k1, g1, AA, pr);
+        if (okg) X3_GATHER2(kg, gg, AX, pr);
         if (act0 | act1) {
           const f32x4* wb = &s_wb[buf][0];
           bf16x8_t Bf[2][PL];
@@ -446,6 +448,45 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
           }
         }
       }
+    };
+#if X3_AHEAD == 2
+    // Rows TWO steps ahead (round 6, A/B builds): the gathers of step n + 2 are issued right after the rows of step n have been split,
+    // into the registers that split freed -- two register sets in ping-pong, the loop unrolled by two, no copies.  Fits without
+    // spills since the in-place MFMA chains freed 11 VGPRs (103 -> 118 at four column tiles, four waves per SIMD kept).  Before the
+    // barrier a wave waits for everything but the four gathers it issued last (vmcnt counts in order: the staging loads of step
+    // n + 1 were issued before them).  Result: 19.31 against 19.34 ms over eleven layer shapes -- neutral; round 5's attempt had to
+    // give up a wave per SIMD for it and lost 5 %.  The kernel is not waiting for its rows.
+    static_assert(T == 2, "the two-steps-ahead form holds two tiles per wave");
+    int k2 = k1, g2 = g1, ok2 = ok1;
+    if (ok1) X3_ADV(k2, g2, Ur, ok2);
+    f32x4 AB[T][2];
+    if (ok1) X3_GATHER2(k1, g1, AB, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#define X3_NEXT()                                                    \
+  {                                                                  \
+    X3_STAGE_FLUSH(buf ^ 1);                                         \
+    if (ok2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
+    if (X3_ABLATE != 5) __syncthreads();                             \
+    k0 = k1; g0 = g1; k1 = k2; g1 = g2; ok1 = ok2;                   \
+    if (ok2) X3_ADV(k2, g2, Ur, ok2);                                \
+    buf ^= 1;                                                        \
+  }
+    for (;;) {
+      x3_step(AA, k2, g2, ok1 & ok2);
+      if (!ok1) break;
+      X3_NEXT();
+      x3_step(AB, k2, g2, ok1 & ok2);
+      if (!ok1) break;
+      X3_NEXT();
+    }
+#undef X3_NEXT
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (;;) {
+      x3_step(AA, k1, g1, ok1);
       if (!ok1) break;
       // before the barrier: this wave's share of the next step's weights has landed (and its rows of the next step)
       X3_STAGE_FLUSH(buf ^ 1);
@@ -456,6 +497,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
       X3_ADV(k1, g1, Ur, ok1);
       buf ^= 1;
     }
+#endif
 #undef X3_SIX
 #undef X3_ADV
 #undef X3_GATHER2

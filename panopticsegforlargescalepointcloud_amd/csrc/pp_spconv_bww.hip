@@ -446,7 +446,13 @@ struct Bww4Plan {
   int mt, nto, chunk, tiles_per_k;
   unsigned gx, gz;
 };
-static Bww4Plan bww4_plan(int cin, int cout, int K, int64_t map_rows) {
+static size_t bww4_det_bytes(const Bww4Plan& p, int K) {
+  return (size_t)p.gx * (size_t)K * p.gz * (size_t)(p.mt * p.nto) * 256u * sizeof(float) + 256;
+}
+// det: the plan of the deterministic form -- one partial tile set per block, so the workspace grows with the number of blocks; from
+// PP_WGRAD_DET_MAX_MB (default 1024) on, a wave walks more pairs (fewer, longer blocks: 512 pairs per wave cost a few per cent)
+// so that the partials always fit: the ordered reduction serves every size, no fall-back to float atomics (round 6)
+static Bww4Plan bww4_plan(int cin, int cout, int K, int64_t map_rows, bool det = false) {
   Bww4Plan p;
   p.tiles_per_k = (int)((map_rows + WP_TILE - 1) / WP_TILE);
   p.nto = (cout + 15) / 16;
@@ -460,6 +466,14 @@ static Bww4Plan bww4_plan(int cin, int cout, int K, int64_t map_rows) {
   if (((map_rows + 4 * p.chunk - 1) / (4 * p.chunk)) * (int64_t)K * p.gz < 2048) p.chunk = 128;
   if (chunk_env > 0) p.chunk = chunk_env;
   p.gx = (unsigned)((map_rows + BWW4_WPB * p.chunk - 1) / (BWW4_WPB * p.chunk));
+  if (det) {
+    static const size_t cap = [] { const char* e = getenv("PP_WGRAD_DET_MAX_MB"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 1024) << 20; }();
+    while (bww4_det_bytes(p, K) > cap && p.gx > 1) {
+      const size_t over = (bww4_det_bytes(p, K) + cap - 1) / cap;  // grow by the factor that is missing, in steps of 128 pairs
+      p.chunk = (int)(((int64_t)p.chunk * (int64_t)over + 127) / 128 * 128);
+      p.gx = (unsigned)((map_rows + BWW4_WPB * p.chunk - 1) / (BWW4_WPB * p.chunk));
+    }
+  }
   return p;
 }
 
@@ -516,8 +530,7 @@ extern "C" int pp_spconv_bwd_weight_pairs(const float* in, int32_t cin, int64_t 
 // ---- deterministic form: block partials in a caller-provided workspace + an ordered reduction (no float atomics)
 extern "C" size_t pp_spconv_bwd_weight_pairs_det_workspace(int32_t cin, int32_t cout, int32_t K, int64_t map_rows) {
   if (cin < 1 || cout < 1 || K < 1 || map_rows <= 0) return 256;
-  const Bww4Plan pl = bww4_plan(cin, cout, K, map_rows);
-  return (size_t)pl.gx * (size_t)K * pl.gz * (size_t)(pl.mt * pl.nto) * 256u * sizeof(float) + 256;
+  return bww4_det_bytes(bww4_plan(cin, cout, K, map_rows, true), K);
 }
 
 extern "C" int pp_spconv_bwd_weight_pairs_det(const float* in, int32_t cin, int64_t n_in, const float* dout, int32_t cout,
@@ -536,7 +549,7 @@ extern "C" int pp_spconv_bwd_weight_pairs_det(const float* in, int32_t cin, int6
   PP_REQUIRE(in && dout && pairs && ws, "pp_spconv_bwd_weight_pairs_det: null pointer");
   PP_REQUIRE(ws_bytes >= pp_spconv_bwd_weight_pairs_det_workspace(cin, cout, K, map_rows),
              "pp_spconv_bwd_weight_pairs_det: workspace too small");
-  const Bww4Plan pl = bww4_plan(cin, cout, K, map_rows);
+  const Bww4Plan pl = bww4_plan(cin, cout, K, map_rows, true);
   int rc = bww4_launch(in, cin, n_in, dout, cout, n_out, pairs, tile_start, K, pl, (float*)ws, bf16, true, s);
   if (rc != PP_OK) return rc;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(pl.mt * pl.nto), (unsigned)K, pl.gz), dim3(256), 0, s, (const float*)ws,

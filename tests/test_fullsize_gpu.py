@@ -292,7 +292,7 @@ def test_strided_and_transposed_convolutions_vs_fp64_on_sampled_rows(ops, level,
 @pytest.mark.parametrize("cin,cout,bf16", [(16, 16, False), (32, 48, False), (64, 64, False), (32, 32, True)])
 def test_weight_gradient_at_full_size(ops, level, cin, cout, bf16):
     """dW over the ~6 M-row level (the 32-bit list positions, the chunk grid and the block reduction at the size of a real
-    launch): the pair lists hold exactly the map's pairs per offset, in row order; dW from the lists equals dW from the dense
+    launch; the deterministic form without its fall-back): the pair lists hold exactly the map's pairs per offset, in row order; dW from the lists equals dW from the dense
     map (two independent kernels, different summation orders: 1e-4 of the largest entry) and, for three offsets, an fp64
     evaluation of the definition (torch index arithmetic); a slot-ordered copy of the map gives the same dW from the same
     output gradient."""
@@ -310,6 +310,10 @@ def test_weight_gradient_at_full_size(ops, level, cin, cout, bf16):
         rows = torch.nonzero(nbr[k] >= 0).view(-1)
         assert torch.equal(wp.pairs[lo:hi, 0].long(), rows) and torch.equal(wp.pairs[lo:hi, 1], nbr[k][rows])
     dw = ops.spconv_bwd_weight_pairs(x, dy, wp, bf16=bf16)
+    # the ordered reduction serves this size too (round 6: a wave walks more pairs when the block partials would exceed
+    # PP_WGRAD_DET_MAX_MB; the float-atomic fall-back of round 5 is gone): the same bits run after run, no warning
+    assert torch.equal(dw, ops.spconv_bwd_weight_pairs(x, dy, wp, bf16=bf16))
+    assert not ops._WGRAD_WARNED[0], "the deterministic weight gradient fell back to float atomics"
     dense = ops.spconv_bwd_weight(x, dy, nbr, 27, bf16=bf16)
     scale = float(dense.abs().max())
     err = float((dw - dense).abs().max()) / scale
