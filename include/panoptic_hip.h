@@ -186,10 +186,10 @@ int pp_kernel_map_bi(const int32_t* out_coords, int64_t n_out, const uint64_t* b
  *                    are stored in the level's own row order, so their convolutions need no indirection)
  * Cross-level maps stay slot-major and pp_spconv_fwd takes `order` as row_order.  Results never depend on the order. */
 int32_t pp_map_window(void);
-int pp_map_set_window(int32_t window /*a power of two in [1024, 32768]; 8192 by default*/);
+int pp_map_set_window(int32_t window /*1024, 2048, 8192 (default), 16384 or 32768*/);
 int pp_map_mask(const int32_t* nbr, int32_t K, int64_t n_out, uint32_t* mask, pp_stream_t stream);
 int pp_map_order(const uint32_t* mask, int64_t n, int32_t* order, pp_stream_t stream);
-/* the same with an explicit window (a power of two in [1024, 32768]): the levels' own (same-level) maps take larger windows than
+/* the same with an explicit window (1024, 2048, 8192, 16384 or 32768; 4096 is refused, csrc/pp_maporder.hip): the levels' own (same-level) maps take larger windows than
  * the cross-level ones, whose convolutions scatter output rows inside a window; pp_map_permute takes the window used here */
 int pp_map_order_window(const uint32_t* mask, int64_t n, int32_t window, int32_t* order, pp_stream_t stream);
 /* Compact form of a SAME-LEVEL map for the convolution's prologue (4 + 6 x pairs bytes per row instead of 108): the present entries

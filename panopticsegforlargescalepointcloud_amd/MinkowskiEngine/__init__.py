@@ -44,7 +44,7 @@ LEVEL_CHAIN_MAX_ROWS = int(os.environ.get("PP_LEVEL_CHAIN_MAX_ROWS", "3000000"))
 # maps carry their own order (`nbr.pp_order`).  PP_MAP_ORDER=0 keeps the plain block order (A/B runs).
 MAP_ORDER = os.environ.get("PP_MAP_ORDER", "1") != "0"
 MAP_ORDER_MIN_ROWS = int(os.environ.get("PP_MAP_ORDER_MIN_ROWS", "50000"))  # smaller levels gain nothing from it
-# rows per sort window of a level's OWN order (its same-level map; 1024 .. 32768).  Larger windows give purer 16-row tiles
+# rows per sort window of a level's OWN order (its same-level map; 1024, 2048, 8192, 16384 or 32768 -- 4096 is refused by the library).  Larger windows give purer 16-row tiles
 # (executed / useful tile rows at tensor stride 1: 2.00 at 8192, 1.82 at 32768, profiles/r03_row_cache_model.txt) and gathers that
 # leave the L2 more often: measured per setting in profiles/r04_ab_same_window.txt (time) and r04_window_traffic.txt (HBM bytes).
 # 8192 at tensor stride 1 (16 channels: bound by the gathers) and 16384 at the coarser levels is the fastest; 32768 there costs
