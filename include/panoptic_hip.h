@@ -308,6 +308,12 @@ int pp_spconv_set_scratch(void* scratch, size_t bytes);
  * kernel family without mirroring it.  replaces: nothing in the reference (ME picks its kernels internally, reached from
  * modules/MinkowskiEngine/api_modules.py:30-51); measurement support for SURVEY.md 8(d). */
 int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int32_t K, int64_t n_out, int32_t cout, int32_t shortcut);
+/* The split-operand kernel gathers its rows either in MFMA fragment shape (k_spconv_x3: 16 rows x 4 pieces of 16 bytes per load) or,
+ * on dense maps over whole 32-channel groups (c0 % 32 == 0), as full 128-byte lines straight into LDS (k_spconv_x3f: 8 rows x one
+ * line per load, fragments read back from LDS) -- same packed weights, same summation order, bit-identical results.  mode 1 / 0
+ * switches the full-line form on / off (default on; environment PP_CONV_X3F), any other value only asks; returns the setting before
+ * the call.  replaces: nothing in the reference (ME's kernel choice is internal, api_modules.py:30-51); A/B and parity-test support. */
+int pp_spconv_x3_full_lines(int32_t mode);
 int pp_spconv_fwd_bf16(const float* in0, int32_t c0, const float* in1, int32_t c1, int64_t n_in,
                        const float* packed_weight, const int32_t* nbr, int32_t K, int64_t n_out, int32_t cout,
                        const float* scale, const float* shift, int32_t relu, const float* residual,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pp_spconv_fwd": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_set_scratch": (C.c_int, [vp, sz]),
     "pp_spconv_kernel_family": (C.c_int, [i32, i32, i64, i32, i64, i32, i32]),
+    "pp_spconv_x3_full_lines": (C.c_int, [i32]),
     "pp_spconv_fwd_shortcut": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_fwd_bf16": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pp_spconv_fwd_ex": (C.c_int, [vp, i32, vp, i32, i64, vp, vp, i32, i64, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -26,6 +26,7 @@
 // ascending order, inside an offset over the 32-channel groups, inside a group over the six products in a fixed order --
 // independent of the map form, the row order and the batch, so results are bit-identical across those.
 #include <stdlib.h>
+#include <string.h>
 
 #include "pp_spconv.h"
 
@@ -587,6 +588,360 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
   }
 }
 
+// ---- K4f: the same convolution with the rows gathered as FULL 128-BYTE LINES straight into LDS (round 6) -----------------------
+//
+// k_spconv_x3 gathers its rows in MFMA fragment shape: lane (i, q) loads 16 bytes of row i, so the 64 lanes of one buffer load
+// touch 16 rows x 4 separate 16-byte pieces.  The texture path prices an instruction by the pieces ADJACENT lanes can be merged
+// into (profiles/r06_gather_forms.txt, L2-resident table): that form costs 46 cycles per wave instruction, eight adjacent lanes
+// reading one 128-byte line 20 -- and on misses the 64-byte-piece forms reach half the bandwidth of full lines (3.8 vs 7.6 TB/s).
+// The kernel is bound by that path (texture path busy 60 %, matrix pipe 41 %, profiles/r05_pmc_conv_x3_c64.md), so here
+//   * a 32-channel group of 32 rows is fetched by four buffer_load_dwordx4 ... lds, each = 8 rows x one whole 128-byte line (lane
+//     (r, c) = (lane >> 3, lane & 7) reads chunk c ^ s of row r), landing as a row-major 1-KiB block in LDS; the MFMA fragments
+//     (lane (i, q): chunks q and 4 + q of row i) are read back with ds_read_b128.  The XOR s = (slot & 3) + 4 (slot >> 3 & 1) on the
+//     chunk makes those reads bank-conflict-free without padding (the texture path merges the 8 lanes of a line in any order:
+//     20.3 cycles swizzled, 20.2 plain), so the block is exactly 4 KiB per wave and four workgroups still fit a CU at 4 column tiles;
+//   * one block per wave, single-buffered: the fragments of step n are in registers before the lines of step n + 1 are requested
+//     into the same block, and they have the whole split + MFMA phase to land -- the distance k_spconv_x3's register gathers have;
+//   * the 14-KiB neighbour table leaves LDS: a lane keeps the byte offsets of ITS four rows for the offset k being fetched (4
+//     VGPRs) and the raw map entries of the wave's next offset (4 VGPRs, one 16-byte load per offset: slot 4 r + j of the wave is
+//     row r of block j, so a lane's four entries are adjacent in the map); the prologue only derives the tiles' occupancy masks.
+// Same channel -> k mapping, same packed weights, same summation order as k_spconv_x3: bit-identical results
+// (tests/test_hip_ops.py::test_spconv_x3_full_line_gathers_are_bit_identical).  Dense maps (same-level, strided) with
+// c0 % 32 == 0; the 8-wide transposed and compact forms and the 48 / 80 / 112-channel inputs stay on k_spconv_x3.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+#ifndef X3F_NBR_X4
+#define X3F_NBR_X4 1  // a lane's four map entries by ONE 16-byte buffer load (4-byte aligned); 0 (A/B builds): four dword loads
+#endif
+template <int NTW, bool DS, int MODE>
+__global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
+                                                                        unsigned nbr_bytes) {
+  constexpr int T = 2, R = 32;
+  constexpr int PL = MODE == 1 ? 1 : 3;
+  constexpr int WB = NTW * PL * 64;                  // f32x4 per weight stage buffer
+  __shared__ f32x4 s_mem[2 * WB + X3_WPB * 256];     // [2][WB] weight stage | per wave 4 blocks x 1 KiB of gathered lines
+  f32x4* const s_wb = s_mem;
+  unsigned* const s_u = (unsigned*)(s_mem + WB);     // (the union of the waves' masks: aliases stage buffer 1, written after the 2nd barrier)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = lane & 15, q = lane >> 4;
+  const unsigned bid = pp_xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row_base = ((int64_t)bid * X3_WPB + wave) * R;
+  const int jt0 = blockIdx.y * NTW;
+  const unsigned row_bytes = (unsigned)a.c0 * 4u;
+  const bool m24 = (flags & 1u) != 0u;
+
+  // ---- prologue: per-tile occupancy masks (the map's sign bits; lanes 0 .. 31 offsets 0 .. 13, lanes 32 .. 63 offsets 14 .. 27)
+  unsigned m[T];
+  {
+    constexpr int NL = X3_MAXK / 2;
+    const int rr = lane & 31, kh = lane >> 5;
+    const bool rv = row_base + rr < a.n_out;
+    const int64_t slot = rv ? row_base + rr : a.n_out - 1;
+    unsigned ml = 0;
+#pragma unroll
+    for (int kk = 0; kk < NL; ++kk) {
+      const int k = kk + NL * kh;
+      const int kc = k < a.K ? k : a.K - 1;
+      const int v = a.nbr[(int64_t)kc * a.n_out + slot];
+      ml |= ((rv && k < a.K && v >= 0) ? 1u : 0u) << kk;
+    }
+    ml = x3_row_or16(ml);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+      m[tt] = (unsigned)__builtin_amdgcn_readlane((int)ml, tt * 16) | ((unsigned)__builtin_amdgcn_readlane((int)ml, 32 + tt * 16) << NL);
+  }
+  unsigned kmask = 0xFFFFFFFFu;
+  if (a.split > 1) {
+    const int k0 = (int)blockIdx.z * a.K / a.split, k1 = ((int)blockIdx.z + 1) * a.K / a.split;
+    kmask = (k1 >= 32 ? 0xFFFFFFFFu : (1u << k1) - 1u) & ~((1u << k0) - 1u);
+  }
+  unsigned Uw = 0;  // offsets this wave computes
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt) {
+    m[tt] = __builtin_amdgcn_readfirstlane(m[tt]) & kmask;
+    Uw |= m[tt];
+  }
+  if (lane == 0) s_u[wave] = Uw;
+  __syncthreads();
+  unsigned U = 0;
+#pragma unroll
+  for (int w = 0; w < X3_WPB; ++w) U |= s_u[w];
+  U = (unsigned)__builtin_amdgcn_readfirstlane((int)U);
+
+  f32x4 acc[T][NTW];
+#pragma unroll
+  for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+    for (int jt = 0; jt < NTW; ++jt) acc[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (U) {  // workgroup-uniform
+    const int S0 = a.c0 >> 4, S = (a.c0 + a.c1) >> 4, G = S >> 1;  // (c0 % 32 == 0 and c1 in {0, c0}: whole groups, none straddles the sources)
+    const unsigned x3_bytes = (unsigned)a.K * (unsigned)G * (unsigned)a.NT * 3072u;
+    const unsigned long long pw_ = (unsigned long long)a.wp + w_bytes + (MODE == 1 ? x3_bytes : 0u);
+    const unsigned wx_bytes = MODE == 1 ? x3_bytes / 3u : x3_bytes;
+    const u32x4_t dw_ = {(unsigned)pw_, (unsigned)(pw_ >> 32) & 0xFFFFu, wx_bytes, 0x00020000u};
+    const unsigned slice = (unsigned)a.NT * (PL * 1024u);  // weight bytes per (k, g)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned wb_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)&s_mem[0];
+    const unsigned rows_lds = wb_lds + 2u * WB * 16u + (unsigned)wave * 4096u;
+    constexpr int NPW = (PL * NTW + X3_WPB - 1) / X3_WPB;  // weight pieces per wave
+#define X3F_STAGE_W(KK, GG, BUF)                                                                             \
+  {                                                                                                          \
+    const unsigned so_ = ((unsigned)(KK) * (unsigned)G + (unsigned)(GG)) * slice + (unsigned)jt0 * (PL * 1024u); \
+    _Pragma("unroll") for (int jj = 0; jj < NPW; ++jj) {                                                     \
+      const int j_ = jj * X3_WPB + wave;                                                                     \
+      if ((jj + 1) * X3_WPB <= PL * NTW || j_ < PL * NTW) {                                                  \
+        const unsigned lds_ = wb_lds + (unsigned)(BUF) * (WB * 16u) + (unsigned)j_ * 1024u;                  \
+        const unsigned sj_ = so_ + (unsigned)j_ * 1024u;                                                     \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"             \
+                     ::"v"(lane16), "s"(lds_), "s"(dw_), "s"(sj_) : "memory", "m0");                         \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+    // gather role: lane (r, c) = (lane >> 3, lane & 7); block j, row r <-> slot 4 r + j of the wave
+    const unsigned gr = (unsigned)lane >> 3, gc = (unsigned)lane & 7u;
+    const unsigned sw4 = 4u * ((gr >> 1) & 1u);
+    unsigned cj16[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cj16[j] = ((gc ^ ((unsigned)j + sw4)) * 16u);
+    unsigned inv = 0;  // bit j: slot 4 r + j lies behind the last row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv |= (row_base + 4 * (int64_t)gr + j >= a.n_out ? 1u : 0u) << j;
+    const __amdgpu_buffer_rsrc_t rn_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.nbr, 0, (int)nbr_bytes, 0x00020000);
+    const unsigned nb_off = ((unsigned)row_base + 4u * gr) * 4u;  // (behind the map's end for a wave behind the last row: zeros, masked by inv)
+#if X3F_NBR_X4
+#define X3F_LOADN(KK) __builtin_bit_cast(i32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rn_, (int)nb_off, (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0))
+#else
+#define X3F_LOADN(KK)                                                                                                  \
+  (i32x4_t){(int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)nb_off, (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0),     \
+            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 4u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0), \
+            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 8u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0), \
+            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 12u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0)}
+#endif
+    // map entries -> byte offset of the row's line | chunk, all ones for a missing neighbour / a slot behind the last row
+#define X3F_CONV(V, OFF)                                                                                           \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+    const unsigned p_ = m24 ? __umul24((unsigned)(V)[j], row_bytes) + cj16[j] : (unsigned)(V)[j] * row_bytes + cj16[j]; \
+    OFF[j] = p_ | (unsigned)((V)[j] >> 31) | (unsigned)((int)(inv << (31 - j)) >> 31);                             \
+  }
+    // the four line loads of group GG (32 channels = 128 bytes per row) of the rows OFF points at
+#define X3F_GATHER(GG, OFF)                                                                                        \
+  {                                                                                                                \
+    const int sl_ = 2 * (GG);                                                                                      \
+    const float* src_ = sl_ < S0 ? a.in0 + sl_ * 16 : a.in1 + (sl_ - S0) * 16;                                     \
+    const unsigned long long ps_ = (unsigned long long)src_;                                                       \
+    const u32x4_t dr_ = {(unsigned)ps_, (unsigned)(ps_ >> 32) & 0xFFFFu, a_bytes, 0x00020000u};                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+      const unsigned lds_ = rows_lds + (unsigned)j * 1024u;                                                        \
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"                     \
+                   ::"v"(OFF[j]), "s"(lds_), "s"(dr_), "s"(0u) : "memory", "m0");                                  \
+    }                                                                                                              \
+  }
+#define X3F_ADV(KI, GI, UR, OK)           \
+  {                                       \
+    if (GI + 1 < G) {                     \
+      ++GI;                               \
+    } else if (UR) {                      \
+      KI = __builtin_ctz(UR);             \
+      UR &= UR - 1u;                      \
+      GI = 0;                             \
+    } else {                              \
+      OK = 0;                             \
+    }                                     \
+  }
+#define X3F_SIX(ACC, PLN, B0, B1, B2)  \
+  ACC = x3_mfma(B2, PLN.p0, ACC);      \
+  ACC = x3_mfma(B0, PLN.p2, ACC);      \
+  ACC = x3_mfma(B1, PLN.p1, ACC);      \
+  ACC = x3_mfma(B1, PLN.p0, ACC);      \
+  ACC = x3_mfma(B0, PLN.p1, ACC);      \
+  ACC = x3_mfma(B0, PLN.p0, ACC);
+    // fragment role: lane (i, q); row i of tile t = slot 16 t + i = block i & 3, row 4 t + (i >> 2); chunk C sits at C ^ s
+    const unsigned fs = ((unsigned)i & 3u) + 4u * (((unsigned)i >> 3) & 1u);
+    const f32x4* const rows = s_mem + 2 * WB + wave * 256;
+    const int fr0 = (i & 3) * 64 + (i >> 2) * 8 + (int)(((unsigned)q) ^ fs);        // f32x4 index of chunk q (tile 0)
+    const int fr1 = (i & 3) * 64 + (i >> 2) * 8 + (int)((4u + (unsigned)q) ^ fs);   // chunk 4 + q
+
+    // the wave's own offset sequence: kd = the offset whose row offsets are in offc, vn = raw entries of the wave's next one
+    unsigned Un = Uw;
+    int kd = -1;
+    unsigned offc[4] = {X3_MISSING, X3_MISSING, X3_MISSING, X3_MISSING};
+    i32x4_t vn = {-1, -1, -1, -1};
+    if (Un) {
+      const int ka = __builtin_ctz(Un);
+      Un &= Un - 1u;
+      const i32x4_t va = X3F_LOADN(ka);
+      if (Un) vn = X3F_LOADN(__builtin_ctz(Un));
+      X3F_CONV(va, offc);
+      kd = ka;
+    }
+    // invariant from here on: offc = row offsets of offset kd; vn = raw map entries of the wave's next offset, the lowest bit of Un
+#define X3F_NEED(KK)                                      \
+  if ((Uw >> (KK)) & 1u) {                                \
+    if ((KK) != kd) {                                     \
+      X3F_CONV(vn, offc);                                 \
+      kd = (KK);                                          \
+      Un &= Un - 1u;  /* vn's offset is consumed */       \
+      if (Un) vn = X3F_LOADN(__builtin_ctz(Un));          \
+    }                                                     \
+  }
+    int k0 = __builtin_ctz(U), g0 = 0, buf = 0;
+    unsigned Ur = U & (U - 1u);
+    int k1 = k0, g1 = g0, ok1 = 1;
+    X3F_ADV(k1, g1, Ur, ok1);
+    X3F_STAGE_W(k0, g0, 0);
+    if ((Uw >> k0) & 1u) X3F_GATHER(g0, offc);   // (k0 is the lowest offset of the union: if the wave has it, it is kd)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (;;) {
+      const unsigned act0 = (m[0] >> k0) & 1u, act1 = (m[1] >> k0) & 1u;
+      f32x4 AA[T][2];
+      if (act0) {
+        AA[0][0] = rows[fr0];
+        AA[0][1] = rows[fr1];
+      }
+      if (act1) {
+        AA[1][0] = rows[fr0 + 32];
+        AA[1][1] = rows[fr1 + 32];
+      }
+      // (the row offsets of the next step first: whatever the compiler waits for here landed before the last barrier -- behind the
+      // staging below it would wait for the weight pieces just requested)
+      if (ok1) X3F_NEED(k1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ok1) X3F_STAGE_W(k1, g1, buf ^ 1);
+      // the fragments are in registers before the next step's lines may overwrite the block
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ok1 && ((Uw >> k1) & 1u)) X3F_GATHER(g1, offc);
+      if (act0 | act1) {
+        X3Planes P0, P1;
+        if (act0) P0 = MODE == 1 ? x3_round(AA[0][0], AA[0][1]) : x3_split(AA[0][0], AA[0][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (act1) P1 = MODE == 1 ? x3_round(AA[1][0], AA[1][1]) : x3_split(AA[1][0], AA[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4* wb = s_wb + buf * WB;
+        bf16x8_t Bf[2][PL];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]);
+#pragma unroll
+        for (int jt = 0; jt < NTW; ++jt) {
+          if (jt + 1 < NTW) {
+#pragma unroll
+            for (int p = 0; p < PL; ++p) Bf[(jt + 1) & 1][p] = __builtin_bit_cast(bf16x8_t, wb[(jt + 1) * (PL * 64) + p * 64 + lane]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (MODE == 1) {
+            const bf16x8_t B0 = Bf[jt & 1][0];
+            if (act0) acc[0][jt] = x3_mfma(B0, P0.p0, acc[0][jt]);
+            if (act1) acc[1][jt] = x3_mfma(B0, P1.p0, acc[1][jt]);
+          } else {
+            const bf16x8_t B0 = Bf[jt & 1][0], B1 = Bf[jt & 1][PL > 1 ? 1 : 0], B2 = Bf[jt & 1][PL > 2 ? 2 : 0];
+            if (act0) {
+              X3F_SIX(acc[0][jt], P0, B0, B1, B2)
+            }
+            if (act1) {
+              X3F_SIX(acc[1][jt], P1, B0, B1, B2)
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (!ok1) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      k0 = k1;
+      g0 = g1;
+      X3F_ADV(k1, g1, Ur, ok1);
+      buf ^= 1;
+    }
+#undef X3F_SIX
+#undef X3F_ADV
+#undef X3F_GATHER
+#undef X3F_CONV
+#undef X3F_LOADN
+#undef X3F_NEED
+#undef X3F_STAGE_W
+  }
+
+  // ---- fused 1x1 shortcut and epilogue: as k_spconv_x3
+  f32x4 acc2[DS ? T : 1][DS ? NTW : 1];
+  if constexpr (DS) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) acc2[tt][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int S2 = a.ds_c >> 4;
+    const unsigned ds_row = (unsigned)a.ds_c * 4u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_in, 0, (int)((unsigned)a.n_out * ds_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_wp, 0, (int)((unsigned)S2 * (unsigned)a.NT * 1024u), 0x00020000);
+    unsigned o2[T];
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      const int64_t r = row_base + tt * 16 + i;
+      o2[tt] = r < a.n_out ? (unsigned)r * ds_row + (unsigned)q * 16u : X3_MISSING;
+    }
+    const unsigned lane16d = (unsigned)lane * 16u;
+#pragma unroll 1
+    for (int s2 = 0; s2 < S2; ++s2) {
+      f32x4 A2[T], B2[NTW];
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        A2[tt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)o2[tt], s2 * 64, 0));
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt)
+        B2[jt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdw, (int)(lane16d + jt * 1024u),
+                                                                                 (int)((unsigned)(s2 * a.NT + jt0) * 1024u), 0));
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          const s16x4 ah = pp_bf16x4(A2[tt]);
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+            acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pp_bf16x4(B2[jt]), ah, acc2[tt][jt], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+          for (int jt = 0; jt < NTW; ++jt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc2[tt][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(B2[jt][t], A2[tt][t], acc2[tt][jt], 0, 0, 0);
+      }
+    }
+  }
+  float* __restrict__ dst = a.split > 1 ? a.part + (int64_t)blockIdx.z * a.n_out * a.cout : a.out;
+#pragma unroll
+  for (int rt = 0; rt < T; ++rt) {
+    const int64_t slot = row_base + rt * 16 + i;
+    if (slot < a.n_out) {
+      const int64_t row = a.row_order ? (int64_t)a.row_order[slot] : slot;
+      const int64_t e0 = row * a.cout + (jt0 * 16 + q * 4);
+#pragma unroll
+      for (int jt = 0; jt < NTW; ++jt) {
+        const int col = (jt0 + jt) * 16 + q * 4;
+        if (jt0 + jt < a.NT && col < a.cout) {
+          f32x4 v = acc[rt][jt];
+          if (a.split > 1) {
+            *(f32x4*)(dst + e0 + jt * 16) = v;
+            continue;
+          }
+          if (a.scale) v *= *(const f32x4*)(a.scale + col);
+          if (a.shift) v += *(const f32x4*)(a.shift + col);
+          if (a.relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          if (a.residual) v += *(const f32x4*)(a.residual + e0 + jt * 16);
+          if constexpr (DS) {
+            f32x4 w = acc2[rt][jt];
+            if (a.ds_scale) w *= *(const f32x4*)(a.ds_scale + col);
+            if (a.ds_shift) w += *(const f32x4*)(a.ds_shift + col);
+            v += w;
+          }
+          *(f32x4*)(dst + e0 + jt * 16) = v;
+        }
+      }
+    }
+  }
+}
+
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
   if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
   if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 6 || n_in <= 0) return false;
@@ -595,10 +950,48 @@ bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
          (double)a.K * G * a.NT * 3072.0 < 4294967000.0 && (double)a.n_out * 32.0 < 4294967000.0;
 }
 
+// full-line gathers through LDS (k_spconv_x3f): dense maps over whole 32-channel groups.  PP_CONV_X3F=0 or
+// pp_spconv_x3_full_lines(0): never (A/B runs, the bit-identity test)
+static int g_x3f = -1;
+static bool x3f_ok(const SpconvArgs& a) {
+  if (g_x3f < 0) g_x3f = getenv("PP_CONV_X3F") ? (atoi(getenv("PP_CONV_X3F")) != 0) : 1;
+  return g_x3f && a.t8 == 0 && a.nbr && a.c0 % 32 == 0 && (a.c1 == 0 || a.c1 == a.c0) &&
+         (double)a.K * (double)a.n_out * 4.0 < 4294967000.0;
+}
+extern "C" int pp_spconv_x3_full_lines(int32_t mode) {
+  if (g_x3f < 0) g_x3f = getenv("PP_CONV_X3F") ? (atoi(getenv("PP_CONV_X3F")) != 0) : 1;
+  const int was = g_x3f;
+  if (mode == 0 || mode == 1) g_x3f = mode;
+  return was;
+}
+
 int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s) {
   const unsigned a_bytes = (unsigned)((uint64_t)n_in * a.c0 * 4u);
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
+  if (x3f_ok(a)) {
+    const unsigned nbr_bytes = (unsigned)((uint64_t)a.K * (uint64_t)a.n_out * 4u);
+    dim3 gridf(pp_blocks(a.n_out, 32 * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
+#define X3F_LAUNCH(N, DSV, MD) \
+  hipLaunchKernelGGL((k_spconv_x3f<N, DSV, MD>), gridf, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags, nbr_bytes)
+#define X3F_CASE(N)                                       \
+  case N:                                                 \
+    if (a.bf16) {                                         \
+      if (a.ds_in) X3F_LAUNCH(N, true, 1);                \
+      else X3F_LAUNCH(N, false, 1);                       \
+    } else {                                              \
+      if (a.ds_in) X3F_LAUNCH(N, true, 0);                \
+      else X3F_LAUNCH(N, false, 0);                       \
+    }                                                     \
+    break;
+    switch (ntw) {
+      X3F_CASE(2) X3F_CASE(3) X3F_CASE(4) X3F_CASE(5) X3F_CASE(6)
+      default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;
+    }
+#undef X3F_CASE
+#undef X3F_LAUNCH
+    return PP_OK;
+  }
   // (64 rows per wave -- T = 4 -- on the two-column-tile launches was built and measured in round 5 and lost: 32->32 at 5.4 M rows
   // 1630 us with 32 rows per wave, 1723 with 64; 64->32 2686 / 2953; 96->32 3798 / 4268, profiles/r05_ab_x3_two_tiles.txt: half the
   // staging and barriers per row do not pay for the third of the occupancy.  The instantiation was removed in round 6.)

@@ -290,6 +290,12 @@ def version():
     return _lib.load().pp_version().decode()
 
 
+def spconv_x3_full_lines(mode=-1):
+    """Switch the split-operand kernel's full-line row gathers (k_spconv_x3f) on (1) / off (0), or only ask (-1); returns the
+    setting before the call.  Results are bit-identical either way (tests/test_hip_ops.py)."""
+    return int(_lib.load().pp_spconv_x3_full_lines(int(mode)))
+
+
 def triad(a, b, c, s):
     lib = _lib.load()
     _lib.check(lib.pp_triad(_ptr(a), _ptr(b), _ptr(c), s, a.numel(), _stream()), "pp_triad")

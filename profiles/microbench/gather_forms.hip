@@ -28,14 +28,27 @@ __global__ __launch_bounds__(256) void k_gather(const float* src, unsigned bytes
   constexpr unsigned LB = FORM == 2 ? 4u : 16u;       // bytes per lane
   constexpr unsigned RB = 64u * LB / RPI;             // row bytes
   constexpr unsigned LPR = 64 / RPI;                  // lanes per row
-  const unsigned rsel = (unsigned)lane / LPR, inrow = ((unsigned)lane % LPR) * LB;
+  unsigned rsel = (unsigned)lane / LPR, inrow = ((unsigned)lane % LPR) * LB;
+  // FORM 3 / 4 (round 6): the SAME 8 rows x 128 bytes per instruction, but with the lanes of a row spread over the wave the way a
+  // register-level transpose into MFMA fragments wants them: row = lane & 7, 16-byte chunk = 4 (lane >> 3 & 1) + (lane >> 4)
+  // (FORM 3) or lane >> 3 (FORM 4).  Does the texture path still see 8 lines, or 64 pieces?
+  if constexpr (FORM == 3) { rsel = (unsigned)lane & 7u; inrow = ((((unsigned)lane >> 3) & 1u) * 4u + ((unsigned)lane >> 4)) * 16u; }
+  if constexpr (FORM == 4) { rsel = (unsigned)lane & 7u; inrow = ((unsigned)lane >> 3) * 16u; }
+  // FORM 5: 8 adjacent lanes = one 128-byte row, the 16-byte chunks XOR-swizzled inside the row (chunk = lane & 7 ^ s, s from the
+  // row and the instruction number: the bank-conflict-free LDS image of k_spconv_x3f).  FORM 6: the pattern k_spconv_x3 uses today
+  // (row = lane & 15, chunk = lane >> 4 of a 64-byte half row).  FORM 7: FORM 5 straight to LDS.
+  if constexpr (FORM == 5 || FORM == 7) { rsel = (unsigned)lane >> 3; inrow = 0u; }
+  if constexpr (FORM == 6) { rsel = (unsigned)lane & 15u; inrow = ((unsigned)lane >> 4) * 16u; }
   const unsigned wid = (blockIdx.x * 4 + wave) * 977u;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
     unsigned off[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) off[u] = ((((wid + (unsigned)(it * U + u) * 64u + rsel) * 2654435761u) >> 9) & (nrows - 1u)) * RB + inrow;  // nrows = 2^n
-    if constexpr (FORM == 0) {
+    for (int u = 0; u < U; ++u) {
+      off[u] = ((((wid + (unsigned)(it * U + u) * 64u + rsel) * 2654435761u) >> 9) & (nrows - 1u)) * RB + inrow;  // nrows = 2^n
+      if constexpr (FORM == 5 || FORM == 7) off[u] += ((((unsigned)lane & 7u) ^ ((unsigned)(u & 3) + 4u * (((unsigned)lane >> 4) & 1u))) * 16u);
+    }
+    if constexpr (FORM == 0 || (FORM >= 3 && FORM != 7)) {
       f32x4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off[u], 0, 0));
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void k_gather(const float* src, unsigned bytes
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-  if constexpr (FORM != 0) acc = lds[wave][0][lane];
+  if constexpr (FORM == 1 || FORM == 2 || FORM == 7) acc = lds[wave][0][lane];
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = 1.f;
 }
 
@@ -117,6 +130,11 @@ int main() {
   (void)tb;
   run<0, 16, 4>("x4 -> VGPR, 16 rows x  64 B (fragment)", src, bytes - 4096, out, e0, e1);
   run<0, 8, 4>("x4 -> VGPR,  8 rows x 128 B", src, bytes - 4096, out, e0, e1);
+  run<3, 8, 4>("x4 -> VGPR,  8 rows x 128 B, lanes q|g2|row", src, bytes - 4096, out, e0, e1);
+  run<4, 8, 4>("x4 -> VGPR,  8 rows x 128 B, lanes chunk|row", src, bytes - 4096, out, e0, e1);
+  run<5, 8, 4>("x4 -> VGPR,  8 rows x 128 B, chunks xor-swizzled", src, bytes - 4096, out, e0, e1);
+  run<7, 8, 4>("x4 -> LDS,   8 rows x 128 B, chunks xor-swizzled", src, bytes - 4096, out, e0, e1);
+  run<6, 16, 4>("x4 -> VGPR, 16 rows x 64 B, lanes chunk|row (x3 today)", src, bytes - 4096, out, e0, e1);
   run<0, 4, 4>("x4 -> VGPR,  4 rows x 256 B", src, bytes - 4096, out, e0, e1);
   run<0, 2, 4>("x4 -> VGPR,  2 rows x 512 B", src, bytes - 4096, out, e0, e1);
   run<1, 16, 4>("x4 -> LDS,  16 rows x  64 B", src, bytes - 4096, out, e0, e1);

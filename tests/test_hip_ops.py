@@ -1187,6 +1187,67 @@ def test_spconv_x3_default_wide_layers(ops, oracle, kind, c0, c1, cout):
     np.testing.assert_allclose(got_bf.cpu().numpy(), want_bf, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want_bf).max())))
 
 
+@pytest.mark.parametrize("kind,c0,c1,cout", [("same", 64, 0, 64), ("same", 32, 0, 32), ("same", 96, 0, 48), ("same", 64, 64, 32),
+                                             ("strided", 32, 0, 96), ("transposed", 64, 64, 80), ("dust", 128, 0, 64),
+                                             ("same", 160, 0, 96)])
+def test_spconv_x3_full_line_gathers_are_bit_identical(ops, oracle, kind, c0, c1, cout):
+    """k_spconv_x3f (rows gathered as whole 128-byte lines straight into LDS, fragments read back from LDS, no neighbour table)
+    against k_spconv_x3 (register gathers in fragment shape): same packed weights, same summation order -> the same bits, on dense
+    maps of every kind, two sources, odd row counts (the 16-byte map loads are then only 4-byte aligned; the last workgroup has
+    empty slots and whole empty waves), the fused shortcut, a permuted output order, split-K and bfloat16 compute; and both against
+    the oracle."""
+    rng = np.random.default_rng(23)
+    fine = surface(rng, n=26000, n_batch=3, extent=120)
+    if kind == "dust":
+        fine = fine[np.sort(rng.choice(len(fine), int(0.42 * len(fine)), replace=False))]
+    fine = fine[: len(fine) - (len(fine) % 128) - 37]  # n_out % 128 = 91: a ragged last workgroup, one wave without rows
+    coarse, _ = oracle.stride_coords(fine, 2)
+    out_c, in_c, sign = {"same": (fine, fine, 1), "dust": (fine, fine, 1), "strided": (coarse, fine, 1),
+                         "transposed": (fine, coarse, -1)}[kind]
+    nbr = oracle.kernel_map(out_c, in_c, 3, 1, sign)
+    n_in, n_out = len(in_c), len(out_c)
+    x0 = (rng.normal(size=(n_in, c0)) * np.exp(rng.normal(size=(n_in, 1)))).astype(np.float32)
+    x1 = rng.normal(size=(n_in, c1)).astype(np.float32) if c1 else None
+    W = (rng.normal(size=(27, c0 + c1, cout)) * 0.1).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(n_out, cout)).astype(np.float32)
+    packed = ops.pack_weight(dev(W))
+    kw = dict(in1=None if x1 is None else dev(x1), scale=dev(sc), shift=dev(sh), relu=True, residual=dev(res))
+    want = oracle.spconv_fwd(x0, W, nbr, n_out, in1=x1, scale=sc, shift=sh, relu=True, residual=res)
+    perm = rng.permutation(n_out).astype(np.int32)
+    nbr_p = np.ascontiguousarray(nbr[:, perm])
+
+    def run_all():
+        out = [ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, **kw),
+               ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, bf16=True, **kw),
+               ops.spconv_fwd(dev(x0), packed, dev(nbr_p), n_out, cout, 27, row_order=dev(perm), **kw)]
+        if 2 * n_out * cout * 4 <= ops.CONV_SCRATCH_BYTES:
+            out.append(ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(0, 0, 2), **kw))
+        if kind in ("same", "dust") and c1 == 0 and cout <= 64:
+            xs = rng2.normal(size=(n_out, 32)).astype(np.float32)
+            W1 = (rng2.normal(size=(1, 32, cout)) * 0.1).astype(np.float32)
+            out.append(ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, scale=dev(sc), shift=dev(sh), relu=True,
+                                      shortcut=(dev(xs), ops.pack_weight(dev(W1)), dev(sc), dev(sh))))
+        return out
+
+    was = ops.spconv_x3_full_lines(1)
+    try:
+        rng2 = np.random.default_rng(5)
+        lines = run_all()
+        ops.spconv_x3_full_lines(0)
+        rng2 = np.random.default_rng(5)
+        frags = run_all()
+    finally:
+        ops.spconv_x3_full_lines(was)
+    f32 = ops.spconv_fwd(dev(x0), packed, dev(nbr), n_out, cout, 27, variant=(32, 1, 1), **kw)
+    assert not torch.equal(lines[0], f32), "the default path did not take the split-bf16 kernel"
+    np.testing.assert_allclose(lines[0].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    assert torch.equal(lines[2], lines[0])  # a row's bits do not depend on its workgroup
+    for a_, b_ in zip(lines, frags):  # (a launch small enough for split-K declines the fused shortcut: None both times)
+        assert (a_ is None) == (b_ is None) and (a_ is None or torch.equal(a_, b_))
+
+
 def test_spconv_x3_fused_shortcut_and_row_subsets(ops, oracle):
     """the fused 1x1 shortcut on the split-bf16 kernel == its two launches bit for bit, and a row's result does not depend on
     which other rows share its workgroup (the workgroup walks the union of its rows' offsets in lockstep; a row's own sum
