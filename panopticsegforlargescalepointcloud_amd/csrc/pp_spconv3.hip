@@ -609,11 +609,8 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 // (tests/test_hip_ops.py::test_spconv_x3_full_line_gathers_are_bit_identical).  Dense maps (same-level, strided) with
 // c0 % 32 == 0; the 8-wide transposed and compact forms and the 48 / 80 / 112-channel inputs stay on k_spconv_x3.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
-#ifndef X3F_NBR_X4
-#define X3F_NBR_X4 1  // a lane's four map entries by ONE 16-byte buffer load (4-byte aligned); 0 (A/B builds): four dword loads
-#endif
 template <int NTW, bool DS, int MODE>
-__global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
+__global__ __launch_bounds__(64 * X3_WPB, (NTW == 2 && !DS) ? 5 : X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
                                                                         unsigned nbr_bytes) {
   constexpr int T = 2, R = 32;
   constexpr int PL = MODE == 1 ? 1 : 3;
@@ -630,9 +627,32 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs
   const unsigned row_bytes = (unsigned)a.c0 * 4u;
   const bool m24 = (flags & 1u) != 0u;
 
-  // ---- prologue: per-tile occupancy masks (the map's sign bits; lanes 0 .. 31 offsets 0 .. 13, lanes 32 .. 63 offsets 14 .. 27)
+  // ---- prologue: per-tile occupancy masks.  Dense map: its sign bits (lanes 0 .. 31 offsets 0 .. 13, lanes 32 .. 63 offsets 14 .. 27).
+  // 8-wide transposed map: entry j of a fine row of parity class cls is offset k(cls, j) (as in k_spconv_x3's prologue)
   unsigned m[T];
-  {
+  if (a.t8) {
+    const int rr = lane & 31;
+    const bool rv = row_base + rr < a.n_out;
+    const int64_t slot = rv ? row_base + rr : a.n_out - 1;
+    int e8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e8[j] = a.nbr[(int64_t)j * a.n_out + slot];
+    unsigned cls = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cls |= e8[j] >= 0 ? (unsigned)e8[j] >> 28 : 0u;
+    unsigned mk = 0;
+    const unsigned kx = (cls & 1u) ? 0u : 1u, ky = (cls & 2u) ? 0u : 3u, kz = (cls & 4u) ? 0u : 9u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = rv && (((unsigned)j & ~cls) == 0u) && e8[j] >= 0;
+      const unsigned k = kx + ((j & 1) ? 2u : 0u) * (cls & 1u) + ky + ((j & 2) ? 6u : 0u) * ((cls >> 1) & 1u) + kz +
+                         ((j & 4) ? 18u : 0u) * ((cls >> 2) & 1u);
+      mk |= ok ? 1u << k : 0u;
+    }
+    mk = x3_row_or16(mk);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) m[tt] = (unsigned)__builtin_amdgcn_readlane((int)mk, tt * 16);
+  } else {
     constexpr int NL = X3_MAXK / 2;
     const int rr = lane & 31, kh = lane >> 5;
     const bool rv = row_base + rr < a.n_out;
@@ -698,31 +718,37 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs
       }                                                                                                      \
     }                                                                                                        \
   }
-    // gather role: lane (r, c) = (lane >> 3, lane & 7); block j, row r <-> slot 4 r + j of the wave
+    // gather role: lane (r, c) = (lane >> 3, lane & 7); block j, row r <-> slot 4 r + j of the wave; chunk c ^ (j + 4 (r >> 1 & 1))
     const unsigned gr = (unsigned)lane >> 3, gc = (unsigned)lane & 7u;
-    const unsigned sw4 = 4u * ((gr >> 1) & 1u);
-    unsigned cj16[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cj16[j] = ((gc ^ ((unsigned)j + sw4)) * 16u);
-    unsigned inv = 0;  // bit j: slot 4 r + j lies behind the last row
-#pragma unroll
-    for (int j = 0; j < 4; ++j) inv |= (row_base + 4 * (int64_t)gr + j >= a.n_out ? 1u : 0u) << j;
+    const unsigned x16 = (gc ^ (4u * ((gr >> 1) & 1u))) * 16u;
+    // map role: lane s (and s + 32) owns slot s of the wave: ONE coalesced 4-byte load per offset, the entry turned into the byte
+    // offset of the row (all ones: no neighbour / a slot behind the last row / on an 8-wide map a row of another parity class),
+    // then four ds_bpermute_b32 hand lane (r, c) the offsets of slots 4 r .. 4 r + 3 (no LDS memory, no texture-path pieces)
+    const unsigned tail1 = (row_base + (lane & 31) >= a.n_out) ? 0xFFFFFFFFu : 0u;
     const __amdgpu_buffer_rsrc_t rn_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.nbr, 0, (int)nbr_bytes, 0x00020000);
-    const unsigned nb_off = ((unsigned)row_base + 4u * gr) * 4u;  // (behind the map's end for a wave behind the last row: zeros, masked by inv)
-#if X3F_NBR_X4
-#define X3F_LOADN(KK) __builtin_bit_cast(i32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rn_, (int)nb_off, (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0))
-#else
-#define X3F_LOADN(KK)                                                                                                  \
-  (i32x4_t){(int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)nb_off, (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0),     \
-            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 4u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0), \
-            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 8u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0), \
-            (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)(nb_off + 12u), (int)((unsigned)(KK) * (unsigned)a.n_out * 4u), 0)}
-#endif
-    // map entries -> byte offset of the row's line | chunk, all ones for a missing neighbour / a slot behind the last row
-#define X3F_CONV(V, OFF)                                                                                           \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
-    const unsigned p_ = m24 ? __umul24((unsigned)(V)[j], row_bytes) + cj16[j] : (unsigned)(V)[j] * row_bytes + cj16[j]; \
-    OFF[j] = p_ | (unsigned)((V)[j] >> 31) | (unsigned)((int)(inv << (31 - j)) >> 31);                             \
+    const unsigned nb_off = ((unsigned)row_base + ((unsigned)lane & 31u)) * 4u;
+    const int bp_addr = (int)(gr * 16u);  // byte address of lane 4 r for ds_bpermute_b32 (+ 4 j in the offset field)
+    const bool t8 = a.t8 != 0;
+    // 8-wide transposed map: offset k belongs to ONE parity class (bit a set <-> component a of k is not the centre) and to
+    // entry j8 = (component == +1) per axis; a row's entries carry its class in bits 28 .. 30
+#define X3F_K8(KK, J8, CLS)                                                       \
+  const unsigned kx_ = (unsigned)(KK) % 3u, ky_ = ((unsigned)(KK) / 3u) % 3u, kz_ = (unsigned)(KK) / 9u; \
+  const unsigned CLS = (kx_ != 1u ? 1u : 0u) | (ky_ != 1u ? 2u : 0u) | (kz_ != 1u ? 4u : 0u);             \
+  const unsigned J8 = (kx_ == 2u ? 1u : 0u) | (ky_ == 2u ? 2u : 0u) | (kz_ == 2u ? 4u : 0u);
+#define X3F_LOADN(KK, E)                                                                                     \
+  {                                                                                                          \
+    X3F_K8(KK, j8_, cls_)                                                                                    \
+    (void)cls_;                                                                                              \
+    E = (int)__builtin_amdgcn_raw_buffer_load_b32(rn_, (int)nb_off, (int)((t8 ? j8_ : (unsigned)(KK)) * (unsigned)a.n_out * 4u), 0); \
+  }
+    // raw entry of offset KK -> byte offset of the row, or all ones
+#define X3F_CONV1(KK, E, O)                                                                                  \
+  {                                                                                                          \
+    X3F_K8(KK, j8_, cls_)                                                                                    \
+    (void)j8_;                                                                                               \
+    const unsigned rw_ = t8 ? (unsigned)(E) & PP_ROW_MASK : (unsigned)(E);                                  \
+    const unsigned bad_ = (unsigned)((E) >> 31) | tail1 | ((t8 && (((unsigned)(E) >> 28) & 7u) != cls_) ? 0xFFFFFFFFu : 0u); \
+    O = (m24 ? __umul24(rw_, row_bytes) : rw_ * row_bytes) | bad_;                                           \
   }
     // the four line loads of group GG (32 channels = 128 bytes per row) of the rows OFF points at
 #define X3F_GATHER(GG, OFF)                                                                                        \
@@ -762,29 +788,29 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs
     const int fr0 = (i & 3) * 64 + (i >> 2) * 8 + (int)(((unsigned)q) ^ fs);        // f32x4 index of chunk q (tile 0)
     const int fr1 = (i & 3) * 64 + (i >> 2) * 8 + (int)((4u + (unsigned)q) ^ fs);   // chunk 4 + q
 
-    // the wave's own offset sequence: kd = the offset whose row offsets are in offc, vn = raw entries of the wave's next one
+    // the wave's own offset sequence: kd = the offset whose row offsets are in offc; en = raw map entries (slot = lane & 31) of the
+    // wave's next offset kn = the lowest bit of Un, requested when kd was taken up (a whole step or more before they are used)
+#define X3F_PERM(O, OFF)                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
+      OFF[j] = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr + 4 * j, (int)(O));
+#define X3F_FINISH(OFF)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) OFF[j] = (OFF[j] | x16) ^ ((unsigned)j << 4);  /* (all ones stay >= 2^32 - 64: out of range) */
     unsigned Un = Uw;
     int kd = -1;
     unsigned offc[4] = {X3_MISSING, X3_MISSING, X3_MISSING, X3_MISSING};
-    i32x4_t vn = {-1, -1, -1, -1};
+    int en = -1;
     if (Un) {
       const int ka = __builtin_ctz(Un);
       Un &= Un - 1u;
-      const i32x4_t va = X3F_LOADN(ka);
-      if (Un) vn = X3F_LOADN(__builtin_ctz(Un));
-      X3F_CONV(va, offc);
+      int ea;
+      X3F_LOADN(ka, ea);
+      if (Un) X3F_LOADN(__builtin_ctz(Un), en);
+      unsigned oa;
+      X3F_CONV1(ka, ea, oa);
+      X3F_PERM(oa, offc);
+      X3F_FINISH(offc);
       kd = ka;
     }
-    // invariant from here on: offc = row offsets of offset kd; vn = raw map entries of the wave's next offset, the lowest bit of Un
-#define X3F_NEED(KK)                                      \
-  if ((Uw >> (KK)) & 1u) {                                \
-    if ((KK) != kd) {                                     \
-      X3F_CONV(vn, offc);                                 \
-      kd = (KK);                                          \
-      Un &= Un - 1u;  /* vn's offset is consumed */       \
-      if (Un) vn = X3F_LOADN(__builtin_ctz(Un));          \
-    }                                                     \
-  }
     int k0 = __builtin_ctz(U), g0 = 0, buf = 0;
     unsigned Ur = U & (U - 1u);
     int k1 = k0, g1 = g0, ok1 = 1;
@@ -804,13 +830,23 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs
         AA[1][0] = rows[fr0 + 32];
         AA[1][1] = rows[fr1 + 32];
       }
-      // (the row offsets of the next step first: whatever the compiler waits for here landed before the last barrier -- behind the
-      // staging below it would wait for the weight pieces just requested)
-      if (ok1) X3F_NEED(k1);
+      // the next step's rows belong to another offset: its entries (requested a step or more ago: whatever the compiler waits for
+      // here landed before the last barrier; behind the staging below it would wait for the weight pieces just requested) become
+      // byte offsets and cross the lanes beside the fragment reads; the entries of the wave's offset after that are requested
+      const bool turn = ok1 && ((Uw >> k1) & 1u) && k1 != kd;
+      if (turn) {
+        unsigned on;
+        X3F_CONV1(k1, en, on);
+        X3F_PERM(on, offc);
+        kd = k1;
+        Un &= Un - 1u;
+        if (Un) X3F_LOADN(__builtin_ctz(Un), en);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (ok1) X3F_STAGE_W(k1, g1, buf ^ 1);
       // the fragments are in registers before the next step's lines may overwrite the block
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (turn) X3F_FINISH(offc);
       if (ok1 && ((Uw >> k1) & 1u)) X3F_GATHER(g1, offc);
       if (act0 | act1) {
         X3Planes P0, P1;
@@ -856,9 +892,11 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3f(SpconvArgs
 #undef X3F_SIX
 #undef X3F_ADV
 #undef X3F_GATHER
-#undef X3F_CONV
+#undef X3F_CONV1
 #undef X3F_LOADN
-#undef X3F_NEED
+#undef X3F_K8
+#undef X3F_PERM
+#undef X3F_FINISH
 #undef X3F_STAGE_W
   }
 
@@ -955,7 +993,7 @@ bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
 static int g_x3f = -1;
 static bool x3f_ok(const SpconvArgs& a) {
   if (g_x3f < 0) g_x3f = getenv("PP_CONV_X3F") ? (atoi(getenv("PP_CONV_X3F")) != 0) : 1;
-  return g_x3f && a.t8 == 0 && a.nbr && a.c0 % 32 == 0 && (a.c1 == 0 || a.c1 == a.c0) &&
+  return g_x3f && (a.t8 == 0 || a.t8 == 1) && a.nbr && a.c0 % 32 == 0 && (a.c1 == 0 || a.c1 == a.c0) &&
          (double)a.K * (double)a.n_out * 4.0 < 4294967000.0;
 }
 extern "C" int pp_spconv_x3_full_lines(int32_t mode) {
@@ -970,7 +1008,7 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
   const unsigned w_bytes = (unsigned)((uint64_t)a.K * ((a.c0 + a.c1) / 16) * a.NT * 1024u);
   const unsigned flags = (n_in < (int64_t(1) << 24) ? 1u : 0u);
   if (x3f_ok(a)) {
-    const unsigned nbr_bytes = (unsigned)((uint64_t)a.K * (uint64_t)a.n_out * 4u);
+    const unsigned nbr_bytes = (unsigned)((uint64_t)(a.t8 ? 8 : a.K) * (uint64_t)a.n_out * 4u);
     dim3 gridf(pp_blocks(a.n_out, 32 * X3_WPB), groups, (unsigned)(a.split > 1 ? a.split : 1));
 #define X3F_LAUNCH(N, DSV, MD) \
   hipLaunchKernelGGL((k_spconv_x3f<N, DSV, MD>), gridf, dim3(64 * X3_WPB), 0, s, a, a_bytes, w_bytes, flags, nbr_bytes)

@@ -1496,6 +1496,13 @@ def test_transposed_map_8_wide_equals_dense(ops, oracle):
             want = ops.spconv_fwd(x, pk, dense_s, n, cout, 27, scale=sc, shift=sh, relu=True, residual=res, row_order=order, bf16=bf16)
             got = ops.spconv_fwd(x, pk, m8s, n, cout, 27, scale=sc, shift=sh, relu=True, residual=res, row_order=enc, bf16=bf16)
             assert torch.equal(got, want), (cin, cout, bf16, slot_ordered)
+            # ... and to the register-gather kernel's (k_spconv_x3 instead of k_spconv_x3f where the shape takes the split kernel)
+            was = ops.spconv_x3_full_lines(0)
+            try:
+                frag = ops.spconv_fwd(x, pk, m8s, n, cout, 27, scale=sc, shift=sh, relu=True, residual=res, row_order=enc, bf16=bf16)
+            finally:
+                ops.spconv_x3_full_lines(was)
+            assert torch.equal(got, frag), (cin, cout, bf16, slot_ordered)
     # the oracle's transposed map (fine rows probing the coarse level with mirrored offsets) names the same pairs
     want = oracle.kernel_map(cs.cpu().numpy(), cc.cpu().numpy(), 3, 1, -1)
     assert np.array_equal(ops.map8_to_dense(m8).cpu().numpy(), want)
