@@ -324,7 +324,7 @@ extern "C" int pp_spconv_set_scratch(void* scratch, size_t bytes) {
 }
 
 // Which launches take the split-operand kernel k_spconv_x3 (pp_spconv3.hip), and with how many column tiles per wave: 0 = none
-// (the fp32-MFMA kernel k_spconv_fwd3 runs the launch).  The rule: cin % 16 == 0, 2 <= K <= 27, >= PP_CONV_X3_MIN_NTW (default 2)
+// (the fp32-MFMA kernel k_spconv_fwd3 runs the launch).  The rule: cin % 16 == 0, 2 <= K <= 27, >= PP_CONV_X3_MIN_NTW (default 1; one tile only where k_spconv_x3f serves the shape)
 // sixteen-column tiles per wave and -- on launches with <= 2 column tiles -- >= 32 input channels.  PP_CONV_X3=0: never.
 //   column tiles per wave: 4, or up to 6 where that saves a column group (80 / 96 / 160 / 192 output channels: every group
 //   gathers AND splits the rows again) -- 96->96 transposed onto 5.4 M rows 2942 -> 2348 us, 96->96 at 2.4 M rows 5566 -> 4662,
@@ -337,9 +337,12 @@ extern "C" int pp_spconv_set_scratch(void* scratch, size_t bytes) {
 //   profiles/r05_ab_x3_two_tiles.txt); one column tile (the 16-channel layers) stays on the fp32 MFMAs: texture-path bound
 //   (... with >= 32 input channels: a 16-channel input is ONE half-empty group per offset -- 16->32 at 5.1 M rows 837 us on the
 //   fp32 MFMAs, 1162 on the split kernel; one column tile, the 16-channel outputs: 16->16 1018 / 1601 us, 64->16 and 32->16 even)
+//   round 6: with the rows gathered as full lines through LDS (k_spconv_x3f; whole 32-channel groups on dense / 8-wide maps) ONE
+//   column tile wins as well -- 64->16 at 10.3 M rows 3434 -> 3002 us, 32->16 1722 -> 1565, 64->16 at 5.4 M rows 2190 -> 1765
+//   (profiles/r06_x3f_ntw1.txt) -- so PP_CONV_X3_MIN_NTW defaults to 1; pp_spconv_x3_ok admits one tile only on that kernel
 static int x3_column_tiles(const SpconvArgs& a, int64_t n_in, bool shortcut) {
   static const int env_x3 = getenv("PP_CONV_X3") ? atoi(getenv("PP_CONV_X3")) : 1;
-  static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 2;
+  static const int env_x3_ntw = getenv("PP_CONV_X3_MIN_NTW") ? atoi(getenv("PP_CONV_X3_MIN_NTW")) : 1;
   static const int env_x3_max = getenv("PP_CONV_X3_MAX_NTW") ? atoi(getenv("PP_CONV_X3_MAX_NTW")) : 0;
   if (!env_x3 || (a.c0 + a.c1) % 16 != 0) return 0;
   const int mx = shortcut ? 4 : (env_x3_max >= 4 && env_x3_max <= 6 ? env_x3_max : (a.n_out >= 400000 ? 6 : 5));

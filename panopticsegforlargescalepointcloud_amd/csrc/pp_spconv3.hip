@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 // c0 % 32 == 0; the 8-wide transposed and compact forms and the 48 / 80 / 112-channel inputs stay on k_spconv_x3.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 template <int NTW, bool DS, int MODE>
-__global__ __launch_bounds__(64 * X3_WPB, (NTW == 2 && !DS) ? 5 : X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
+__global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
                                                                         unsigned nbr_bytes) {
   constexpr int T = 2, R = 32;
   constexpr int PL = MODE == 1 ? 1 : 3;
@@ -980,9 +980,10 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW == 2 && !DS) ? 5 : X3_WAVES) void
   }
 }
 
+static bool x3f_ok(const SpconvArgs& a);
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw) {
   if (a.c0 % 16 != 0 || (a.c1 != 0 && a.c1 != a.c0)) return false;
-  if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < 2 || ntw > 6 || n_in <= 0) return false;
+  if ((a.cout & 3) != 0 || a.K > 27 || a.K < 2 || ntw < (x3f_ok(a) ? 1 : 2) || ntw > 6 || n_in <= 0) return false;  // (one column tile: k_spconv_x3f only)
   const double S = (a.c0 + a.c1) / 16, G = ((a.c0 + a.c1) / 16 + 1) / 2;
   return (double)n_in * a.c0 * 4.0 < 4294967000.0 && (double)a.K * S * a.NT * 1024.0 < 4294967000.0 &&
          (double)a.K * G * a.NT * 3072.0 < 4294967000.0 && (double)a.n_out * 32.0 < 4294967000.0;
@@ -1023,7 +1024,7 @@ int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned gro
     }                                                     \
     break;
     switch (ntw) {
-      X3F_CASE(2) X3F_CASE(3) X3F_CASE(4) X3F_CASE(5) X3F_CASE(6)
+      X3F_CASE(1) X3F_CASE(2) X3F_CASE(3) X3F_CASE(4) X3F_CASE(5) X3F_CASE(6)
       default: pp_set_error("pp_spconv_x3: ntw %d out of range", ntw); return PP_ERR_INVALID;
     }
 #undef X3F_CASE
