@@ -702,11 +702,14 @@ def main():
                 pass
         roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)
         x3_on = os.environ.get("PP_CONV_X3", "1") != "0"
-        roof.update({"kernel": "k_spconv_fwd3 + k_spconv_x3 (pp_spconv_fwd)" if x3_on else "k_spconv_fwd3 (pp_spconv_fwd)",
-                     # fp32 operands and fp32-accurate results everywhere; which matrix pipe multiplies them (DESIGN.md 4.34)
-                     "mfma_path": ("layers with >= 2 column tiles per wave (>= 32 output channels; on two tiles >= 32 input channels): v_mfma_f32_16x16x32_bf16 on operands split exactly into "
-                                   "three bfloat16 terms, six products, fp32 accumulation (k_spconv_x3); the others: "
-                                   "v_mfma_f32_16x16x4_f32.  peak = the fp32 MFMA peak either way") if x3_on else
+        roof.update({"kernel": "k_spconv_x3f + k_spconv_x3 + k_spconv_fwd3 (pp_spconv_fwd)" if x3_on else "k_spconv_fwd3 (pp_spconv_fwd)",
+                     # fp32 operands and fp32-accurate results everywhere; which matrix pipe multiplies them (DESIGN.md 4.1)
+                     "mfma_path": ("family x3 = layers with >= 32 input channels (and the 16 -> >= 48 ones): v_mfma_f32_16x16x32_bf16 on "
+                                   "operands split exactly into three bfloat16 terms, six products, fp32 accumulation -- k_spconv_x3f "
+                                   "(rows gathered as full 128-byte lines through LDS) where the input is whole 32-channel groups on a "
+                                   "dense or 8-wide map, k_spconv_x3 (register gathers) on 48 / 80 / 112-channel inputs; family fwd3 = "
+                                   "the 16-channel-input layers: v_mfma_f32_16x16x4_f32.  peak = the fp32 MFMA peak either way "
+                                   "(frac); frac_pipe = against the pipe each family runs on") if x3_on else
                                   "v_mfma_f32_16x16x4_f32 on every layer (PP_CONV_X3=0)", "launches_per_step": prof["launches"] // max(event_steps, 1), "event_steps": event_steps,
                      "avg_launch_us": 1e3 * prof["ms"] / max(prof["launches"], 1),
                      "alg_GB_per_step": prof["bytes"] / event_steps / 1e9, "alg_TFLOP_per_step": prof["flops"] / event_steps / 1e12,

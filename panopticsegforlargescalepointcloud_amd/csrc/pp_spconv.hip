@@ -362,6 +362,7 @@ extern "C" int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int
   SpconvArgs a;
   memset(&a, 0, sizeof(a));
   a.n_out = n_out; a.c0 = c0; a.c1 = c1; a.K = K; a.cout = cout; a.NT = pp_nt(cout);
+  a.nbr = (const int32_t*)(uintptr_t)64;  // (a map is given: K >= 2 launches always have one; the full-line form of the split kernel asks)
   const bool mode16 = ((c0 + c1) % 16 == 0) && c0 % 16 == 0;
   if (!mode16 || K > 28 || !pp_spconv_fwd3_ok(a, n_in)) return 0;
   return x3_column_tiles(a, n_in, shortcut != 0) ? 1 : 0;
