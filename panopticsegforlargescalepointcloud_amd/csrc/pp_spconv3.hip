@@ -609,6 +609,12 @@ __global__ __launch_bounds__(64 * X3_WPB, X3_WAVES) void k_spconv_x3(SpconvArgs 
 // (tests/test_hip_ops.py::test_spconv_x3_full_line_gathers_are_bit_identical).  Dense maps (same-level, strided) with
 // c0 % 32 == 0; the 8-wide transposed and compact forms and the 48 / 80 / 112-channel inputs stay on k_spconv_x3.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// X3F_ABLATE (profiling builds only, profiles/build_x3_variants.sh; results are wrong by construction): 1 = no line gathers,
+// 2 = no operand split (X3_ABLATE=2 shares the switch), 3 = no MFMAs (X3_ABLATE=3), 4 = no weight staging, 5 = no per-step barrier,
+// 6 = no fragment reads from LDS, 7 = no offset pipeline (map loads + ds_bpermute)
+#ifndef X3F_ABLATE
+#define X3F_ABLATE 0
+#endif
 template <int NTW, bool DS, int MODE>
 __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void k_spconv_x3f(SpconvArgs a, unsigned a_bytes, unsigned w_bytes, unsigned flags,
                                                                         unsigned nbr_bytes) {
@@ -721,13 +727,14 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
     // gather role: lane (r, c) = (lane >> 3, lane & 7); block j, row r <-> slot 4 r + j of the wave; chunk c ^ (j + 4 (r >> 1 & 1))
     const unsigned gr = (unsigned)lane >> 3, gc = (unsigned)lane & 7u;
     const unsigned x16 = (gc ^ (4u * ((gr >> 1) & 1u))) * 16u;
-    // map role: lane s (and s + 32) owns slot s of the wave: ONE coalesced 4-byte load per offset, the entry turned into the byte
-    // offset of the row (all ones: no neighbour / a slot behind the last row / on an 8-wide map a row of another parity class),
-    // then four ds_bpermute_b32 hand lane (r, c) the offsets of slots 4 r .. 4 r + 3 (no LDS memory, no texture-path pieces)
-    const unsigned tail1 = (row_base + (lane & 31) >= a.n_out) ? 0xFFFFFFFFu : 0u;
+    // map role: lane (r, c) owns slot 4 r + (c & 3) of the wave (every slot twice): ONE 4-byte load per offset, contiguous inside the
+    // lane quads; the entry is turned into the byte offset of the row (all ones: no neighbour / a slot behind the last row / on an
+    // 8-wide map a row of another parity class), and four quad broadcasts (DPP quad_perm: plain vector-ALU moves, no LDS crossbar, no
+    // wait) hand lane (r, c) the offsets of slots 4 r .. 4 r + 3
+    const unsigned mslot = 4u * gr + (gc & 3u);
+    const unsigned tail1 = (row_base + (int64_t)mslot >= a.n_out) ? 0xFFFFFFFFu : 0u;
     const __amdgpu_buffer_rsrc_t rn_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.nbr, 0, (int)nbr_bytes, 0x00020000);
-    const unsigned nb_off = ((unsigned)row_base + ((unsigned)lane & 31u)) * 4u;
-    const int bp_addr = (int)(gr * 16u);  // byte address of lane 4 r for ds_bpermute_b32 (+ 4 j in the offset field)
+    const unsigned nb_off = ((unsigned)row_base + mslot) * 4u;
     const bool t8 = a.t8 != 0;
     // 8-wide transposed map: offset k belongs to ONE parity class (bit a set <-> component a of k is not the centre) and to
     // entry j8 = (component == +1) per axis; a row's entries carry its class in bits 28 .. 30
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
     const float* src_ = sl_ < S0 ? a.in0 + sl_ * 16 : a.in1 + (sl_ - S0) * 16;                                     \
     const unsigned long long ps_ = (unsigned long long)src_;                                                       \
     const u32x4_t dr_ = {(unsigned)ps_, (unsigned)(ps_ >> 32) & 0xFFFFu, a_bytes, 0x00020000u};                    \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+    if (X3F_ABLATE != 1) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
       const unsigned lds_ = rows_lds + (unsigned)j * 1024u;                                                        \
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"                     \
                    ::"v"(OFF[j]), "s"(lds_), "s"(dr_), "s"(0u) : "memory", "m0");                                  \
@@ -790,11 +797,14 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
 
     // the wave's own offset sequence: kd = the offset whose row offsets are in offc; en = raw map entries (slot = lane & 31) of the
     // wave's next offset kn = the lowest bit of Un, requested when kd was taken up (a whole step or more before they are used)
-#define X3F_PERM(O, OFF)                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                           \
-      OFF[j] = (unsigned)__builtin_amdgcn_ds_bpermute(bp_addr + 4 * j, (int)(O));
-#define X3F_FINISH(OFF)                                                                                   \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) OFF[j] = (OFF[j] | x16) ^ ((unsigned)j << 4);  /* (all ones stay >= 2^32 - 64: out of range) */
+#define X3F_QB(O, J, CTRL) (((unsigned)__builtin_amdgcn_update_dpp(0, (int)(O), CTRL, 0xf, 0xf, true) | x16) ^ ((unsigned)(J) << 4))
+#define X3F_PERM(O, OFF)            /* (all ones stay >= 2^32 - 64 under the chunk bits: out of range) */ \
+  {                                                                                                       \
+    OFF[0] = X3F_QB(O, 0, 0x00);                                                                          \
+    OFF[1] = X3F_QB(O, 1, 0x55);                                                                          \
+    OFF[2] = X3F_QB(O, 2, 0xAA);                                                                          \
+    OFF[3] = X3F_QB(O, 3, 0xFF);                                                                          \
+  }
     unsigned Un = Uw;
     int kd = -1;
     unsigned offc[4] = {X3_MISSING, X3_MISSING, X3_MISSING, X3_MISSING};
@@ -808,7 +818,6 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
       unsigned oa;
       X3F_CONV1(ka, ea, oa);
       X3F_PERM(oa, offc);
-      X3F_FINISH(offc);
       kd = ka;
     }
     int k0 = __builtin_ctz(U), g0 = 0, buf = 0;
@@ -822,18 +831,22 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
     for (;;) {
       const unsigned act0 = (m[0] >> k0) & 1u, act1 = (m[1] >> k0) & 1u;
       f32x4 AA[T][2];
-      if (act0) {
-        AA[0][0] = rows[fr0];
-        AA[0][1] = rows[fr1];
-      }
-      if (act1) {
-        AA[1][0] = rows[fr0 + 32];
-        AA[1][1] = rows[fr1 + 32];
+      if (X3F_ABLATE == 6) {
+        AA[0][0] = AA[0][1] = AA[1][0] = AA[1][1] = (f32x4){1.f, 2.f, 3.f, (float)lane};
+      } else {
+        if (act0) {
+          AA[0][0] = rows[fr0];
+          AA[0][1] = rows[fr1];
+        }
+        if (act1) {
+          AA[1][0] = rows[fr0 + 32];
+          AA[1][1] = rows[fr1 + 32];
+        }
       }
       // the next step's rows belong to another offset: its entries (requested a step or more ago: whatever the compiler waits for
       // here landed before the last barrier; behind the staging below it would wait for the weight pieces just requested) become
-      // byte offsets and cross the lanes beside the fragment reads; the entries of the wave's offset after that are requested
-      const bool turn = ok1 && ((Uw >> k1) & 1u) && k1 != kd;
+      // byte offsets and are broadcast inside the lane quads; the entries of the wave's offset after that are requested
+      const bool turn = X3F_ABLATE != 7 && ok1 && ((Uw >> k1) & 1u) && k1 != kd;
       if (turn) {
         unsigned on;
         X3F_CONV1(k1, en, on);
@@ -843,15 +856,15 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
         if (Un) X3F_LOADN(__builtin_ctz(Un), en);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (ok1) X3F_STAGE_W(k1, g1, buf ^ 1);
-      // the fragments are in registers before the next step's lines may overwrite the block
+      if (ok1 && X3F_ABLATE != 4) X3F_STAGE_W(k1, g1, buf ^ 1);
+      // the first tile is split while the second tile's fragments are still on their way; once they are in registers the next
+      // step's lines may overwrite the block (the wait is free by then: LDS reads return in order)
+      X3Planes P0, P1;
+      if (act0) P0 = MODE == 1 ? x3_round(AA[0][0], AA[0][1]) : x3_split(AA[0][0], AA[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (turn) X3F_FINISH(offc);
       if (ok1 && ((Uw >> k1) & 1u)) X3F_GATHER(g1, offc);
       if (act0 | act1) {
-        X3Planes P0, P1;
-        if (act0) P0 = MODE == 1 ? x3_round(AA[0][0], AA[0][1]) : x3_split(AA[0][0], AA[0][1]);
-        __builtin_amdgcn_sched_barrier(0);
         if (act1) P1 = MODE == 1 ? x3_round(AA[1][0], AA[1][1]) : x3_split(AA[1][0], AA[1][1]);
         __builtin_amdgcn_sched_barrier(0);
         const f32x4* wb = s_wb + buf * WB;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
       }
       if (!ok1) break;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (X3F_ABLATE != 5) __syncthreads();
       k0 = k1;
       g0 = g1;
       X3F_ADV(k1, g1, Ur, ok1);
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
 #undef X3F_LOADN
 #undef X3F_K8
 #undef X3F_PERM
-#undef X3F_FINISH
+#undef X3F_QB
 #undef X3F_STAGE_W
   }
 
