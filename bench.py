@@ -38,7 +38,7 @@ def pipe_seconds(family, flops):
     """time the matrix pipe a kernel family runs on needs for `flops` algorithmic fp32 flops at its dense peak: the split-operand
     kernel executes 6 bf16 products per fp32 product on the 2.5 PFLOP/s pipe (ceiling 417 TFLOP/s fp32-equivalent), the fp32-MFMA
     kernels one product on the 157.3 TFLOP/s pipe"""
-    return X3_PRODUCTS * flops / BF16_MFMA_PEAK if family == "x3" else flops / FP32_MFMA_PEAK
+    return X3_PRODUCTS * flops / BF16_MFMA_PEAK if family in ("x3", "x3f", "x3_all") else flops / FP32_MFMA_PEAK
 
 
 def env_int(name, default):
@@ -669,8 +669,16 @@ def main():
                              "alg_bytes_per_launch": pf["bytes"] / n_,
                              "frac_mfma_fp32": pf["flops"] / (pf["ms"] * 1e-3) / FP32_MFMA_PEAK,
                              "frac_pipe": pipe_seconds(fam, pf["flops"]) / (pf["ms"] * 1e-3),
-                             "pipe": "bf16 MFMA 2.5 PFLOP/s, 6 products per fp32 product" if fam == "x3" else "fp32 MFMA 157.3 TFLOP/s",
+                             "pipe": "bf16 MFMA 2.5 PFLOP/s, 6 products per fp32 product" if fam in ("x3", "x3f") else "fp32 MFMA 157.3 TFLOP/s",
                              "frac_hbm": pf["bytes"] / (pf["ms"] * 1e-3) / HBM_PEAK}
+        # "x3_all": every launch on the split-operand arithmetic (k_spconv_x3 + k_spconv_x3f) -- the "x3" family of earlier rounds
+        xs = [pf for fam, pf in prof.get("by_family", {}).items() if fam in ("x3", "x3f") and pf["launches"]]
+        if xs:
+            n_, ms_, fl_, by_ = (sum(pf[k] for pf in xs) for k in ("launches", "ms", "flops", "bytes"))
+            fams["x3_all"] = {"launches_per_step": n_ // max(event_steps, 1), "ms_per_step": ms_ / event_steps,
+                              "alg_bytes_per_launch": by_ / n_, "frac_mfma_fp32": fl_ / (ms_ * 1e-3) / FP32_MFMA_PEAK,
+                              "frac_pipe": pipe_seconds("x3_all", fl_) / (ms_ * 1e-3), "frac_hbm": by_ / (ms_ * 1e-3) / HBM_PEAK,
+                              "pipe": "bf16 MFMA 2.5 PFLOP/s, 6 products per fp32 product"}
         roof["by_kernel_family"] = fams
         roof["frac_pipe"] = pipe_s / secs  # all launches: matrix-pipe time at the dense peak of the pipe each runs on / measured time
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/collect.sh -> traffic.json; a
@@ -684,20 +692,35 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                map_b = prof["map_bytes"] / max(prof["launches"], 1)
-                w_, f_ = tj["write_bytes_per_launch"], tj["fetch_raw_bytes_per_launch"]
-                roof["traffic"] = w_ + f_ + 0.5 * map_b
-                roof["traffic_bounds"] = [w_ + f_ + 0.5 * map_b, w_ + 1.059 * f_ + 0.5 * map_b]
-                roof["map_bytes_per_launch"] = map_b
-                roof["traffic_over_algorithmic"] = roof["traffic"] / (prof["bytes"] / max(prof["launches"], 1))
+                # per kernel class (traffic.json "classes"): fwd3 / x3 gather in 64-byte requests, counted in full, and stream their
+                # kernel map with wide loads, counted half (+ 0.5 x map bytes); x3f fetches everything -- rows as whole 128-byte
+                # lines, weights, map -- in 128-byte requests: 2 x its raw counter (round 6)
+                tot_tr = tot_lo = tot_hi = 0.0
+                n_tot = 0
                 for fam, pf in prof.get("by_family", {}).items():
                     cj = tj.get("classes", {}).get(fam)
-                    if cj and pf["launches"] and fam in fams:
-                        n_ = pf["launches"]
-                        tr = cj["write_bytes_per_launch"] + cj["fetch_raw_bytes_per_launch"] + 0.5 * pf["map_bytes"] / n_
+                    if not (cj and pf["launches"]):
+                        continue
+                    n_ = pf["launches"]
+                    w_c, f_c, m_c = cj["write_bytes_per_launch"], cj["fetch_raw_bytes_per_launch"], pf["map_bytes"] / n_
+                    if fam == "x3f":
+                        # (lower bound: every request tallied in full -- the L2 request counters of one layer on both kernels,
+                        # profiles/r06_pmc_conv_x3f_c64.md vs r05_pmc_conv_x3_c64.md, differ by 10 %, not by 2 x)
+                        tr, lo, hi = w_c + 2.0 * f_c, w_c + f_c + 0.5 * m_c, w_c + 2.0 * f_c
+                    else:
+                        tr, lo, hi = w_c + f_c + 0.5 * m_c, w_c + f_c + 0.5 * m_c, w_c + 1.059 * f_c + 0.5 * m_c
+                    if fam in fams:
                         fams[fam].update({"traffic_per_launch": tr, "traffic_over_algorithmic": tr / (pf["bytes"] / n_)})
-                roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE + FETCH_SIZE raw + 0.5 x kernel-map "
-                                          "bytes; calibration profiles/r05_fetch_calibration.md)")
+                    tot_tr, tot_lo, tot_hi, n_tot = tot_tr + tr * n_, tot_lo + lo * n_, tot_hi + hi * n_, n_tot + n_
+                if n_tot:
+                    roof["traffic"] = tot_tr / n_tot
+                    roof["traffic_bounds"] = [tot_lo / n_tot, tot_hi / n_tot]
+                    roof["map_bytes_per_launch"] = prof["map_bytes"] / max(prof["launches"], 1)
+                    roof["traffic_over_algorithmic"] = roof["traffic"] / (prof["bytes"] / max(prof["launches"], 1))
+                roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc passes of this command, per kernel class: WRITE_SIZE + "
+                                          "FETCH_SIZE raw + 0.5 x kernel-map bytes for k_spconv_fwd3 / k_spconv_x3, WRITE_SIZE + 2 x "
+                                          "FETCH_SIZE raw for k_spconv_x3f whose requests are whole 128-byte lines; calibration "
+                                          "profiles/r05_fetch_calibration.md)")
             except Exception:
                 pass
         roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)

@@ -303,8 +303,9 @@ int pp_spconv_fwd_ex(const float* in0, int32_t c0, const float* in1, int32_t c1,
  * split * n_out * cout * 4 bytes, otherwise the launch runs unsplit. */
 int pp_spconv_set_scratch(void* scratch, size_t bytes);
 /* Which kernel the pp_spconv_fwd family runs a launch of this shape on: 1 = k_spconv_x3 (fp32 operands split exactly into three
- * bfloat16 terms, bf16 matrix pipe; >= 2 sixteen-column tiles per wave and, on <= 2 tiles, >= 32 input channels), 0 = the fp32-MFMA
- * kernels.  The dispatch's own rule (environment overrides included), exported so that a profiler attributes launch times to a
+ * bfloat16 terms, bf16 matrix pipe; >= 2 sixteen-column tiles per wave and, on <= 2 tiles, >= 32 input channels), 2 = k_spconv_x3f
+ * (the same arithmetic and bits with the rows gathered as full 128-byte lines through LDS: inputs of whole 32-channel groups, from
+ * one column tile per wave up; see pp_spconv_x3_full_lines), 0 = the fp32-MFMA kernels.  The dispatch's own rule (environment overrides included), exported so that a profiler attributes launch times to a
  * kernel family without mirroring it.  replaces: nothing in the reference (ME picks its kernels internally, reached from
  * modules/MinkowskiEngine/api_modules.py:30-51); measurement support for SURVEY.md 8(d). */
 int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int32_t K, int64_t n_out, int32_t cout, int32_t shortcut);

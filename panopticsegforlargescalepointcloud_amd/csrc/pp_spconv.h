@@ -78,6 +78,8 @@ int pp_spconv_split_reduce_launch(const SpconvArgs& a, hipStream_t s);
 // wide layers on the bf16 matrix pipe with exactly split fp32 operands (pp_spconv3.hip)
 bool pp_spconv_x3_ok(const SpconvArgs& a, int64_t n_in, int ntw);
 int pp_spconv_x3_launch(const SpconvArgs& a, int64_t n_in, int ntw, unsigned groups, hipStream_t s);
+// does pp_spconv_x3_launch run this launch on k_spconv_x3f (full-line gathers through LDS)?  (a.nbr, a.t8, channels, sizes)
+bool pp_spconv_x3f_ok(const SpconvArgs& a);
 
 // pipelined weight gradient (pp_spconv_bww.hip); 32-bit buffer offsets over the input rows
 bool pp_spconv_bww2_ok(int cin, int cout, int64_t n_in, const int32_t* nbr);

@@ -354,7 +354,7 @@ static int x3_column_tiles(const SpconvArgs& a, int64_t n_in, bool shortcut) {
 }
 
 /* Which kernel pp_spconv_fwd / _shortcut / _t8 run a launch of this shape on: 1 = k_spconv_x3 (split-operand, bf16 matrix pipe),
- * 0 = k_spconv_fwd3 / k_spconv_fwd (fp32 MFMAs).  The same function the dispatch calls -- for profilers that attribute launch times
+ * 2 = k_spconv_x3f (the same arithmetic, rows gathered as full lines through LDS), 0 = k_spconv_fwd3 / k_spconv_fwd (fp32 MFMAs).  The same function the dispatch calls -- for profilers that attribute launch times
  * to a kernel family (ops.LaunchProfiler) without mirroring the rule. */
 extern "C" int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int32_t K, int64_t n_out, int32_t cout,
                                        int32_t shortcut) {
@@ -365,7 +365,8 @@ extern "C" int pp_spconv_kernel_family(int32_t c0, int32_t c1, int64_t n_in, int
   a.nbr = (const int32_t*)(uintptr_t)64;  // (a map is given: K >= 2 launches always have one; the full-line form of the split kernel asks)
   const bool mode16 = ((c0 + c1) % 16 == 0) && c0 % 16 == 0;
   if (!mode16 || K > 28 || !pp_spconv_fwd3_ok(a, n_in)) return 0;
-  return x3_column_tiles(a, n_in, shortcut != 0) ? 1 : 0;
+  if (!x3_column_tiles(a, n_in, shortcut != 0)) return 0;
+  return pp_spconv_x3f_ok(a) ? 2 : 1;  // (on a dense or 8-wide map; the compact form is never handed to such a launch)
 }
 
 // rows_per_wave (0 | 32 | 64), pipeline (0 | 1 | 3) and split_k (0 | 1 | 2 | 4 | 8) select the variant of the pipelined

@@ -1010,6 +1010,7 @@ static bool x3f_ok(const SpconvArgs& a) {
   return g_x3f && (a.t8 == 0 || a.t8 == 1) && a.nbr && a.c0 % 32 == 0 && (a.c1 == 0 || a.c1 == a.c0) &&
          (double)a.K * (double)a.n_out * 4.0 < 4294967000.0;
 }
+bool pp_spconv_x3f_ok(const SpconvArgs& a) { return x3f_ok(a); }
 extern "C" int pp_spconv_x3_full_lines(int32_t mode) {
   if (g_x3f < 0) g_x3f = getenv("PP_CONV_X3F") ? (atoi(getenv("PP_CONV_X3F")) != 0) : 1;
   const int was = g_x3f;

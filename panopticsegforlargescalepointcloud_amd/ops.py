@@ -57,7 +57,7 @@ class LaunchProfiler:
     def __init__(self, reserve=0):
         self.records = []  # (start, end, n_in, n_out, cin, cout, K, nbr tensor or None, has_residual, fused shortcut channels)
         self.map_k = []    # per record: rows of the kernel map the launch streams (27, or 8 for an 8-wide transposed map)
-        self.fams = []     # per record: kernel family the launch ran on ("x3" / "fwd3"), asked from the library at launch time
+        self.fams = []     # per record: kernel family the launch ran on ("x3" / "x3f" / "fwd3"), asked from the library at launch time
         self.tags = []     # per record: TAG at launch time ("fwd" / "dgrad": the input gradient runs on the forward kernel)
         self.records_w = []  # weight-gradient launches (pp_spconv_bwd_weight): (start, end, n_in, n_out, cin, cout, K, pairs)
         # creating a timing event costs ~12 us of host time, recording one ~3 us: the pairs a run needs are created up front
@@ -96,7 +96,7 @@ class LaunchProfiler:
         kernels.  Asks the library (pp_spconv_kernel_family: the dispatch's own rule, its cached environment overrides included)
         instead of mirroring it.  cin = channels of both sources together, c1 = those of the second (ME.cat fused)."""
         fam = _lib.load().pp_spconv_kernel_family(int(cin) - int(c1), int(c1), int(n_in), int(K), int(n_out), int(cout), int(bool(shortcut)))
-        return "x3" if fam == 1 else "fwd3"
+        return {1: "x3", 2: "x3f"}.get(fam, "fwd3")  # ("x3f": the split-operand arithmetic with full-line gathers through LDS)
 
     def summarize(self, tag=None):
         torch.cuda.synchronize()
@@ -158,7 +158,7 @@ class LaunchProfiler:
                  "frac HBM | frac fp32 MFMA | frac pipe |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
         for (n_in, n_out, cin, cout, K, P, fam), (cnt, ms, b, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
             sec = ms / 1e3
-            pipe = 6.0 * fl / bf16_peak if fam == "x3" else fl / mfma_peak
+            pipe = 6.0 * fl / bf16_peak if fam in ("x3", "x3f") else fl / mfma_peak
             lines.append("| %d | %d | %s | %d | %d | %.2f | %s | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f | %.3f | %.3f |" % (
                 n_in, n_out, cin, cout, K, P / max(n_out, 1), fam, cnt / steps, ms / steps, ms / cnt * 1e3, b / sec / 1e9,
                 fl / sec / 1e12, b / sec / hbm_peak, fl / sec / mfma_peak, pipe / sec))

@@ -85,7 +85,9 @@ def traffic(db_fetch, db_write, out):
     res = {"classes": {}}
     # round 5: two kernel families -- k_spconv_fwd3 (fp32 MFMAs: the <= 32-channel layers) and k_spconv_x3 (split operands on the
     # bf16 pipe: the wide layers); totals over both, and per family so that bench.py can set each beside its algorithmic bytes
-    fams = {"fwd3": "%k_spconv_fwd%", "x3": "%k_spconv_x3%"}
+    # round 6: k_spconv_x3f (the split-operand arithmetic with full-line gathers) as a class of its own: its gathers are 128-byte
+    # requests, which the counter tallies at 64 bytes -- bench.py doubles that class' raw counter instead of adding back map bytes
+    fams = {"fwd3": "%k_spconv_fwd%", "x3": "%k_spconv_x3<%", "x3f": "%k_spconv_x3f<%"}
     tot = {"fetch": [0, 0.0], "write": [0, 0.0]}
     for fam, like in fams.items():
         ent = {}
@@ -103,7 +105,7 @@ def traffic(db_fetch, db_write, out):
     res["write_launches"], res["write_KiB_total"] = tot["write"]
     fetch_raw = 1024.0 * res["fetch_KiB_total"] / max(res["fetch_launches"], 1)
     write_b = 1024.0 * res["write_KiB_total"] / max(res["write_launches"], 1)
-    res.update({"kernel": "k_spconv_fwd3 + k_spconv_x3", "fetch_raw_bytes_per_launch": fetch_raw, "write_bytes_per_launch": write_b,
+    res.update({"kernel": "k_spconv_fwd3 + k_spconv_x3 + k_spconv_x3f", "fetch_raw_bytes_per_launch": fetch_raw, "write_bytes_per_launch": write_b,
                 "calibration": {"streaming_known_over_raw": 2.0, "gather64_known_over_raw": 1.059, "write_known_over_raw": 1.0,
                                 "source": "profiles/r05_fetch_calibration.md (64 .. 384-byte rows) / r02_fetch_calibration.md",
                                 "rule": "FETCH_SIZE tallies 64 bytes per request; a request is <= 128 bytes: full-line (128-byte) "

@@ -489,21 +489,31 @@ def test_bench_launches_its_own_ranks(monkeypatch):
 
 def test_conv_kernel_family_rule():
     """which kernel a convolution shape runs on, as bench.py's per-family figures attribute it: the library's own dispatch rule
-    (pp_spconv_kernel_family, a host function -- no GPU needed): >= 2 sixteen-column tiles per wave (>= 32 output channels) and,
-    on <= 2 tiles, >= 32 input channels -> the split-operand kernel; 1x1 and 16-channel layers, the 4-channel input layer and
-    everything under PP_CONV_X3=0 (read once per process: checked in a child) -> the fp32-MFMA kernel"""
+    (pp_spconv_kernel_family, a host function -- no GPU needed).  Split-operand arithmetic (bf16 matrix pipe): inputs of whole
+    32-channel groups on k_spconv_x3f ("x3f": full-line gathers through LDS, from one column tile per wave up); 48 / 80 / 112-channel
+    inputs, two sources of 16 (2 k + 1) channels and 16-channel inputs with >= 3 column tiles on k_spconv_x3 ("x3").  The fp32-MFMA
+    kernel ("fwd3"): 16-channel inputs on <= 2 column tiles, 1x1 layers, the 4-channel input layer, inputs of 4 GiB or more, and
+    everything under PP_CONV_X3=0 (read once per process: checked in a child); PP_CONV_X3F=0 puts the x3f shapes back on x3 and
+    the one-column-tile ones on fwd3"""
     import subprocess
     import sys
     from panopticsegforlargescalepointcloud_amd import ops
     fam = ops.LaunchProfiler.kernel_family
-    want = {(64, 64, 27): "x3", (48, 48, 27): "x3", (128, 48, 27): "x3", (160, 64, 27): "x3", (96, 96, 27): "x3", (192, 80, 27): "x3",
-            (112, 112, 27): "x3", (96, 32, 27): "x3", (64, 32, 27): "x3", (32, 32, 27): "x3", (16, 16, 27): "fwd3",
-            (64, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3", (16, 32, 27): "fwd3", (16, 48, 27): "x3"}
-    if os.environ.get("PP_CONV_X3", "1") != "0" and not os.environ.get("PP_CONV_X3_MIN_NTW"):
+    want = {(64, 64, 27): "x3f", (48, 48, 27): "x3", (128, 48, 27): "x3f", (160, 64, 27): "x3f", (96, 96, 27): "x3f", (192, 80, 27): "x3f",
+            (112, 112, 27): "x3", (96, 32, 27): "x3f", (64, 32, 27): "x3f", (32, 32, 27): "x3f", (16, 16, 27): "fwd3",
+            (64, 16, 27): "x3f", (32, 16, 27): "x3f", (48, 16, 27): "fwd3", (4, 16, 27): "fwd3", (96, 112, 1): "fwd3", (32, 64, 27): "x3f",
+            (16, 32, 27): "fwd3", (16, 48, 27): "x3", (80, 80, 27): "x3"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("PP_CONV_X3", "1") != "0" and not os.environ.get("PP_CONV_X3_MIN_NTW") and os.environ.get("PP_CONV_X3F", "1") != "0":
         for (cin, cout, K), f in want.items():
             assert fam(cin, cout, K) == f, (cin, cout, K)
-        assert fam(64, 32, 27, c1=32) == "x3" and fam(48, 32, 27, c1=16) == "fwd3"  # two sources (ME.cat fused): equal widths only
+        assert fam(64, 32, 27, c1=32) == "x3f" and fam(48, 32, 27, c1=16) == "fwd3"  # two sources (ME.cat fused): equal widths only
+        assert fam(96, 32, 27, c1=48) == "x3"   # ... and a source boundary inside a 32-channel group stays on the register gathers
         assert fam(64, 64, 27, n_in=1 << 26) == "fwd3"  # >= 4 GiB of input rows: not addressable by the buffer descriptors
+        code = ("from panopticsegforlargescalepointcloud_amd import ops; f = ops.LaunchProfiler.kernel_family; "
+                "print(f(64, 64, 27), f(64, 16, 27), f(48, 48, 27))")
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PP_CONV_X3F="0"), capture_output=True, text=True, cwd=root)
+        assert out.stdout.split()[-3:] == ["x3", "fwd3", "x3"], out.stdout + out.stderr
     code = "from panopticsegforlargescalepointcloud_amd import ops; print(ops.LaunchProfiler.kernel_family(64, 64, 27))"
     env = dict(os.environ, PP_CONV_X3="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
