@@ -876,8 +876,7 @@ def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=Non
         # ... and not by the full-line form of the split kernel (k_spconv_x3f: dense and 8-wide maps).  A launch that kernel serves
         # keeps its dense map: which kernel family evaluates a layer must not depend on the map's form (one-column-tile layers
         # are on the split kernel only in that form), and results never do
-        if cmap is not None and c0 % 32 == 0 and lib.pp_spconv_x3_full_lines(-1) == 1 and \
-                lib.pp_spconv_kernel_family(c0, c1, in0.shape[0], K, n_out, cout, int(shortcut is not None)) == 1:
+        if cmap is not None and lib.pp_spconv_kernel_family(c0, c1, in0.shape[0], K, n_out, cout, int(shortcut is not None)) == 2:
             cmap = None
     if cmap is not None:
         # same-level map in its compact form (map_compact): 4 + 6 x pairs bytes per row in the prologue instead of 108
