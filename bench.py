@@ -452,6 +452,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-prefetch", action="store_true",
                     help="build every batch's coordinate manager at the start of its own pass (no overlap with the previous batch)")
+    ap.add_argument("--backbone-ahead", action="store_true",
+                    help="timed region with the next batch's backbone launched beside this batch's grouping (TileRunner backbone_ahead; "
+                         "also PP_BACKBONE_AHEAD=1).  Off by default: the step gets ~5 %% faster, but convolutions that share the GPU "
+                         "with the grouping kernels take longer per launch, so per-launch events stop measuring the kernel "
+                         "(roofline.frac 0.58 -> 0.47, profiles/r06_backbone_ahead.txt)")
     ap.add_argument("--no-checks", action="store_true", help="skip the untimed self-check (batch invariance, oracle parity)")
     ap.add_argument("--layer-table", default=None, help="write the per-shape convolution table (markdown) here")
     ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
@@ -485,7 +490,10 @@ def main():
     shards = shard_tiles(sizes, world)
     mine = shards[rank]
     model, cfg, DS = build_model(device, args.voxel)
-    runner = TileRunner(model, device)
+    # a stream of batches: the next batch's backbone + heads are launched beside this batch's grouping / scorer front end
+    # (scene.TileRunner; PP_BACKBONE_AHEAD=0 or --no-backbone-ahead: one batch at a time)
+    backbone_ahead = (args.backbone_ahead or os.environ.get("PP_BACKBONE_AHEAD", "0") == "1") and not args.no_input_prefetch
+    runner = TileRunner(model, device, backbone_ahead=backbone_ahead)
 
     # resident inputs: tile batches + synthetic head statistics (HBM) before the timed region
     rng = np.random.default_rng(2022 + rank)
@@ -511,7 +519,8 @@ def main():
             # the job is a stream of tile batches (this scene's next batch, or the first batch of the next scene): the runner
             # builds the coordinate manager of the batch that follows while this one is in its grouping / scorer stages
             nxt = batches[(j + 1) % len(batches)][1] if input_prefetch else None
-            labels, res, counts = runner.run(dev_b, len(ids), override=override, next_batch=nxt)
+            nxt2 = batches[(j + 2) % len(batches)][1] if input_prefetch else None
+            labels, res, counts = runner.run(dev_b, len(ids), override=override, next_batch=nxt, after_next=nxt2)
             stats["proposals"] += res.clusters_csr.n if res.clusters_csr is not None else 0
             stats["instances"] += sum(counts)
             # what the scene assembly needs from a cylinder: origin ids, instance labels, semantic vote contributions
@@ -571,7 +580,9 @@ def main():
         ops.PROFILER = profiler if it < event_steps else None
         result = step()          # (ends with the host read of the per-tile instance counts: the step's own sync point)
         step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
-    # the last step prepared a batch nobody will run: its build is still part of the timed region (K steps = K builds)
+    # the last step prepared a batch nobody will run (and, with backbone_ahead, ran its backbone): that work is still part of the
+    # timed region (K steps = K builds = K backbones; the first timed step's backbone ran in the last warm-up step)
+    runner.drain()
     held = model.Backbone.__dict__.pop("_prepared_input", None)
     if held is not None:
         held[2].take().join_prefetch()
@@ -748,6 +759,7 @@ def main():
                                    "+ ScorerUnet + NMS" % (len(tiles), radius, total_points, len(scene.pos)),
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "input_prefetch": input_prefetch,  # next batch's coordinate manager built during the current batch
+                       "backbone_ahead": backbone_ahead,  # next batch's backbone + heads launched beside this batch's grouping (own stream)
                        "single_scene_ms": single_scene_ms,  # a step that builds its own coordinate manager first (3 steps, untimed region)
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],

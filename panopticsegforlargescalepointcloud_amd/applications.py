@@ -222,6 +222,9 @@ class MinkowskiUnet(BaseMinkowski):
             cm._log = []            # first inference pass of this model: record the level / map requests ...
         elif prefetch:
             cm.prefetch(plan)       # ... later passes replay them ahead of the convolutions on the side stream
+        hook = self.__dict__.pop("_before_first_conv", None)
+        if hook is not None:
+            hook()                  # (scene.TileRunner: the proposal scorer's convolutions wait for the next batch's backbone here)
         try:
             stack_down = []
             for i in range(len(self.down_modules) - 1):

@@ -811,17 +811,22 @@ def pack_weight_cached(param, transpose=False, kflip=False):
     return PACKED_WEIGHTS.get(param, transpose, kflip)
 
 
-_CONV_SCRATCH = {"device": None, "buf": None}
+_CONV_SCRATCH = {"key": None, "bufs": {}}
 CONV_SCRATCH_BYTES = int(os.environ.get("PP_CONV_SCRATCH_MB", "64")) << 20
 
 
 def _conv_scratch(lib, device):
-    """registers the split-K scratch of small convolution launches (pp_spconv_set_scratch) once per device; the buffer
-    is owned here and serves the stream the convolutions are launched on"""
-    if _CONV_SCRATCH["device"] != device:
-        buf = torch.empty(CONV_SCRATCH_BYTES, dtype=torch.uint8, device=device) if CONV_SCRATCH_BYTES > 0 else None
+    """registers the split-K scratch of small convolution launches (pp_spconv_set_scratch) for the stream the next convolution
+    is launched on: the library holds ONE pointer and reads it at launch time, the buffers are owned here, one per (device,
+    stream) -- two streams' convolutions (the next batch's backbone beside this batch's grouping, scene.TileRunner) must not
+    add their partial sums in the same block"""
+    key = (device, _stream().value)
+    if _CONV_SCRATCH["key"] != key:
+        buf = _CONV_SCRATCH["bufs"].get(key)
+        if buf is None and CONV_SCRATCH_BYTES > 0:
+            buf = _CONV_SCRATCH["bufs"][key] = torch.empty(CONV_SCRATCH_BYTES, dtype=torch.uint8, device=device)
         _lib.check(lib.pp_spconv_set_scratch(_ptr(buf), CONV_SCRATCH_BYTES if buf is not None else 0), "pp_spconv_set_scratch")
-        _CONV_SCRATCH["device"], _CONV_SCRATCH["buf"] = device, buf
+        _CONV_SCRATCH["key"] = key
 
 
 def bf16_conv_supported(c0, c1, K, nbr_given=True):

@@ -280,13 +280,61 @@ def assemble_scene(results, tile_order, n_scene_points, num_classes):
 
 
 # ------------------------------------------------------------------------------------------------ the hot path over tiles
-class TileRunner:
-    """Runs batches of cylinder tiles through the model on one device (eval mode, no_grad)."""
+class _BackboneAhead:
+    """what stage A (set_input + backbone + heads) of a batch leaves for its stage B (grouping, scorer, NMS)"""
+    __slots__ = ("key", "input", "raw_pos", "labels", "outs", "done", "hold")
 
-    def __init__(self, model, device, epoch=10 ** 6, stage_timing=False):
+
+def _batch_key(b):
+    return (b["coords"].data_ptr() if torch.is_tensor(b["coords"]) else id(b["coords"]), int(b["coords"].shape[0]))
+
+
+class TileRunner:
+    """Runs batches of cylinder tiles through the model on one device (eval mode, no_grad).
+
+    backbone_ahead=True (a stream of batches, `run(..., next_batch=, after_next=)`): the NEXT batch's backbone + heads are launched
+    on a stream of their own before this batch's grouping starts, so that the convolutions of batch i + 1 fill the GPU while
+    batch i is in region growing / mean shift / the proposal scorer's front end (latency- and atomics-bound kernels and host reads
+    that leave most of the chip idle, profiles/r06_kt/timeline.txt); the scorer's own convolutions wait for that backbone (two
+    saturating convolution streams only take turns).  Results are those of the one-batch-at-a-time order bit for bit
+    (tests/test_scene_gpu.py::test_backbone_ahead_does_not_change_results); the batch after next gets its coordinate manager
+    built meanwhile (`after_next`), as `next_batch` does without the option."""
+
+    def __init__(self, model, device, epoch=10 ** 6, stage_timing=False, backbone_ahead=False):
         self.model, self.device, self.epoch = model, device, epoch
         self.stage_timing = stage_timing
         self.stage_ms = {}
+        self.backbone_ahead = bool(backbone_ahead) and not stage_timing
+        self._ahead = None
+        # The stream the backbone ahead runs on is created AND USED here, before the model's first pass uses its side / preparation /
+        # clustering streams: a process' HIP streams share a few hardware queues, bound in order of first use, and a stream first used
+        # late landed on a queue where the two batches ran one after the other (profiles/r06_backbone_ahead.txt: 108.6 ms per step
+        # when the option was switched on after a few serial steps, 104.2 from the start, 105.4 either way with this first submission).
+        # Only with the option: the extra stream shifts the other streams' queues (PP_AHEAD_PRIORITY: its HIP priority, A/B runs)
+        # PP_STREAM_ORDER (A/B runs): first-use order of the model's streams, letters S (map prefetch), P / Q (the two preparation
+        # streams), C (clustering / NMS side stream) -- e.g. "SCPQ"; unset: whatever order the first pass uses them in (P, Q, C, S)
+        order = os.environ.get("PP_STREAM_ORDER", "")
+        if order and torch.cuda.is_available() and torch.device(device).type == "cuda":
+            from . import MinkowskiEngine as _ME
+            for ch in order:
+                if ch == "S":
+                    st = _ME._side_stream(torch.device(device))
+                elif ch in "PQ":
+                    st = _ME._prep_stream(torch.device(device), 0 if ch == "P" else 1)
+                elif ch == "C":
+                    st = model._side_streams.get(torch.device(device)) if hasattr(model, "_side_streams") else None
+                    if st is None and hasattr(model, "_side_streams"):
+                        st = model._side_streams[torch.device(device)] = torch.cuda.Stream(device=device)
+                else:
+                    st = None
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        torch.zeros(1, device=device)
+        self._ahead_stream = None
+        if self.backbone_ahead and torch.cuda.is_available() and torch.device(device).type == "cuda":
+            self._ahead_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
+            with torch.cuda.stream(self._ahead_stream):
+                torch.zeros(1, device=device)
 
     def _tick(self, name, t0):
         """wall time of a stage incl. its device work (only when stage_timing is on: it synchronises)."""
@@ -298,34 +346,87 @@ class TileRunner:
             return now
         return t0
 
+    def _stage_a(self, batch_np):
+        """set_input + backbone + heads of a batch on the current stream"""
+        dev = self.device
+        to = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)  # noqa: E731
+        data = Data(pos=to(batch_np["pos"]), coords=to(batch_np["coords"]), batch=to(batch_np["batch"]), x=to(batch_np["x"]))
+        self.model.set_input(data, dev)
+        c = _BackboneAhead()
+        c.key, c.outs = _batch_key(batch_np), self.model.backbone_and_heads()
+        c.input, c.raw_pos, c.labels = self.model.input, self.model.raw_pos, self.model.labels
+        c.done = c.hold = None
+        return c
+
+    def drain(self):
+        """wait for (and drop) a backbone that was launched ahead and never consumed"""
+        a, self._ahead = self._ahead, None
+        if a is not None and a.done is not None:
+            a.done.synchronize()
+
     @torch.no_grad()
-    def run(self, batch_np, n_tiles, override=None, next_batch=None):
+    def run(self, batch_np, n_tiles, override=None, next_batch=None, after_next=None):
         """batch_np: dict of numpy/torch arrays (pos, coords, batch, x, origin_id). override: optional
         (pred int64 [N], offsets [N,3], embeddings [N,D]) device tensors replacing the heads' outputs for grouping.
         next_batch: the batch the NEXT call will be given (device tensors): its coordinate manager -- Morton order, block index,
         level chain and kernel maps of the backbone -- is built on a stream of its own while this batch is in its grouping and
-        scorer stages (BaseMinkowski.prepare_input), so the next call's first convolution does not wait for it.
+        scorer stages (BaseMinkowski.prepare_input), so the next call's first convolution does not wait for it; with
+        backbone_ahead its backbone + heads run now as well and `after_next` (the batch after it) is the one that is prepared.
         Returns (labels int32 [N] device, PanopticResults)."""
         dev = self.device
-        to = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)  # noqa: E731
-        data = Data(pos=to(batch_np["pos"]), coords=to(batch_np["coords"]), batch=to(batch_np["batch"]), x=to(batch_np["x"]))
         import time
         t0 = time.perf_counter() if self.stage_timing else 0.0
         if self.stage_timing:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        self.model.set_input(data, dev)
-        feats, sem, off, emb, pred = self.model.backbone_and_heads()
+        main = torch.cuda.current_stream(dev)
+        ctx, self._ahead = self._ahead, None
+        if ctx is not None and ctx.key == _batch_key(batch_np):
+            # stage A of this batch ran ahead on its own stream: this stream takes its tensors over
+            main.wait_event(ctx.done)
+            for t in ctx.hold:
+                t.record_stream(main)
+            self.model.input, self.model.raw_pos, self.model.labels = ctx.input, ctx.raw_pos, ctx.labels
+        else:
+            if ctx is not None and ctx.done is not None:
+                ctx.done.synchronize()  # (another batch than announced: let its launches finish before its tensors are dropped)
+            ctx = self._stage_a(batch_np)
+        feats, sem, off, emb, pred = ctx.outs
         t0 = self._tick("backbone+heads", t0)
-        if next_batch is not None and INPUT_PREFETCH:
-            if not all(torch.is_tensor(next_batch[k]) and next_batch[k].is_cuda for k in ("coords", "batch")):
-                raise ValueError("next_batch must hold device tensors (the build reads them on its own stream)")
+        prefetchable = next_batch is not None and INPUT_PREFETCH
+        if prefetchable and not all(torch.is_tensor(next_batch[k]) and next_batch[k].is_cuda for k in ("coords", "batch")):
+            raise ValueError("next_batch must hold device tensors (the build reads them on its own stream)")
+        if prefetchable and self.backbone_ahead:
+            if self._ahead_stream is None:
+                self._ahead_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
+            sa = self._ahead_stream
+            sa.wait_stream(main)  # (the batch tensors and everything this stream has freed so far)
+            with torch.cuda.stream(sa):
+                nctx = self._stage_a(next_batch)
+                nctx.done = torch.cuda.Event()
+                nctx.done.record(sa)
+            f = nctx.outs[0]
+            nctx.hold = [t for t in ((f.base, f.index) if hasattr(f, "base") else (f,)) + tuple(nctx.outs[1:]) if torch.is_tensor(t)]
+            self._ahead = nctx
+            if after_next is not None:
+                self.model.Backbone.prepare_input(Data(coords=after_next["coords"], batch=after_next["batch"]))
+            # stage B below belongs to THIS batch again; the scorer's convolutions start when the backbone ahead is through
+            self.model.input, self.model.raw_pos, self.model.labels = ctx.input, ctx.raw_pos, ctx.labels
+            scorer = getattr(self.model, "ScorerUnet", None)
+            if scorer is not None:
+                scorer._before_first_conv = lambda ev=nctx.done, dv=dev: torch.cuda.current_stream(dv).wait_event(ev)
+        elif prefetchable:
             self.model.Backbone.prepare_input(Data(coords=next_batch["coords"], batch=next_batch["batch"]))
         if override is not None:
             pred, off, emb = override
-        res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred, timer=self._tick if self.stage_timing else None,
-                                         t0=t0)
-        t0 = self._tick("(group+score total marker)", time.perf_counter()) if False else (time.perf_counter() if self.stage_timing else 0.0)
+        try:
+            res = self.model.group_and_score(self.epoch, feats, sem, off, emb, pred, timer=self._tick if self.stage_timing else None,
+                                             t0=t0)
+        finally:
+            scorer = getattr(self.model, "ScorerUnet", None)
+            if scorer is not None:
+                scorer.__dict__.pop("_before_first_conv", None)  # (no proposals / another scorer type: never consumed)
+        t0 = time.perf_counter() if self.stage_timing else 0.0
         labels, counts = instance_labels_per_tile(res, self.model.input.batch, n_tiles)  # (reads the row-gather flag too)
         self._tick("nms+paint", t0)
         return labels, res, counts

@@ -96,6 +96,53 @@ def test_prepared_next_batch_does_not_change_results():
         scene_mod.INPUT_PREFETCH = True
 
 
+def test_backbone_ahead_does_not_change_results():
+    """TileRunner(backbone_ahead=True): the NEXT batch's backbone + heads run on a stream of their own beside this batch's grouping
+    and scorer front end, the batch after next gets its coordinate manager prepared, the scorer's convolutions wait for the
+    backbone ahead.  Over a stream of three different batches (twice round, then with a batch that was NOT the announced one) the
+    labels, scores, semantic outputs and counts are those of one batch at a time, bit for bit; the real head outputs (no
+    override) cross the streams as well."""
+    import bench
+    from panopticsegforlargescalepointcloud_amd import synthetic as syn
+    from panopticsegforlargescalepointcloud_amd.scene import TileRunner
+    dev = torch.device("cuda")
+    scene, tiles, _ = bench.build_scene(150_000, 3, 0.05, 2024)
+    model, cfg, DS = bench.build_model(dev, 0.05)
+    batches = []
+    for ids in ([0, 1], [2, 3], [4, 5, 6]):
+        b = syn.tile_batch(scene, tiles, ids)
+        ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(17 + ids[0]))
+        batches.append(({k: torch.from_numpy(v).to(dev) for k, v in b.items()}, tuple(torch.from_numpy(a).to(dev) for a in ov), len(ids)))
+
+    def out(r):
+        labels, res, counts = r
+        return (labels.cpu().numpy(), res.cluster_scores.cpu().numpy(), res.semantic_logits.cpu().numpy(),
+                res.embed_logits.cpu().numpy(), res.clusters_csr.points.cpu().numpy(), list(counts))
+
+    serial = TileRunner(model, dev)
+    want = [out(serial.run(b, n, override=ov)) for b, ov, n in batches]
+    want_own = out(serial.run(batches[1][0], batches[1][2]))   # the network's OWN head outputs feed the grouping
+    ahead = TileRunner(model, dev, backbone_ahead=True)
+    order = [0, 1, 2, 0, 1, 2, 0]
+    for j, i in enumerate(order):
+        nxt = batches[order[j + 1]][0] if j + 1 < len(order) else None
+        nxt2 = batches[order[j + 2]][0] if j + 2 < len(order) else None
+        got = out(ahead.run(batches[i][0], batches[i][2], override=batches[i][1], next_batch=nxt, after_next=nxt2))
+        assert (ahead._ahead is not None) == (nxt is not None)
+        for g, w in zip(got, want[i]):
+            assert np.array_equal(g, w) if isinstance(g, np.ndarray) else g == w, (j, i)
+    # a batch other than the announced one: the backbone that ran ahead is dropped, this batch runs its own
+    got = out(ahead.run(batches[0][0], batches[0][2], override=batches[0][1], next_batch=batches[2][0]))
+    got = out(ahead.run(batches[1][0], batches[1][2], next_batch=batches[1][0]))   # (announced 2, given 1; no override)
+    for g, w in zip(got, want_own):
+        assert np.array_equal(g, w) if isinstance(g, np.ndarray) else g == w
+    got = out(ahead.run(batches[1][0], batches[1][2]))                              # takes the backbone launched by the call before
+    for g, w in zip(got, want_own):
+        assert np.array_equal(g, w) if isinstance(g, np.ndarray) else g == w
+    ahead.drain()
+    assert ahead._ahead is None and "_before_first_conv" not in model.ScorerUnet.__dict__
+
+
 def test_tile_batch_on_the_gpu_matches_numpy_collation():
     """voxelise -> cut cylinders -> collate on the GPU (row f1) vs the NumPy generator path on the same raw cloud."""
     from oracle import oracle
