@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
 ulimit -c 0
-mkdir -p gpurun_out/s2j
-P='
-import json,sys
-d=json.loads(sys.stdin.read()); r=d["roofline"]
-print("ms_per_step %.2f frac %.4f single %s"%(d["ms_per_step"], r["frac"], d["config"]["single_scene_ms"]))
-'
-for v in "" SCPQ CSPQ SPQC PQSC "" SCPQ CSPQ; do echo "== PP_STREAM_ORDER=[$v]"; PP_STREAM_ORDER=$v timeout 600 python bench.py --no-cpu-baseline --no-checks --steps 8 2>/dev/null | tail -1 | python -c "$P"; done > gpurun_out/s2j/stream_order.txt 2>&1
-cat gpurun_out/s2j/stream_order.txt
+mkdir -p gpurun_out/s2k
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "^E |Error|FAILED|passed|failed" | head -30 > gpurun_out/s2k/first_fail.txt
+cat gpurun_out/s2k/first_fail.txt

@@ -229,7 +229,7 @@ def test_spconv_split_k_small_launches(ops, oracle, cin, cout, n):
         assert lib.pp_spconv_set_scratch(None, 0) == 0
         unsplit = run()
     finally:
-        ops._CONV_SCRATCH["device"] = None  # re-register on the next call
+        ops._CONV_SCRATCH["key"] = None  # re-register on the next call
     np.testing.assert_allclose(unsplit.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
     if cin * 27 > 500:
         assert not torch.equal(unsplit, got)  # a different summation order: the split path really ran
