@@ -452,11 +452,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-prefetch", action="store_true",
                     help="build every batch's coordinate manager at the start of its own pass (no overlap with the previous batch)")
-    ap.add_argument("--backbone-ahead", action="store_true",
-                    help="timed region with the next batch's backbone launched beside this batch's grouping (TileRunner backbone_ahead; "
-                         "also PP_BACKBONE_AHEAD=1).  Off by default: the step gets ~5 %% faster, but convolutions that share the GPU "
-                         "with the grouping kernels take longer per launch, so per-launch events stop measuring the kernel "
-                         "(roofline.frac 0.58 -> 0.47, profiles/r06_backbone_ahead.txt)")
+    ap.add_argument("--backbone-ahead", choices=("auto", "on", "off"), default=os.environ.get("PP_BACKBONE_AHEAD", "auto"),
+                    help="launch the next batch's backbone beside this batch's grouping (scene.TileRunner backbone_ahead).  auto = on "
+                         "when a batch has fewer than PP_AHEAD_MAX_VOXELS (4 M) voxels -- there the step is paced by latency-bound "
+                         "kernels and host reads (1.2 M voxels, one rank's share at 8 GPUs: 22.2 -> 17.6 ms) -- and off above: at "
+                         "9.8 M voxels it is worth 5 %% of the step but convolutions that share the GPU with the grouping kernels "
+                         "take longer per launch, so per-launch events stop measuring the kernel (roofline.frac 0.58 -> 0.47, "
+                         "profiles/r06_backbone_ahead.txt)")
     ap.add_argument("--no-checks", action="store_true", help="skip the untimed self-check (batch invariance, oracle parity)")
     ap.add_argument("--layer-table", default=None, help="write the per-shape convolution table (markdown) here")
     ap.add_argument("--stage-timing", action="store_true", help="extra (untimed) step with per-stage wall times")
@@ -492,8 +494,7 @@ def main():
     model, cfg, DS = build_model(device, args.voxel)
     # a stream of batches: the next batch's backbone + heads are launched beside this batch's grouping / scorer front end
     # (scene.TileRunner; PP_BACKBONE_AHEAD=0 or --no-backbone-ahead: one batch at a time)
-    backbone_ahead = (args.backbone_ahead or os.environ.get("PP_BACKBONE_AHEAD", "0") == "1") and not args.no_input_prefetch
-    runner = TileRunner(model, device, backbone_ahead=backbone_ahead)
+    # (decided below, once the batches exist: "auto" looks at their size)
 
     # resident inputs: tile batches + synthetic head statistics (HBM) before the timed region
     rng = np.random.default_rng(2022 + rank)
@@ -507,6 +508,13 @@ def main():
         starts = np.concatenate([[0], np.cumsum([len(tiles[t]) for t in ids])])
         batches.append((ids, dev_b, override, starts, [int(len(tiles[t])) for t in ids]))
     t_gen = time.perf_counter() - t_gen
+    mode = {"1": "on", "0": "off"}.get(args.backbone_ahead, args.backbone_ahead)
+    if mode not in ("auto", "on", "off"):
+        raise SystemExit("--backbone-ahead / PP_BACKBONE_AHEAD: auto, on or off")
+    batch_voxels = max([int(bt[1]["coords"].shape[0]) for bt in batches] or [0])
+    backbone_ahead = (mode == "on" or (mode == "auto" and 0 < batch_voxels < env_int("PP_AHEAD_MAX_VOXELS", 4_000_000))) \
+        and not args.no_input_prefetch
+    runner = TileRunner(model, device, backbone_ahead=backbone_ahead)
 
     stats = {"proposals": 0, "instances": 0, "local_ms": [], "exchange_events": []}
     input_prefetch = not args.no_input_prefetch
@@ -759,7 +767,9 @@ def main():
                                    "+ ScorerUnet + NMS" % (len(tiles), radius, total_points, len(scene.pos)),
                        "tiles": len(tiles), "tiles_per_batch": args.tiles_per_batch, "points": total_points,
                        "input_prefetch": input_prefetch,  # next batch's coordinate manager built during the current batch
-                       "backbone_ahead": backbone_ahead,  # next batch's backbone + heads launched beside this batch's grouping (own stream)
+                       # next batch's backbone + heads launched beside this batch's grouping (own stream): --backbone-ahead auto = on
+                       # below PP_AHEAD_MAX_VOXELS (4 M) voxels per batch
+                       "backbone_ahead": backbone_ahead, "backbone_ahead_mode": mode, "batch_voxels": batch_voxels,
                        "single_scene_ms": single_scene_ms,  # a step that builds its own coordinate manager first (3 steps, untimed region)
                        "grouping_inputs": "synthetic head statistics (SURVEY.md 8d)", "parallelism": "tile-sharded x%d" % world,
                        "proposals_per_step": stats["proposals"], "instances_per_step": stats["instances"],

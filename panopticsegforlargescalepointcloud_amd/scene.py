@@ -396,7 +396,7 @@ class TileRunner:
         prefetchable = next_batch is not None and INPUT_PREFETCH
         if prefetchable and not all(torch.is_tensor(next_batch[k]) and next_batch[k].is_cuda for k in ("coords", "batch")):
             raise ValueError("next_batch must hold device tensors (the build reads them on its own stream)")
-        if prefetchable and self.backbone_ahead:
+        if prefetchable and self.backbone_ahead and not self.stage_timing:
             if self._ahead_stream is None:
                 self._ahead_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
             sa = self._ahead_stream
