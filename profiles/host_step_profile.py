@@ -22,24 +22,24 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda")
 scene, tiles, _ = bench.build_scene(points, grid, 0.05, 2022)
 model, cfg, DS = bench.build_model(dev, 0.05)
-runner = TileRunner(model, dev)
+runner = TileRunner(model, dev, backbone_ahead=os.environ.get("PP_BACKBONE_AHEAD", "1") != "0")
 ids = list(range(len(tiles)))
 b = syn.tile_batch(scene, tiles, ids)
 ov = syn.synthetic_head_outputs(scene, b["origin_id"], 0.0, np.random.default_rng(2022))
 dev_b = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 ovd = tuple(torch.from_numpy(a).to(dev) for a in ov)
 for _ in range(5):
-    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b, after_next=dev_b)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b, after_next=dev_b)
 torch.cuda.synchronize()
 print("unprofiled: %.2f ms per step (%d voxels, %d tiles)" % (1e3 * (time.perf_counter() - t0) / steps, len(b["pos"]), len(ids)))
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
-    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b)
+    runner.run(dev_b, len(ids), override=ovd, next_batch=dev_b, after_next=dev_b)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()

@@ -1,13 +1,10 @@
-# round 6: refresh of the records that --backbone-ahead auto changes: configs[1] / [2], one rank's share (line + traced timeline)
 cd $GRAFT_REPO_ROOT
 ulimit -c 0
-O=gpurun_out/r06b; mkdir -p $O
-python profiles/config_microbench.py --out $O > $O/configs.log 2>&1
-python bench.py --points 1250000 --grid 3 --steps 30 --warmup 4 --no-cpu-baseline --no-checks 2>/dev/null | tail -1 > $O/shard_bench.json
-SHARD_TAG=r06_shard_ahead bash profiles/kt_shard.sh > $O/shard.log 2>&1
+mkdir -p gpurun_out/s2n
+PP_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --points 2000000 --grid 4 --steps 5 --warmup 2 --no-cpu-baseline --no-checks 2>gpurun_out/s2n/err.txt | tail -1 > gpurun_out/s2n/gloo2_ahead.json
 python - <<'PY'
 import json
-for f in ("c2","c3","shard_bench"):
-    d=json.load(open("gpurun_out/r06b/%s.json"%f)); print(f, d.get("ms_per_step"), d.get("value"), d.get("config",{}).get("backbone_ahead"))
+g=json.load(open("gpurun_out/s2n/gloo2_ahead.json")); c=g["config"]
+print("n_gpus", g["n_gpus"], "ms", g["ms_per_step"], "ahead", c["backbone_ahead"], "voxels/batch", c["batch_voxels"], "multi", c["multi_gpu"])
 PY
-head -8 gpurun_out/r06_shard_ahead/timeline_shard.txt; grep -n "largest idle gaps" -A6 gpurun_out/r06_shard_ahead/timeline_shard.txt | head -12
+tail -3 gpurun_out/s2n/err.txt
