@@ -871,6 +871,10 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
         bf16x8_t Bf[2][PL];
 #pragma unroll
         for (int p = 0; p < PL; ++p) Bf[0][p] = __builtin_bit_cast(bf16x8_t, wb[p * 64 + lane]);
+#ifndef X3F_SETPRIO
+#define X3F_SETPRIO 0  // A/B builds: 1 = the wave raises its issue priority for the MFMA phase of a step (s_setprio 3 ... 0)
+#endif
+        if (X3F_SETPRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int jt = 0; jt < NTW; ++jt) {
           if (jt + 1 < NTW) {
@@ -893,6 +897,7 @@ __global__ __launch_bounds__(64 * X3_WPB, (NTW <= 2 && !DS) ? 5 : X3_WAVES) void
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (X3F_SETPRIO) __builtin_amdgcn_s_setprio(0);
       }
       if (!ok1) break;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

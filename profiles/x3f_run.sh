@@ -1,10 +1,4 @@
 cd $GRAFT_REPO_ROOT
 ulimit -c 0
-mkdir -p gpurun_out/s2n
-PP_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --points 2000000 --grid 4 --steps 5 --warmup 2 --no-cpu-baseline --no-checks 2>gpurun_out/s2n/err.txt | tail -1 > gpurun_out/s2n/gloo2_ahead.json
-python - <<'PY'
-import json
-g=json.load(open("gpurun_out/s2n/gloo2_ahead.json")); c=g["config"]
-print("n_gpus", g["n_gpus"], "ms", g["ms_per_step"], "ahead", c["backbone_ahead"], "voxels/batch", c["batch_voxels"], "multi", c["multi_gpu"])
-PY
-tail -3 gpurun_out/s2n/err.txt
+bash profiles/ab_x3_libs.sh r06_x3f_setprio.txt "4:64:64,2:32:32,2:96:32,1:64:16,8:64:64,4:128:48,1:64:64:up" g_base g_prio g_base g_prio > /dev/null 2>&1
+grep -v "^ts" gpurun_out/r06_x3f_setprio.txt | paste - - | head
