@@ -23,6 +23,9 @@ from . import ops  # noqa: E402
 
 # TileRunner.run(next_batch=...): build the next batch's coordinate manager during the current batch (PP_INPUT_PREFETCH=0: off)
 INPUT_PREFETCH = os.environ.get("PP_INPUT_PREFETCH", "1") != "0"
+# TileRunner(backbone_ahead=True): the proposal scorer's convolutions wait for the backbone that runs ahead (PP_AHEAD_SCORER_WAIT=0,
+# A/B runs: both convolution streams at once)
+SCORER_WAITS = os.environ.get("PP_AHEAD_SCORER_WAIT", "1") != "0"
 
 
 def instance_labels_per_tile(res, batch, n_tiles, nms_threshold=0.3, min_cluster_points=10, min_score=0.5):
@@ -413,7 +416,7 @@ class TileRunner:
             # stage B below belongs to THIS batch again; the scorer's convolutions start when the backbone ahead is through
             self.model.input, self.model.raw_pos, self.model.labels = ctx.input, ctx.raw_pos, ctx.labels
             scorer = getattr(self.model, "ScorerUnet", None)
-            if scorer is not None:
+            if scorer is not None and SCORER_WAITS:
                 scorer._before_first_conv = lambda ev=nctx.done, dv=dev: torch.cuda.current_stream(dv).wait_event(ev)
         elif prefetchable:
             self.model.Backbone.prepare_input(Data(coords=next_batch["coords"], batch=next_batch["batch"]))
