@@ -839,8 +839,19 @@ def bf16_conv_supported(c0, c1, K, nbr_given=True):
 _AB_T4 = tuple(int(v) for v in os.environ["PP_AB_T4"].split(",")) if os.environ.get("PP_AB_T4") else None
 
 
-def spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
-               row_order=None, bf16=False, variant=None, shortcut=None):
+_CONV_LOCK = threading.Lock()
+
+
+def spconv_fwd(*args, **kwargs):
+    """pp_spconv_fwd and its variants (see _spconv_fwd).  The library reads ONE split-K scratch pointer at launch time and this
+    module registers the buffer of the launching stream right before the launch: the pair is atomic, because two host threads
+    may launch convolutions on two streams (scene.TileRunner's backbone ahead in its own thread)."""
+    with _CONV_LOCK:
+        return _spconv_fwd(*args, **kwargs)
+
+
+def _spconv_fwd(in0, packed, nbr, n_out, cout, K, in1=None, scale=None, shift=None, relu=False, residual=None, out=None,
+                row_order=None, bf16=False, variant=None, shortcut=None):
     """variant = (rows_per_wave, pipeline, split_k): an explicit variant of the pipelined kernel through
     pp_spconv_fwd_ex (tests / A-B runs); None = the library's per-shape choice.  row_order: slot order of a
     cross-level map (nbr is slot-major then).  shortcut = (x [n_out, c], packed 1x1 weights, scale, shift): the 1x1

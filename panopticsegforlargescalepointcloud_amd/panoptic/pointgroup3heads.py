@@ -173,16 +173,18 @@ class PointGroup3heads(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
-    def backbone_and_heads(self):
+    def backbone_and_heads(self, data=None):
         """Sparse U-Net + the three heads.  Returns (features [N,16], semantic log-probs, offsets, embeddings,
-        predicted labels [N] int64)."""
+        predicted labels [N] int64).  data: the batch to run instead of the one `set_input` stored (scene.TileRunner runs the
+        NEXT batch's backbone from a thread of its own while `self.input` still belongs to the batch being grouped)."""
         has_off, has_emb = "Offset" in self.HEADS, "Embed" in self.HEADS
+        inp = self.input if data is None else data
         if not self.training and not torch.is_grad_enabled() and self.Backbone.output_nc == 16 and FUSE_HEADS:
             # inference: the backbone's features stay in the coordinate manager's row order and ALL heads run as one pass
             # that reads row inv_perm[i] for point i -- no un-permuting gather of the features, one read of them instead of
             # three; `feats` is handed on as "rows inv_perm of the internal matrix" (the scorer composes it with its own
             # proposal gather)
-            out = self.Backbone(self.input, internal_order=True)
+            out = self.Backbone(inp, internal_order=True)
             cm = self.Backbone.input.coordinate_manager
             specs = [head_spec(self.Semantic, True, True)] + ([head_spec(self.Offset)] if has_off else []) \
                 + ([head_spec(self.Embed)] if has_emb else [])
@@ -192,7 +194,7 @@ class PointGroup3heads(nn.Module):
             emb = res[1 + int(has_off)][0] if has_emb else None
             feats = out.x if cm.inv_perm is None else ME.GatheredRows(out.x, cm.inv_perm)
             return feats, sem, off, emb, pred
-        feats = self.Backbone(self.input).x
+        feats = self.Backbone(inp).x
         if not self.training and not torch.is_grad_enabled():
             sem, pred = fused_head(self.Semantic, feats, log_softmax=True, want_argmax=True)
             off = fused_head(self.Offset, feats) if has_off else None

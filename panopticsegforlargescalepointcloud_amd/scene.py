@@ -284,8 +284,8 @@ def assemble_scene(results, tile_order, n_scene_points, num_classes):
 
 # ------------------------------------------------------------------------------------------------ the hot path over tiles
 class _BackboneAhead:
-    """what stage A (set_input + backbone + heads) of a batch leaves for its stage B (grouping, scorer, NMS)"""
-    __slots__ = ("key", "input", "raw_pos", "labels", "outs", "done", "hold")
+    """what stage A (backbone + heads) of a batch leaves for its stage B (grouping, scorer, NMS)"""
+    __slots__ = ("key", "data", "outs", "done", "hold", "thread", "err")
 
 
 def _batch_key(b):
@@ -301,19 +301,17 @@ class TileRunner:
     that leave most of the chip idle, profiles/r06_kt/timeline.txt); the scorer's own convolutions wait for that backbone (two
     saturating convolution streams only take turns).  Results are those of the one-batch-at-a-time order bit for bit
     (tests/test_scene_gpu.py::test_backbone_ahead_does_not_change_results); the batch after next gets its coordinate manager
-    built meanwhile (`after_next`), as `next_batch` does without the option."""
+    built meanwhile (`after_next`), as `next_batch` does without the option.
+    ahead_thread=True (PP_AHEAD_THREAD): the backbone ahead is ENQUEUED by a host thread of its own as well -- its ~250 launches
+    (a few ms of Python) overlap this batch's host reads instead of preceding them."""
 
-    def __init__(self, model, device, epoch=10 ** 6, stage_timing=False, backbone_ahead=False):
+    def __init__(self, model, device, epoch=10 ** 6, stage_timing=False, backbone_ahead=False, ahead_thread=None):
         self.model, self.device, self.epoch = model, device, epoch
         self.stage_timing = stage_timing
         self.stage_ms = {}
         self.backbone_ahead = bool(backbone_ahead) and not stage_timing
+        self.ahead_thread = (os.environ.get("PP_AHEAD_THREAD", "0") == "1") if ahead_thread is None else bool(ahead_thread)
         self._ahead = None
-        # The stream the backbone ahead runs on is created AND USED here, before the model's first pass uses its side / preparation /
-        # clustering streams: a process' HIP streams share a few hardware queues, bound in order of first use, and a stream first used
-        # late landed on a queue where the two batches ran one after the other (profiles/r06_backbone_ahead.txt: 108.6 ms per step
-        # when the option was switched on after a few serial steps, 104.2 from the start, 105.4 either way with this first submission).
-        # Only with the option: the extra stream shifts the other streams' queues (PP_AHEAD_PRIORITY: its HIP priority, A/B runs)
         # PP_STREAM_ORDER (A/B runs): first-use order of the model's streams, letters S (map prefetch), P / Q (the two preparation
         # streams), C (clustering / NMS side stream) -- e.g. "SCPQ"; unset: whatever order the first pass uses them in (P, Q, C, S)
         order = os.environ.get("PP_STREAM_ORDER", "")
@@ -333,6 +331,11 @@ class TileRunner:
                 if st is not None:
                     with torch.cuda.stream(st):
                         torch.zeros(1, device=device)
+        # The stream the backbone ahead runs on is created AND USED here, before the model's first pass uses its side / preparation /
+        # clustering streams: a process' HIP streams share a few hardware queues, bound in order of first use, and a stream first used
+        # late landed on a queue where the two batches ran one after the other (profiles/r06_backbone_ahead.txt: 108.6 ms per step
+        # when the option was switched on after a few serial steps, 104.2 from the start, 105.4 either way with this first submission).
+        # Only with the option: the extra stream shifts the other streams' queues (PP_AHEAD_PRIORITY: its HIP priority, A/B runs)
         self._ahead_stream = None
         if self.backbone_ahead and torch.cuda.is_available() and torch.device(device).type == "cuda":
             self._ahead_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
@@ -349,22 +352,71 @@ class TileRunner:
             return now
         return t0
 
-    def _stage_a(self, batch_np):
-        """set_input + backbone + heads of a batch on the current stream"""
+    def _data(self, batch_np):
         dev = self.device
         to = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)  # noqa: E731
-        data = Data(pos=to(batch_np["pos"]), coords=to(batch_np["coords"]), batch=to(batch_np["batch"]), x=to(batch_np["x"]))
-        self.model.set_input(data, dev)
+        return Data(pos=to(batch_np["pos"]), coords=to(batch_np["coords"]), batch=to(batch_np["batch"]), x=to(batch_np["x"]))
+
+    def _stage_a(self, batch_np):
+        """backbone + heads of a batch on the current stream, WITHOUT touching the model's per-batch attributes (`input`, `raw_pos`,
+        `labels` may still belong to the batch another stage is grouping): `set_input(record.data)` installs them for stage B"""
         c = _BackboneAhead()
-        c.key, c.outs = _batch_key(batch_np), self.model.backbone_and_heads()
-        c.input, c.raw_pos, c.labels = self.model.input, self.model.raw_pos, self.model.labels
-        c.done = c.hold = None
+        c.key, c.data = _batch_key(batch_np), self._data(batch_np).to(self.device)
+        c.outs = self.model.backbone_and_heads(c.data)
+        c.done = c.hold = c.thread = c.err = None
         return c
+
+    def _launch_ahead(self, next_batch, after_next, main):
+        """stage A of the next batch on the ahead stream (from this thread, or from one of its own), then the preparation of the
+        batch after it"""
+        sa = self._ahead_stream
+        if sa is None:
+            sa = self._ahead_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
+        sa.wait_stream(main)  # (the batch tensors and everything this stream has freed so far)
+        rec = _BackboneAhead()
+        rec.key, rec.data, rec.outs, rec.hold, rec.err = _batch_key(next_batch), None, None, None, None
+        rec.done = torch.cuda.Event()
+        dev = self.device
+
+        def work():
+            try:
+                with torch.no_grad(), torch.cuda.device(dev):   # (grad mode and current device are per thread)
+                    with torch.cuda.stream(sa):
+                        c = self._stage_a(next_batch)
+                        rec.done.record(sa)
+                    rec.data, rec.outs = c.data, c.outs
+                    f = c.outs[0]
+                    rec.hold = [t for t in ((f.base, f.index) if hasattr(f, "base") else (f,)) + tuple(c.outs[1:]) if torch.is_tensor(t)]
+                    if after_next is not None:
+                        self.model.Backbone.prepare_input(Data(coords=after_next["coords"], batch=after_next["batch"]))
+            except BaseException as e:  # (re-raised by the thread that joins)
+                rec.err = e
+
+        if self.ahead_thread:
+            import threading
+            rec.thread = threading.Thread(target=work, name="pp-backbone-ahead", daemon=True)
+            rec.thread.start()
+        else:
+            rec.thread = None
+            work()
+            if rec.err is not None:
+                raise rec.err
+        return rec
+
+    @staticmethod
+    def _join(rec):
+        if rec.thread is not None:
+            rec.thread.join()
+            rec.thread = None
+        if rec.err is not None:
+            err, rec.err = rec.err, None
+            raise err
 
     def drain(self):
         """wait for (and drop) a backbone that was launched ahead and never consumed"""
         a, self._ahead = self._ahead, None
-        if a is not None and a.done is not None:
+        if a is not None:
+            self._join(a)
             a.done.synchronize()
 
     @torch.no_grad()
@@ -384,40 +436,34 @@ class TileRunner:
             t0 = time.perf_counter()
         main = torch.cuda.current_stream(dev)
         ctx, self._ahead = self._ahead, None
+        if ctx is not None:
+            self._join(ctx)
         if ctx is not None and ctx.key == _batch_key(batch_np):
             # stage A of this batch ran ahead on its own stream: this stream takes its tensors over
             main.wait_event(ctx.done)
             for t in ctx.hold:
                 t.record_stream(main)
-            self.model.input, self.model.raw_pos, self.model.labels = ctx.input, ctx.raw_pos, ctx.labels
         else:
-            if ctx is not None and ctx.done is not None:
+            if ctx is not None:
                 ctx.done.synchronize()  # (another batch than announced: let its launches finish before its tensors are dropped)
             ctx = self._stage_a(batch_np)
+        self.model.set_input(ctx.data, dev)   # (stage B reads the batch through the model's attributes)
         feats, sem, off, emb, pred = ctx.outs
         t0 = self._tick("backbone+heads", t0)
         prefetchable = next_batch is not None and INPUT_PREFETCH
         if prefetchable and not all(torch.is_tensor(next_batch[k]) and next_batch[k].is_cuda for k in ("coords", "batch")):
             raise ValueError("next_batch must hold device tensors (the build reads them on its own stream)")
+        nctx = None
         if prefetchable and self.backbone_ahead and not self.stage_timing:
-            if self._ahead_stream is None:
-                self._ahead_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PP_AHEAD_PRIORITY", "0")))
-            sa = self._ahead_stream
-            sa.wait_stream(main)  # (the batch tensors and everything this stream has freed so far)
-            with torch.cuda.stream(sa):
-                nctx = self._stage_a(next_batch)
-                nctx.done = torch.cuda.Event()
-                nctx.done.record(sa)
-            f = nctx.outs[0]
-            nctx.hold = [t for t in ((f.base, f.index) if hasattr(f, "base") else (f,)) + tuple(nctx.outs[1:]) if torch.is_tensor(t)]
-            self._ahead = nctx
-            if after_next is not None:
-                self.model.Backbone.prepare_input(Data(coords=after_next["coords"], batch=after_next["batch"]))
-            # stage B below belongs to THIS batch again; the scorer's convolutions start when the backbone ahead is through
-            self.model.input, self.model.raw_pos, self.model.labels = ctx.input, ctx.raw_pos, ctx.labels
+            nctx = self._ahead = self._launch_ahead(next_batch, after_next, main)
+            # the scorer's convolutions start when the backbone ahead is through (its record exists once its thread has enqueued it)
             scorer = getattr(self.model, "ScorerUnet", None)
             if scorer is not None and SCORER_WAITS:
-                scorer._before_first_conv = lambda ev=nctx.done, dv=dev: torch.cuda.current_stream(dv).wait_event(ev)
+                def wait_for_backbone(rec=nctx, dv=dev):
+                    if rec.thread is not None:
+                        rec.thread.join()
+                    torch.cuda.current_stream(dv).wait_event(rec.done)
+                scorer._before_first_conv = wait_for_backbone
         elif prefetchable:
             self.model.Backbone.prepare_input(Data(coords=next_batch["coords"], batch=next_batch["batch"]))
         if override is not None:

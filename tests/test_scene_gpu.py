@@ -96,8 +96,9 @@ def test_prepared_next_batch_does_not_change_results():
         scene_mod.INPUT_PREFETCH = True
 
 
-def test_backbone_ahead_does_not_change_results():
-    """TileRunner(backbone_ahead=True): the NEXT batch's backbone + heads run on a stream of their own beside this batch's grouping
+@pytest.mark.parametrize("ahead_thread", [False, True])
+def test_backbone_ahead_does_not_change_results(ahead_thread):
+    """TileRunner(backbone_ahead=True) -- enqueued by the calling thread or (ahead_thread) by a host thread of its own: the NEXT batch's backbone + heads run on a stream of their own beside this batch's grouping
     and scorer front end, the batch after next gets its coordinate manager prepared, the scorer's convolutions wait for the
     backbone ahead.  Over a stream of three different batches (twice round, then with a batch that was NOT the announced one) the
     labels, scores, semantic outputs and counts are those of one batch at a time, bit for bit; the real head outputs (no
@@ -122,7 +123,7 @@ def test_backbone_ahead_does_not_change_results():
     serial = TileRunner(model, dev)
     want = [out(serial.run(b, n, override=ov)) for b, ov, n in batches]
     want_own = out(serial.run(batches[1][0], batches[1][2]))   # the network's OWN head outputs feed the grouping
-    ahead = TileRunner(model, dev, backbone_ahead=True)
+    ahead = TileRunner(model, dev, backbone_ahead=True, ahead_thread=ahead_thread)
     order = [0, 1, 2, 0, 1, 2, 0]
     for j, i in enumerate(order):
         nxt = batches[order[j + 1]][0] if j + 1 < len(order) else None
