@@ -711,9 +711,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                # per kernel class (traffic.json "classes"): fwd3 / x3 gather in 64-byte requests, counted in full, and stream their
-                # kernel map with wide loads, counted half (+ 0.5 x map bytes); x3f fetches everything -- rows as whole 128-byte
-                # lines, weights, map -- in 128-byte requests: 2 x its raw counter (round 6)
+                # per kernel class (traffic.json "classes"): fwd3 gathers 64-byte rows, counted in full, and streams its kernel map
+                # with wide loads, counted half (+ 0.5 x map bytes); x3f / x3 fetch rows, weights and map in 128-byte requests:
+                # 2 x the raw counter (round 6)
                 tot_tr = tot_lo = tot_hi = 0.0
                 n_tot = 0
                 for fam, pf in prof.get("by_family", {}).items():
@@ -722,9 +722,11 @@ def main():
                         continue
                     n_ = pf["launches"]
                     w_c, f_c, m_c = cj["write_bytes_per_launch"], cj["fetch_raw_bytes_per_launch"], pf["map_bytes"] / n_
-                    if fam == "x3f":
-                        # (lower bound: every request tallied in full -- the L2 request counters of one layer on both kernels,
-                        # profiles/r06_pmc_conv_x3f_c64.md vs r05_pmc_conv_x3_c64.md, differ by 10 %, not by 2 x)
+                    if fam in ("x3f", "x3"):
+                        # both split-operand kernels reach the L2 with 128-byte requests (the register-gather kernel's two 64-byte
+                        # pieces of a line merge before the L2: profiles/r06_pmc_fetch_x3f.md -- L2 requests x 128 bytes = rows +
+                        # staged weights on both, equal memory-side request counts), a miss is a 128-byte fill tallied at 64 bytes.
+                        # (lower bound: round 5's rule, every request tallied in full + half the map)
                         tr, lo, hi = w_c + 2.0 * f_c, w_c + f_c + 0.5 * m_c, w_c + 2.0 * f_c
                     else:
                         tr, lo, hi = w_c + f_c + 0.5 * m_c, w_c + f_c + 0.5 * m_c, w_c + 1.059 * f_c + 0.5 * m_c
@@ -737,9 +739,9 @@ def main():
                     roof["map_bytes_per_launch"] = prof["map_bytes"] / max(prof["launches"], 1)
                     roof["traffic_over_algorithmic"] = roof["traffic"] / (prof["bytes"] / max(prof["launches"], 1))
                 roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc passes of this command, per kernel class: WRITE_SIZE + "
-                                          "FETCH_SIZE raw + 0.5 x kernel-map bytes for k_spconv_fwd3 / k_spconv_x3, WRITE_SIZE + 2 x "
-                                          "FETCH_SIZE raw for k_spconv_x3f whose requests are whole 128-byte lines; calibration "
-                                          "profiles/r05_fetch_calibration.md)")
+                                          "FETCH_SIZE raw + 0.5 x kernel-map bytes for k_spconv_fwd3, WRITE_SIZE + 2 x FETCH_SIZE raw for "
+                                          "k_spconv_x3f / k_spconv_x3 whose L2 requests are whole 128-byte lines; calibration "
+                                          "profiles/r05_fetch_calibration.md, profiles/r06_pmc_fetch_x3f.md)")
             except Exception:
                 pass
         roof["alg_bytes_per_launch"] = prof["bytes"] / max(prof["launches"], 1)
